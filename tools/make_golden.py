@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (authoring container only).
+
+The reference's Python never travels to the GPU box; this script imports
+``/root/reference/src/mot_neural_solver/models/mpn.py`` here, drives it on inputs from the
+repo's own deterministic generator (``mpntrackseg_amd/synth.py``) and stores the outputs as
+small fixtures.  The only thing injected is a stand-in for the un-vendored third-party
+``torch_scatter`` 2.0.4 package (``environment.yml:146``), restating its documented semantics with
+stock torch ops (scatter_add_ / clamp / scatter_reduce amax, empty segments -> 0).
+
+Fixtures:
+  g1_tiny_{sum,mean,max}.npz   full ``MOTMPNet.forward`` (mask branch included) on N=60/E=800, default
+                               dims with node_in_dim=64; inputs, weights, logits of every step, final
+                               x/e, and autograd gradients of loss = sum_steps sum_edges logit*r.
+  g4_structure.npz             isolated nodes, only-past / only-future nodes, 3 batched sub-graphs
+                               (interleaved halves), self loops, ties at 0 under max.
+  g5_modules.npz               MetaLayer.forward single step and node_agg_fn alone.
+  g2_cfgA_{agg}.npz            cfg-A (500/4000/d32/L6): logits [6,4000]; inputs regenerated (checksums).
+  g3_cfgB_{agg}.npz            cfg-B (5000/50000/d128/L12): logits at 4096 fixed edges x 12 steps +
+                               per-step sum / abs-sum / max checksums.
+  g0_l0.npz                    num_enc_steps == 0 special case (mpn.py:387-389).
+
+Usage:  python tools/make_golden.py [--only g1,g2,...]
+"""
+import sys
+sys.dont_write_bytecode = True  # never leave __pycache__ inside the read-only reference tree
+import argparse
+import os
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from mpntrackseg_amd import synth  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+# ------------------------------------------------------------------ torch_scatter 2.0.4 stand-in
+def _bcast(index, src, dim):
+    if index.dim() == 1:
+        shape = [1] * src.dim()
+        shape[dim] = -1
+        index = index.view(shape)
+    return index.expand_as(src)
+
+
+def _scatter_add(src, index, dim=-1, out=None, dim_size=None):
+    dim = dim % src.dim()
+    size = list(src.size())
+    size[dim] = dim_size if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
+    out = torch.zeros(size, dtype=src.dtype, device=src.device)
+    return out.scatter_add_(dim, _bcast(index, src, dim), src)
+
+
+def _scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+    dim = dim % src.dim()
+    out = _scatter_add(src, index, dim, None, dim_size)
+    ones = torch.ones(index.size(), dtype=src.dtype, device=src.device)
+    count = _scatter_add(ones, index, 0, None, out.size(dim)).clamp_(1)
+    shape = [1] * out.dim()
+    shape[dim] = -1
+    return out / count.view(shape)
+
+
+def _scatter_max(src, index, dim=-1, out=None, dim_size=None):
+    dim = dim % src.dim()
+    size = list(src.size())
+    size[dim] = dim_size if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
+    out = torch.zeros(size, dtype=src.dtype, device=src.device)
+    if src.numel():
+        out = out.scatter_reduce(dim, _bcast(index, src, dim), src, reduce="amax", include_self=False)
+    return out, None
+
+
+def _scatter_min(src, index, dim=-1, out=None, dim_size=None):
+    raise NotImplementedError
+
+
+def _scatter_softmax(src, index, dim=-1, eps=1e-12):
+    dim = dim % src.dim()
+    n = int(index.max()) + 1 if index.numel() else 0
+    idx = _bcast(index, src, dim)
+    mx = torch.zeros([n] + list(src.shape[1:]), dtype=src.dtype).scatter_reduce(
+        dim, idx, src, reduce="amax", include_self=False)
+    ex = (src - mx.gather(dim, idx)).exp()
+    sm = _scatter_add(ex, index, dim, None, n)
+    return ex / (sm.gather(dim, idx) + eps)
+
+
+def install_shim():
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_add, ts.scatter_mean, ts.scatter_max, ts.scatter_min = (
+        _scatter_add, _scatter_mean, _scatter_max, _scatter_min)
+    comp = types.ModuleType("torch_scatter.composite")
+    comp.scatter_softmax = _scatter_softmax
+    ts.composite = comp
+    sys.modules["torch_scatter"] = ts
+    sys.modules["torch_scatter.composite"] = comp
+
+
+def import_reference():
+    install_shim()
+    sys.path.insert(0, "/root/reference/src")
+    from mot_neural_solver.models import mpn  # noqa
+    return mpn
+
+
+# mask-branch dicts of configs/tracking_cfg.yaml:168-218 (needed to construct the full MOTMPNet)
+MASK_PARAMS = {
+    "node_ext_encoder_feats_dict": dict(input_dim=256, dims=[128, 32], kernel_sizes=[1, 1], strides=[1, 1],
+                                        paddings=[0, 0], dropout_p=0, use_batchnorm=False),
+    "attention_model_feats_dict": dict(fc_dims=[16, 1], dropout_p=0, use_batchnorm=False),
+    "node_ext_model_feats_dict": dict(dims=[96, 32], kernel_sizes=[3, 3], strides=[1, 1], paddings=[1, 1],
+                                      dropout_p=0, use_batchnorm=False),
+    "mask_model_feats_dict": {
+        "feature_encoder_feats_dict": dict(input_dim=256, dims=[32], kernel_sizes=[1], strides=[1], paddings=[0],
+                                           dropout_p=0, use_batchnorm=False),
+        "mask_head_feats_dict": dict(input_dim=64, dims=[64, 64, 64], kernel_sizes=[3, 3, 3], strides=[1, 1, 1],
+                                     paddings=[1, 1, 1], dropout_p=0, use_batchnorm=False),
+        "mask_predictor_feats_dict": dict(input_dim=64, dims=[64, 64, 64, 1], kernel_sizes=[2, 3, 2, 1],
+                                          strides=[2, 1, 2, 1], paddings=[0, 1, 0, 0],
+                                          transposed=[True, False, True, False]),
+    },
+}
+
+
+def build_reference_model(mpn, params, weights):
+    full = dict(params)
+    full.update(MASK_PARAMS)
+    torch.manual_seed(0)
+    model = mpn.MOTMPNet(full)
+    sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(not any(m.startswith(p) for p in ("encoder.", "MPNet.", "classifier.")) for m in missing), missing
+    return model
+
+
+def ref_hot_path(model, x, edge_index, edge_attr, want_all=True):
+    """Drive the REFERENCE modules (encoder / MPNet / classifier) with the loop of mpn.py:355-381,
+    leaving out the x_ext lines.  Verified equal to the full forward in g1 below."""
+    e, xn = model.encoder(edge_attr, x)
+    e0, x0 = e, xn
+    logits = []
+    for _ in range(model.num_enc_steps):
+        e = torch.cat((e0, e), dim=1)
+        xn = torch.cat((x0, xn), dim=1)
+        xn, e = model.MPNet(xn, edge_index, e)
+        dec, _ = model.classifier(e)
+        logits.append(dec)
+    if model.num_enc_steps == 0:
+        dec, _ = model.classifier(e)
+        logits.append(dec)
+    return logits, xn, e
+
+
+class Data:
+    pass
+
+
+def gen_g1(mpn):
+    for agg in ("sum", "mean", "max"):
+        N, E, L, nin = 60, 800, 4, 64
+        params = synth.model_params(32, L, agg, num_class_steps=3, node_in_dim=nin)
+        W = synth.make_weights(params, seed=7)
+        g = synth.make_graph(N, E, T=10, seed=1, node_in_dim=nin)
+        model = build_reference_model(mpn, params, W)
+        d = Data()
+        # reference input layout: x is [N, C, 8, 4] before the avg-pool (seq_processor.py:445)
+        x4 = synth.normal(3, (N, nin, 8, 4), stream=9)
+        d.x = torch.from_numpy(x4)
+        d.x_ext = torch.from_numpy(synth.normal(3, (N, 256, 14, 14), stream=10, std=0.5))
+        d.edge_index = torch.from_numpy(g["edge_index"])
+        d.edge_attr = torch.from_numpy(g["edge_attr"])
+        with torch.no_grad():
+            out = model(d)
+        full_logits = [t.numpy() for t in out["classified_edges"]]
+        assert len(full_logits) == 3 and full_logits[0].shape == (E, 1)
+
+        # hot-path driver on the pooled input, with autograd
+        xp = d.x.mean(dim=(2, 3)).clone().requires_grad_(True)
+        ea = d.edge_attr.clone().requires_grad_(True)
+        logits, xL, eL = ref_hot_path(model, xp, d.edge_index, ea)
+        for a, b in zip(full_logits, logits[-3:]):
+            assert np.array_equal(a, b.detach().numpy()), "driver loop != MOTMPNet.forward"
+        r = torch.from_numpy(synth.normal(11, (L, E), stream=0))
+        loss = sum((logits[s].view(-1) * r[s]).sum() for s in range(L))
+        hot = {k: p for k, p in model.named_parameters() if k in W}
+        grads = torch.autograd.grad(loss, [xp, ea] + list(hot.values()))
+        rec = {
+            "agg": agg, "N": N, "E": E, "L": L, "d": 32, "node_in_dim": nin,
+            "x4": x4, "x_pooled": xp.detach().numpy(), "edge_index": g["edge_index"], "edge_attr": g["edge_attr"],
+            "logits": np.stack([t.detach().numpy().reshape(-1) for t in logits]),
+            "x_final": xL.detach().numpy(), "e_final": eL.detach().numpy(),
+            "r": r.numpy(), "grad_x": grads[0].numpy(), "grad_edge_attr": grads[1].numpy(),
+        }
+        for k, v in W.items():
+            rec["W:" + k] = v
+        for k, gr in zip(hot.keys(), grads[2:]):
+            rec["G:" + k] = gr.numpy()
+        np.savez_compressed(os.path.join(GOLD, f"g1_tiny_{agg}.npz"), **rec)
+        print("g1", agg, "max|logit|", float(np.abs(rec["logits"]).max()))
+
+
+def structure_graph():
+    """Hand-built corner cases.  Sub-graph 0 (nodes 0..7): node 0 isolated, node 1 only future
+    neighbours, node 7 only past neighbours, one self loop (3,3) -- contributes to the edge update but
+    to neither aggregate (mpn.py:85,91).  Sub-graphs 1 and 2 are generated and batched behind it so
+    the (i<j) / (j<i) halves interleave."""
+    lo = np.array([1, 1, 2, 2, 4, 5, 6, 2], dtype=np.int64)
+    hi = np.array([2, 4, 5, 7, 7, 6, 7, 6], dtype=np.int64)
+    ei = np.stack([np.concatenate([lo, hi, [3]]), np.concatenate([hi, lo, [3]])]).astype(np.int64)
+    nin = 64
+    g0 = {"x": synth.normal(21, (8, nin), stream=0), "edge_index": ei,
+          "edge_attr": synth.normal(21, (ei.shape[1], 6), stream=1), "frame": np.arange(8)}
+    g1 = synth.make_graph(20, 60, T=5, seed=22, node_in_dim=nin)
+    g2 = synth.make_graph(12, 30, T=4, seed=23, node_in_dim=nin)
+    return synth.batch_graphs([g0, g1, g2])
+
+
+def gen_g4(mpn):
+    g = structure_graph()
+    rec = {"x": g["x"], "edge_index": g["edge_index"], "edge_attr": g["edge_attr"]}
+    for agg in ("sum", "mean", "max"):
+        params = synth.model_params(32, 3, agg, node_in_dim=64)
+        W = synth.make_weights(params, seed=8)
+        model = build_reference_model(mpn, params, W)
+        with torch.no_grad():
+            logits, xL, eL = ref_hot_path(model, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
+                                          torch.from_numpy(g["edge_attr"]))
+        rec[f"logits_{agg}"] = np.stack([t.numpy().reshape(-1) for t in logits])
+        rec[f"x_final_{agg}"] = xL.numpy()
+        rec[f"e_final_{agg}"] = eL.numpy()
+    # empty graph (E = 0)
+    params = synth.model_params(32, 2, "sum", node_in_dim=64)
+    model = build_reference_model(mpn, params, synth.make_weights(params, seed=8))
+    with torch.no_grad():
+        logits, xL, eL = ref_hot_path(model, torch.from_numpy(g["x"][:5]), torch.zeros((2, 0), dtype=torch.int64),
+                                      torch.zeros((0, 6)))
+    rec["empty_x_final"] = xL.numpy()
+    assert logits[0].shape == (0, 1)
+    np.savez_compressed(os.path.join(GOLD, "g4_structure.npz"), **rec)
+    print("g4 ok, E =", g["edge_index"].shape[1])
+
+
+def gen_g5(mpn):
+    rec = {}
+    g = synth.make_graph(40, 300, T=6, seed=31, node_in_dim=64)
+    ei = torch.from_numpy(g["edge_index"])
+    for agg in ("sum", "mean", "max"):
+        params = synth.model_params(32, 1, agg, node_in_dim=64)
+        W = synth.make_weights(params, seed=9)
+        model = build_reference_model(mpn, params, W)
+        x = torch.from_numpy(synth.normal(32, (40, 64), stream=0))   # [N, 2dn]
+        e = torch.from_numpy(synth.normal(32, (300, 32), stream=1))  # [E, 2de]
+        with torch.no_grad():
+            xo, eo = model.MPNet(x, ei, e)                           # MetaLayer.forward mpn.py:33-54
+            m = torch.from_numpy(np.maximum(synth.normal(33, (300, 32), stream=2), 0))  # post-ReLU: ties at 0
+            row = ei[0]
+            ao = model.MPNet.node_model.node_agg_fn(m, row, 40)      # mpn.py:266-273
+        rec.update({f"meta_x_{agg}": xo.numpy(), f"meta_e_{agg}": eo.numpy(), f"agg_{agg}": ao.numpy()})
+    rec.update({"x_in": x.numpy(), "e_in": e.numpy(), "edge_index": g["edge_index"], "msg": m.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "g5_modules.npz"), **rec)
+    print("g5 ok")
+
+
+def gen_g0(mpn):
+    params = synth.model_params(32, 0, "sum", num_class_steps=0, node_in_dim=64)
+    W = synth.make_weights(params, seed=7)
+    g = synth.make_graph(30, 100, T=5, seed=2, node_in_dim=64)
+    model = build_reference_model(mpn, params, W)
+    d = Data()
+    d.x = torch.from_numpy(g["x"]).view(30, 64, 1, 1)
+    d.x_ext = torch.from_numpy(synth.normal(3, (30, 256, 14, 14), stream=10, std=0.5))
+    d.edge_index = torch.from_numpy(g["edge_index"])
+    d.edge_attr = torch.from_numpy(g["edge_attr"])
+    with torch.no_grad():
+        out = model(d)
+    assert len(out["classified_edges"]) == 1
+    np.savez_compressed(os.path.join(GOLD, "g0_l0.npz"), logits=out["classified_edges"][0].numpy().reshape(-1))
+    print("g0 ok")
+
+
+def gen_cfg(mpn, name, tag, sample=None):
+    c = synth.CONFIGS[name]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    for agg in ("sum", "mean", "max"):
+        params = synth.model_params(c["d"], c["L"], agg)
+        W = synth.make_weights(params, seed=7)
+        model = build_reference_model(mpn, params, W)
+        with torch.no_grad():
+            logits, xL, eL = ref_hot_path(model, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
+                                          torch.from_numpy(g["edge_attr"]))
+        lg = np.stack([t.numpy().reshape(-1) for t in logits])          # [L, E]
+        rec = {"N": c["N"], "E": c["E"], "d": c["d"], "L": c["L"], "agg": agg,
+               "cs_x": np.uint64(synth.checksum(g["x"])), "cs_edge_index": np.uint64(synth.checksum(g["edge_index"])),
+               "cs_edge_attr": np.uint64(synth.checksum(g["edge_attr"])),
+               "cs_weights": np.uint64(synth.checksum(np.concatenate([v.ravel() for v in W.values()]))),
+               "step_sum": lg.astype(np.float64).sum(1), "step_abssum": np.abs(lg).astype(np.float64).sum(1),
+               "step_max": np.abs(lg).max(1)}
+        if sample is None:
+            rec["logits"] = lg
+        else:
+            ids = (synth.uniform01(99, sample, stream=0) * c["E"]).astype(np.int64)
+            rec["edge_ids"] = ids
+            rec["logits"] = lg[:, ids]
+            rec["x_final_rows"] = xL.numpy()[:64]
+        np.savez_compressed(os.path.join(GOLD, f"{tag}_{agg}.npz"), **rec)
+        print(tag, agg, "max|logit| per step", rec["step_max"][[0, -1]])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="g0,g1,g4,g5,g2,g3")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(GOLD, exist_ok=True)
+    mpn = import_reference()
+    only = set(args.only.split(","))
+    if "g0" in only: gen_g0(mpn)
+    if "g1" in only: gen_g1(mpn)
+    if "g4" in only: gen_g4(mpn)
+    if "g5" in only: gen_g5(mpn)
+    if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
+    if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
+
+
+if __name__ == "__main__":
+    main()
