@@ -1,0 +1,21 @@
+# Builds the C-ABI library (hand-written HIP for gfx950) and nothing else.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := mpntrackseg_amd/csrc
+SRCS := $(CSRC)/gemm.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip
+OBJS := $(SRCS:.hip=.o)
+LIB := $(CSRC)/libmpnhip.so
+CXXFLAGS := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/mpnhip.h
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

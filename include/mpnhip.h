@@ -1,0 +1,164 @@
+/*
+ * mpnhip.h -- C ABI of the MI355X-native MPNTrackSeg message-passing hot path.
+ *
+ * The reference (ocetintas/MPNTrackSeg) has no FFI: the path sits behind a Python nn.Module API.
+ * Each entry point below names the reference interface it replaces (paths relative to
+ * /root/reference/src/mot_neural_solver/); INTEGRATION.md shows the ctypes binding a maintainer
+ * would add.  All pointers are DEVICE pointers (HIP) unless stated otherwise; buffers are caller
+ * owned; `stream` is a hipStream_t passed as void*; nothing here allocates, frees or synchronises,
+ * so every call can be captured in a HIP graph.  Return value: 0 on success, negative MPNHIP_ERR_*
+ * otherwise (mpnhip_last_error() gives a host string).  Feature matrices are dense row-major fp32.
+ */
+#ifndef MPNHIP_H
+#define MPNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPNHIP_OK 0
+#define MPNHIP_ERR_ARG (-1)         /* bad argument (null pointer, inconsistent dims, misalignment) */
+#define MPNHIP_ERR_HIP (-2)         /* a HIP runtime call / kernel launch failed */
+#define MPNHIP_ERR_WORKSPACE (-3)   /* caller buffer too small */
+#define MPNHIP_ERR_UNSUPPORTED (-4) /* valid reference configuration this build does not cover */
+
+#define MPNHIP_MAX_LAYERS 8
+
+#define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
+#define MPNHIP_AGG_MEAN 1 /* torch_scatter.scatter_mean (models/mpn.py:267) */
+#define MPNHIP_AGG_MAX 2  /* torch_scatter.scatter_max  (models/mpn.py:270), empty segment -> 0 */
+
+/* One reference `MLP` (models/mlp.py:4-28) with dropout_p = 0 and use_batchnorm = False:
+ * n_layers Linear layers, weight[i] is nn.Linear layout [out_dims[i], in] row-major, ReLU after every
+ * layer whose out dim != 1 (mlp.py:17).  grad pointers (same shapes) are used by mpnhip_backward only
+ * and may be NULL otherwise; gradients are ACCUMULATED into them (+=), like autograd's .grad. */
+typedef struct {
+    int n_layers;
+    int in_dim;
+    int out_dims[MPNHIP_MAX_LAYERS];
+    const float* weight[MPNHIP_MAX_LAYERS];
+    const float* bias[MPNHIP_MAX_LAYERS];
+    float* grad_weight[MPNHIP_MAX_LAYERS];
+    float* grad_bias[MPNHIP_MAX_LAYERS];
+} mpnhip_mlp;
+
+/* The hot-path sub-modules of MOTMPNet (models/mpn.py:220-317) -- what
+ * `MOTMPNet.__init__(model_params)` builds from `graph_model_params` (configs/tracking_cfg.yaml:134-168). */
+typedef struct {
+    int dn;               /* encoder_feats_dict.node_out_dim */
+    int de;               /* encoder_feats_dict.edge_out_dim */
+    int reattach_nodes;   /* reattach_initial_nodes (mpn.py:276) */
+    int reattach_edges;   /* reattach_initial_edges (mpn.py:277) */
+    int agg;              /* node_agg_fn: MPNHIP_AGG_*  (mpn.py:263-273) */
+    int num_enc_steps;    /* mpn.py:249 */
+    mpnhip_mlp enc_node;  /* encoder.node_model       (mpn.py:153,237) */
+    mpnhip_mlp enc_edge;  /* encoder.edge_model       (mpn.py:159,237) */
+    mpnhip_mlp edge;      /* MPNet.edge_model.edge_model, in = nf*2*dn + ef*de (mpn.py:282-283,294) */
+    mpnhip_mlp flow_in;   /* MPNet.node_model.flow_in_model,  in = nf*dn + de (mpn.py:285,299) */
+    mpnhip_mlp flow_out;  /* MPNet.node_model.flow_out_model (mpn.py:304) */
+    mpnhip_mlp node;      /* MPNet.node_model.node_model: ONE Linear(2dn -> dn) + ReLU (mpn.py:309-310) */
+    mpnhip_mlp classifier;/* classifier.edge_model    (mpn.py:238) */
+} mpnhip_model;
+
+const char* mpnhip_version(void);
+/* Host string describing the last error raised on the calling thread ("" if none). */
+const char* mpnhip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph preparation -- replaces the six boolean-mask indexings per step of
+ * TimeAwareNodeModel.forward (models/mpn.py:85-87,91-93) and the implicit index structures behind
+ * torch_scatter / index_put_.  Done once per edge_index, reused by all steps, forward and backward.
+ *
+ * edge_index: int64 [2,E] row-major (row = edge_index[0], col = edge_index[1]), as the reference's
+ * Graph.edge_index (data/mot_graph.py:312).  Edges are stably sorted by (direction, row) with
+ * direction 0 = row<col (flow_out), 1 = row>col (flow_in), 2 = row==col (in neither aggregate,
+ * mpn.py:85,91).  The prepared graph lives in `graph_buf` (mpnhip_graph_bytes) and is opaque.
+ * Out-of-range indices set an error flag readable with mpnhip_graph_status (which synchronises).
+ * ------------------------------------------------------------------------------------------- */
+size_t mpnhip_graph_bytes(int n_nodes, int64_t n_edges);
+size_t mpnhip_graph_prep_workspace_bytes(int n_nodes, int64_t n_edges);
+int mpnhip_graph_prep(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf, size_t graph_bytes,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Synchronising debug helper: host copy of {error_flag, E_flow_out, E_flow_in, E_self}. */
+int mpnhip_graph_status(const void* graph_buf, int n_nodes, int64_t n_edges, int32_t status[4], void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MOTMPNet.forward hot path (models/mpn.py:349-392 minus the x_ext / mask lines): encoder, then
+ * num_enc_steps x { reattach (:369-373), MetaLayer (:376 -> :33-54), classifier (:377 -> :114) }.
+ *
+ * x         [N, enc_node.in_dim]   node inputs after the avg-pool of mpn.py:351-352
+ * edge_attr [E, enc_edge.in_dim]   in edge_index order
+ * logits    [max(L,1), E]          OUT: classifier output of EVERY step, edge_index order (the
+ *                                  reference's classified_edges are the last num_class_steps rows)
+ * x_out [N,dn], e_out [E,de]       OUT, optional (NULL): final latent node / edge features
+ * save_for_backward != 0 keeps every step's activations in `workspace` for mpnhip_backward.
+ * ------------------------------------------------------------------------------------------- */
+size_t mpnhip_forward_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges, int save_for_backward);
+int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges, const float* x,
+                   const float* edge_attr, float* logits, float* x_out, float* e_out, void* workspace,
+                   size_t workspace_bytes, int save_for_backward, void* stream);
+
+/* Autograd of the above (what torch.autograd derives for mpn.py:349-392).
+ * grad_logits [max(L,1), E] incoming gradient for every step's logits (zeros where unused);
+ * grad_x_out / grad_e_out optional incoming gradients for the final latents (NULL = 0);
+ * grad_x [N, enc_node.in_dim], grad_edge_attr [E, enc_edge.in_dim]: OUT, optional (overwritten).
+ * Parameter gradients are accumulated into model->*.grad_weight / grad_bias.
+ * `workspace` must be the buffer the matching forward ran with save_for_backward = 1. */
+size_t mpnhip_backward_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges);
+int mpnhip_backward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges, const float* x,
+                    const float* edge_attr, const float* grad_logits, const float* grad_x_out,
+                    const float* grad_e_out, float* grad_x, float* grad_edge_attr, void* fwd_workspace,
+                    size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator level.
+ * ------------------------------------------------------------------------------------------- */
+
+/* MetaLayer.forward(x, edge_index, edge_attr) -> (x', e')  (models/mpn.py:33-54) with
+ * x [N, nf*dn], e [E, ef*de] (already re-attached, edge_index order); x_new [N,dn], e_new [E,de].
+ * Only model->edge / flow_in / flow_out / node and dn, de, agg, reattach_* are read. */
+size_t mpnhip_meta_layer_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges);
+int mpnhip_meta_layer_forward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
+                              const float* x, const float* e, float* x_new, float* e_new, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* node_agg_fn(out, row, x_size) (models/mpn.py:266-273): out[i] = AGG over {j : row[j] == i} src[j];
+ * src [M, dim], row int64 [M] (any order), out [x_size, dim]; empty -> 0; max returns values only.
+ * argmax (optional, int32 [x_size, dim]): for MAX the source row chosen (first maximum in index
+ * order, -1 for empty segments), as torch_scatter's CPU kernel picks it. */
+size_t mpnhip_segment_reduce_workspace_bytes(int64_t m, int x_size);
+int mpnhip_segment_reduce(const float* src, const int64_t* row, int64_t m, int dim, int x_size, int agg, float* out,
+                          int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = act(x W^T + b): one layer of models/mlp.py (nn.Linear + optional ReLU).
+ * x [M,K] (row stride ldx), w [N,K], b [N] or NULL, y [M,N] (row stride ldy). */
+int mpnhip_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n,
+                  int k, int relu, void* stream);
+
+/* MLP.forward (models/mlp.py:27-28): all layers; scratch [2, M, max(out_dims)] floats. */
+size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m);
+int mpnhip_mlp_forward(const mpnhip_mlp* mlp, const float* x, float* y, int64_t m, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* nn.AdaptiveAvgPool2d((1,1)) + view (models/mpn.py:252,351-352): x [rows, hw] -> y [rows] = mean over
+ * the hw contiguous spatial positions (rows = N * C). */
+int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement helpers used by bench.py (HIP events on the launch stream; these synchronise).
+ * ------------------------------------------------------------------------------------------- */
+/* Average duration in microseconds of `iters` back-to-back launches of the aggregation kernel on
+ * a prepared graph: src [E, dim] in SORTED edge order, out [N, 2*dim]. */
+int mpnhip_time_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, const float* src, int dim, int agg,
+                          float* out, int iters, float* avg_us, void* stream);
+/* Average duration (us) of `iters` launches of y = relu(x W^T + b). */
+int mpnhip_time_linear(const float* x, const float* w, const float* b, float* y, int64_t m, int n, int k, int iters,
+                       float* avg_us, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPNHIP_H */

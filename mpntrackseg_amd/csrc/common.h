@@ -1,0 +1,126 @@
+// Shared declarations of the mpnhip library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mpnhip.h"
+
+namespace mpnhip {
+
+void set_error(const char* fmt, ...);
+
+#define MPN_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            mpnhip::set_error(__VA_ARGS__); \
+            return MPNHIP_ERR_ARG;        \
+        }                                 \
+    } while (0)
+
+#define MPN_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            mpnhip::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MPNHIP_ERR_HIP;                                                         \
+        }                                                                                  \
+    } while (0)
+
+#define MPN_LAUNCH_CHECK()                                                                   \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            mpnhip::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MPNHIP_ERR_HIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+#define MPN_TRY(call)            \
+    do {                         \
+        int _r = (call);         \
+        if (_r != MPNHIP_OK) return _r; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ GEMM
+// C[m, n] = epilogue( sum_k A[m, k] * B[k, n] ) for up to two row groups that share N and K but have
+// their own row range (read from device memory so no host sync is needed), weights and tables.
+//
+// A layouts:  A_KCONTIG  A[m][k] row-major (leading dim lda), optionally rows through a_idx and a
+//                         second K segment [ksplit, K) taken from A2 (the reference's torch.cat of
+//                         initial and current features, mpn.py:369-373, without the copy);
+//             A_MCONTIG  A stored [k][m] (m contiguous, leading dim lda): C = A^T-style products.
+// B layouts:  B_KCONTIG  B given as W[n][k] (nn.Linear weight, leading dim ldb);
+//             B_NCONTIG  B stored [k][n] (n contiguous, leading dim ldb).
+enum { A_KCONTIG = 0, A_MCONTIG = 1 };
+enum { B_KCONTIG = 0, B_NCONTIG = 1 };
+
+struct GemmGroup {
+    const float* A;
+    const float* A2;       // second K segment (k >= ksplit) or nullptr
+    const int* a_idx;      // optional row indirection for A (A_KCONTIG only)
+    const float* B;
+    const float* bias;     // [N] or nullptr
+    const float* G1;       // gather-add epilogue: + G1[g1_idx[m]][n]
+    const int* g1_idx;     // nullptr -> identity (row m - row_begin + g_row0)
+    const float* G2;
+    const int* g2_idx;
+    const float* mask;     // ReLU-backward mask: value *= (mask[m][n] > 0); leading dim ldmask
+    float* C;
+    const int* c_idx;      // optional row scatter for C
+    const int* row_begin;  // device int: first row of this group (nullptr -> 0)
+    const int* row_end;    // device int: one past the last row (nullptr -> m_static)
+    int64_t lda, lda2, ldb, ldg1, ldg2, ldmask, ldc;
+    int64_t m_static;      // row count when row_end == nullptr
+};
+
+struct GemmArgs {
+    GemmGroup g[2];
+    int ngroups;
+    int N, K, ksplit;      // ksplit == K when A2 is unused
+    int relu;              // max(.,0) at the end
+    int accumulate;        // C += result (after mask / relu)
+    int64_t m_upper;       // host-side upper bound of the total row count (sizes the grid)
+    // split-K over the k range (used by the weight-gradient products): the grid's z dimension
+    // enumerates slices of `kslice` consecutive k; slice z writes C + z * c_slice_stride
+    int kslice;
+    int64_t c_slice_stride;
+};
+
+int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);
+
+// Convenience: y = act(x W^T + b)
+int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k,
+           int relu, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------ graph
+// Layout of the prepared graph buffer (all int32 arrays; offsets in bytes from the buffer start are
+// a pure function of (N, E), see graph_layout()).
+struct GraphView {
+    int N;
+    int64_t E;
+    int* header;    // [8]: {error_flag, E_out, E_in, E_self, E_out (dup, as group-0 row_end), E_out+E_in, 0, 0}
+    int* perm;      // [E]   sorted position -> original edge id
+    int* srow;      // [E]   row of the edge at sorted position
+    int* scol;      // [E]   col ...
+    int* seg_ptr;   // [3N+1] CSR over keys dir*N + row (dir 0 out, 1 in, 2 self)
+    int* cperm;     // [E]   positions (in sorted order) re-sorted stably by key dir*N + col
+    int* cseg_ptr;  // [3N+1] CSR over keys dir*N + col, indexing cperm
+    int* rperm;     // [E]   positions sorted by row only (all directions): row-gradient segments
+    int* rseg_ptr;  // [N+1]
+    int* cperm_all; // [E]   positions sorted by col only (all directions)
+    int* cseg_all;  // [N+1]
+};
+size_t graph_layout(int N, int64_t E, GraphView* view, void* base);
+
+// ------------------------------------------------------------------------------------ segments
+// out[n][0:dim] = AGG over in-segment(n), out[n][dim:2dim] = AGG over out-segment(n)
+// (torch.cat((flow_in, flow_out)), mpn.py:97); src rows in sorted edge order.
+int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out, int* argmax, hipStream_t stream);
+// generic: out[s][:] = AGG_{j in [ptr[s], ptr[s+1])} src[list ? list[j] : j][:]; out leading dim ldo
+int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, int agg,
+                       float* out, int64_t ldo, int* argmax, int accumulate, hipStream_t stream);
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace mpnhip

@@ -1,0 +1,627 @@
+// Host-side orchestration of the MPN hot path on one MI355X: MOTMPNet.forward restricted to the
+// encoder -> L x {reattach, MetaLayer, classifier} loop (reference models/mpn.py:349-392), expressed
+// as fused-epilogue MFMA GEMMs + one segmented aggregation per step.  No allocation, no host sync.
+//
+// Re-association used (fp32 throughout, only the summation order differs from the reference):
+//   EdgeModel  (mpn.py:67-69):  W1 [x[row] | x[col] | e] = (W1r x)[row] + (W1c x)[col] + W1e e
+//   flow MLPs  (mpn.py:87-88):  Wf [x[col] | e']         = (Wfx x)[col] + Wfe e'
+// The node-side products are computed once per node per step by ONE GEMM against the row-stacked
+// weight block [W1r; W1c; Wfo_x; Wfi_x] (biases folded in) and added per edge in the epilogue of the
+// per-edge GEMMs; torch.cat([x0, x]) / torch.cat([e0, e]) (mpn.py:369-373) are never materialised --
+// the GEMM's A operand is read from two K segments.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace mpnhip {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------ small kernels
+// dst[r][c] = src[r][c0 + c] for r < rows, c < cols  (weight sub-block copy)
+__global__ void k_copy_block(const float* __restrict__ src, int64_t lds, int c0, float* __restrict__ dst, int64_t ldd,
+                             int rows, int cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c0 + c];
+}
+
+__global__ void k_copy_vec(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src ? src[i] : 0.f;
+}
+
+// dst[idx ? idx[r] : r][:] = src[r][:]
+__global__ void k_scatter_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                               int64_t rows, int cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    int64_t r = i / cols;
+    int c = (int)(i % cols);
+    dst[(int64_t)(idx ? idx[r] : r) * cols + c] = src[i];
+}
+
+// y[r] = mean(x[r][0:hw]); `sub` lanes (power of two) share one row and reduce with shuffles
+__global__ void k_avgpool(const float* __restrict__ x, int64_t rows, int hw, float* __restrict__ y, int sub) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r = t / sub;
+    int l = (int)(t % sub);
+    float acc = 0.f;
+    if (r < rows) {
+        const float* p = x + r * hw;
+        for (int i = l; i < hw; i += sub) acc += p[i];
+    }
+    for (int o = sub >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (r < rows && l == 0) y[r] = acc / (float)hw;
+}
+
+static int copy_block(const float* src, int64_t lds, int c0, float* dst, int64_t ldd, int rows, int cols, hipStream_t s) {
+    int64_t n = (int64_t)rows * cols;
+    if (n <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_copy_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, c0, dst, ldd, rows, cols);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+static int copy_vec(const float* src, float* dst, int n, hipStream_t s) {
+    if (n <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_copy_vec, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+static int scatter_rows(const float* src, const int* idx, float* dst, int64_t rows, int cols, hipStream_t s) {
+    int64_t n = rows * cols;
+    if (n <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, cols);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ model checks
+struct Dims {
+    int dn, de, nf, ef;
+    int he;   // first hidden width of the edge MLP
+    int hn;   // first hidden width of the flow MLPs
+    int pw;   // width of the per-node projection block: 2 he + 2 hn
+    int kx;   // nf * dn
+    int ke;   // ef * de
+    int L;
+};
+
+static int mlp_ok(const mpnhip_mlp& m, const char* name, bool need_ptrs) {
+    MPN_CHECK_ARG(m.n_layers >= 1 && m.n_layers <= MPNHIP_MAX_LAYERS, "%s: n_layers %d", name, m.n_layers);
+    MPN_CHECK_ARG(m.in_dim >= 1, "%s: in_dim %d", name, m.in_dim);
+    for (int i = 0; i < m.n_layers; ++i) {
+        MPN_CHECK_ARG(m.out_dims[i] >= 1, "%s: out_dims[%d] = %d", name, i, m.out_dims[i]);
+        if (need_ptrs) MPN_CHECK_ARG(m.weight[i] && m.bias[i], "%s: null weight/bias in layer %d", name, i);
+    }
+    return MPNHIP_OK;
+}
+
+static int check_core(const mpnhip_model& m, Dims* d, bool ptrs = true) {
+    MPN_CHECK_ARG(m.dn >= 1 && m.de >= 1, "model: dn/de");
+    MPN_CHECK_ARG(m.agg >= 0 && m.agg <= 2, "model: node_agg_fn code %d (reference asserts 'mean'|'max'|'sum', mpn.py:264)", m.agg);
+    d->dn = m.dn;
+    d->de = m.de;
+    d->nf = m.reattach_nodes ? 2 : 1;
+    d->ef = m.reattach_edges ? 2 : 1;
+    d->kx = d->nf * d->dn;
+    d->ke = d->ef * d->de;
+    d->L = m.num_enc_steps;
+    MPN_TRY(mlp_ok(m.edge, "edge_model", ptrs));
+    MPN_TRY(mlp_ok(m.flow_in, "flow_in_model", ptrs));
+    MPN_TRY(mlp_ok(m.flow_out, "flow_out_model", ptrs));
+    MPN_TRY(mlp_ok(m.node, "node_model", ptrs));
+    MPN_CHECK_ARG(m.edge.in_dim == 2 * d->kx + d->ke, "edge_model in_dim %d != %d (mpn.py:282-283)", m.edge.in_dim, 2 * d->kx + d->ke);
+    MPN_CHECK_ARG(m.edge.out_dims[m.edge.n_layers - 1] == d->de, "edge_model must end at edge_out_dim");
+    MPN_CHECK_ARG(m.flow_in.in_dim == d->kx + d->de && m.flow_out.in_dim == d->kx + d->de, "flow model in_dim != %d (mpn.py:285)", d->kx + d->de);
+    MPN_CHECK_ARG(m.flow_in.n_layers == m.flow_out.n_layers, "flow_in / flow_out depth differ");
+    for (int i = 0; i < m.flow_in.n_layers; ++i)
+        MPN_CHECK_ARG(m.flow_in.out_dims[i] == m.flow_out.out_dims[i], "flow_in / flow_out dims differ");
+    MPN_CHECK_ARG(m.flow_in.out_dims[m.flow_in.n_layers - 1] == d->dn, "flow models must end at node_out_dim");
+    MPN_CHECK_ARG(m.node.n_layers == 1 && m.node.in_dim == 2 * d->dn && m.node.out_dims[0] == d->dn, "node_model must be Linear(2dn, dn) (mpn.py:309)");
+    d->he = m.edge.out_dims[0];
+    d->hn = m.flow_in.out_dims[0];
+    d->pw = 2 * d->he + 2 * d->hn;
+    return MPNHIP_OK;
+}
+
+static int check_full(const mpnhip_model& m, Dims* d, bool ptrs = true) {
+    MPN_TRY(check_core(m, d, ptrs));
+    MPN_CHECK_ARG(m.num_enc_steps >= 0, "model: num_enc_steps");
+    MPN_TRY(mlp_ok(m.enc_node, "encoder.node_model", ptrs));
+    MPN_TRY(mlp_ok(m.enc_edge, "encoder.edge_model", ptrs));
+    MPN_TRY(mlp_ok(m.classifier, "classifier.edge_model", ptrs));
+    MPN_CHECK_ARG(m.enc_node.out_dims[m.enc_node.n_layers - 1] == d->dn, "encoder node_out_dim mismatch");
+    MPN_CHECK_ARG(m.enc_edge.out_dims[m.enc_edge.n_layers - 1] == d->de, "encoder edge_out_dim mismatch");
+    MPN_CHECK_ARG(m.classifier.in_dim == d->de, "classifier edge_in_dim != edge_out_dim");
+    MPN_CHECK_ARG(m.classifier.out_dims[m.classifier.n_layers - 1] == 1, "classifier must end with out dim 1");
+    return MPNHIP_OK;
+}
+
+static int max_hidden(const mpnhip_mlp& m) {
+    int mx = 0;
+    for (int i = 0; i + 1 < m.n_layers; ++i) mx = m.out_dims[i] > mx ? m.out_dims[i] : mx;
+    return mx;
+}
+static int64_t sum_hidden(const mpnhip_mlp& m) {
+    int64_t s = 0;
+    for (int i = 0; i + 1 < m.n_layers; ++i) s += m.out_dims[i];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------ workspace
+struct Arena {
+    char* base;
+    size_t off;
+    float* f(size_t n) {
+        size_t o = off;
+        off = align_up(off + n * sizeof(float), 256);
+        return base ? reinterpret_cast<float*>(base + o) : nullptr;
+    }
+    int* i(size_t n) { return reinterpret_cast<int*>(f(n)); }
+};
+
+// per-step activation buffers of one MetaLayer + classifier evaluation
+struct StepBufs {
+    float* P;                          // [N, pw]   per-node projections (+ folded biases)
+    float* HE[MPNHIP_MAX_LAYERS];      // hidden activations of the edge MLP   [E, edge.out_dims[i]]
+    float* HC[MPNHIP_MAX_LAYERS];      // hidden activations of the classifier [E, cls.out_dims[i]]
+    float* HF[MPNHIP_MAX_LAYERS];      // hidden activations of the flow MLPs  [E, flow.out_dims[i]]
+    float* M;                          // [E, dn]   messages (post-ReLU), sorted order
+    float* AGG;                        // [N, 2dn]  [flow_in | flow_out]
+    int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
+};
+
+struct FwdPlan {
+    float* Wnode;  // [pw, kx]
+    float* bnode;  // [pw]
+    float* enc_n[2];
+    float* enc_e[2];
+    float* x_hist;  // [(L+1) or 3][N, dn]   x_hist[0] = encoder output
+    float* e_hist;  // [(L+1) or 3][E, de]   sorted order
+    int hist_slots;
+    StepBufs step0;
+    size_t step_stride_bytes;  // 0 when the step buffers are reused (inference)
+    size_t total;
+};
+
+static void carve_step(Arena& a, const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, bool with_cls, bool with_arg,
+                       StepBufs* sb) {
+    StepBufs s = {};
+    s.P = a.f((size_t)N * d.pw);
+    for (int i = 0; i + 1 < m.edge.n_layers; ++i) s.HE[i] = a.f((size_t)E * m.edge.out_dims[i]);
+    if (with_cls)
+        for (int i = 0; i + 1 < m.classifier.n_layers; ++i) s.HC[i] = a.f((size_t)E * m.classifier.out_dims[i]);
+    for (int i = 0; i + 1 < m.flow_in.n_layers; ++i) s.HF[i] = a.f((size_t)E * m.flow_in.out_dims[i]);
+    s.M = a.f((size_t)E * d.dn);
+    s.AGG = a.f((size_t)N * 2 * d.dn);
+    s.ARG = with_arg ? a.i((size_t)N * 2 * d.dn) : nullptr;
+    if (sb) *sb = s;
+}
+
+static StepBufs step_at(const FwdPlan& p, int s) {
+    StepBufs b = p.step0;
+    size_t sh = p.step_stride_bytes * (size_t)s;
+    auto mv = [&](float*& q) { if (q) q = reinterpret_cast<float*>(reinterpret_cast<char*>(q) + sh); };
+    mv(b.P);
+    for (int i = 0; i < MPNHIP_MAX_LAYERS; ++i) { mv(b.HE[i]); mv(b.HC[i]); mv(b.HF[i]); }
+    mv(b.M);
+    mv(b.AGG);
+    if (b.ARG) b.ARG = reinterpret_cast<int*>(reinterpret_cast<char*>(b.ARG) + sh);
+    return b;
+}
+
+static size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, int save, void* base, FwdPlan* out) {
+    Arena a = {static_cast<char*>(base), 0};
+    FwdPlan p = {};
+    p.Wnode = a.f((size_t)d.pw * d.kx);
+    p.bnode = a.f((size_t)d.pw);
+    int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
+    if (save) {
+        // keep every encoder activation for the backward pass: one buffer per hidden layer
+        p.enc_n[0] = a.f((size_t)N * (sum_hidden(m.enc_node) > 0 ? sum_hidden(m.enc_node) : 1));
+        p.enc_e[0] = a.f((size_t)E * (sum_hidden(m.enc_edge) > 0 ? sum_hidden(m.enc_edge) : 1));
+        p.enc_n[1] = p.enc_e[1] = nullptr;
+    } else {
+        for (int i = 0; i < 2; ++i) {
+            p.enc_n[i] = a.f((size_t)N * (hn_ > 0 ? hn_ : 1));
+            p.enc_e[i] = a.f((size_t)E * (he_ > 0 ? he_ : 1));
+        }
+    }
+    p.hist_slots = save ? d.L + 1 : 3;
+    p.x_hist = a.f((size_t)p.hist_slots * N * d.dn);
+    p.e_hist = a.f((size_t)p.hist_slots * E * d.de);
+    size_t before = a.off;
+    carve_step(a, m, d, N, E, true, save && m.agg == MPNHIP_AGG_MAX, &p.step0);
+    p.step_stride_bytes = 0;
+    if (save && d.L > 1) {
+        p.step_stride_bytes = a.off - before;
+        a.off = before + p.step_stride_bytes * (size_t)d.L;
+    }
+    p.total = a.off;
+    if (out) *out = p;
+    return p.total;
+}
+
+// ------------------------------------------------------------------------------------ building blocks
+static void init_group(GemmGroup& g) { memset(&g, 0, sizeof(g)); }
+
+// hidden / output layers i >= 1 of an MLP on [rows, :] activations; `two` = direction-grouped run
+// of the flow MLPs (group 0: flow_out weights on rows [0, E_out), group 1: flow_in on [E_out, E_out+E_in)).
+static int mlp_tail(const mpnhip_mlp& m0, const mpnhip_mlp* m1, const GraphView* g, float* const* hidden,
+                    float* out_last, int64_t ld_last, const int* c_idx_last, int64_t rows, hipStream_t s) {
+    for (int i = 1; i < m0.n_layers; ++i) {
+        GemmArgs a = {};
+        a.ngroups = m1 ? 2 : 1;
+        a.N = m0.out_dims[i];
+        a.K = m0.out_dims[i - 1];
+        a.ksplit = a.K;
+        a.relu = m0.out_dims[i] != 1;  // mlp.py:17
+        a.m_upper = rows;
+        bool last = i == m0.n_layers - 1;
+        for (int q = 0; q < a.ngroups; ++q) {
+            const mpnhip_mlp& m = q == 0 ? m0 : *m1;
+            GemmGroup& G = a.g[q];
+            init_group(G);
+            G.A = hidden[i - 1];
+            G.lda = a.K;
+            G.B = m.weight[i];
+            G.ldb = a.K;
+            G.bias = m.bias[i];
+            G.C = last ? out_last : hidden[i];
+            G.ldc = last ? ld_last : a.N;
+            G.c_idx = last ? c_idx_last : nullptr;
+            G.m_static = rows;
+            if (m1) {
+                G.row_begin = q == 0 ? nullptr : g->header + 4;
+                G.row_end = q == 0 ? g->header + 4 : g->header + 5;
+            }
+        }
+        MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+    }
+    return MPNHIP_OK;
+}
+
+static int pack_node_weights(const mpnhip_model& m, const Dims& d, float* Wnode, float* bnode, hipStream_t s) {
+    const int he = d.he, hn = d.hn, kx = d.kx;
+    MPN_TRY(copy_block(m.edge.weight[0], m.edge.in_dim, 0, Wnode, kx, he, kx, s));                         // W1 row part
+    MPN_TRY(copy_block(m.edge.weight[0], m.edge.in_dim, kx, Wnode + (size_t)he * kx, kx, he, kx, s));      // W1 col part
+    MPN_TRY(copy_block(m.flow_out.weight[0], m.flow_out.in_dim, 0, Wnode + (size_t)2 * he * kx, kx, hn, kx, s));
+    MPN_TRY(copy_block(m.flow_in.weight[0], m.flow_in.in_dim, 0, Wnode + (size_t)(2 * he + hn) * kx, kx, hn, kx, s));
+    MPN_TRY(copy_vec(m.edge.bias[0], bnode, he, s));
+    MPN_TRY(copy_vec(nullptr, bnode + he, he, s));
+    MPN_TRY(copy_vec(m.flow_out.bias[0], bnode + 2 * he, hn, s));
+    MPN_TRY(copy_vec(m.flow_in.bias[0], bnode + 2 * he + hn, hn, s));
+    return MPNHIP_OK;
+}
+
+struct StepIO {
+    // node features as one or two K segments (x0 | x) -- together kx columns
+    const float* xa; int64_t ldxa; const float* xb; int64_t ldxb; int kxa;
+    // edge features (e0 | e) -- together ke columns; optional row indirection (original-order input)
+    const float* ea; int64_t ldea; const float* eb; int64_t ldeb; int kea; const int* e_idx;
+    float* e_new; const int* e_new_idx;   // [E, de]; row scatter when the caller wants original order
+    const int* e_new_read_idx;            // how the flow MLPs must index e_new (nullptr = sorted order)
+    float* x_new;                         // [N, dn]
+    float* logits;                        // [E] original order, or nullptr (operator-level call)
+};
+
+// One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
+static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, const float* Wnode, const float* bnode,
+                    const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s) {
+    const int64_t N = g.N, E = g.E;
+    const int he = d.he, hn = d.hn;
+    // (1) per-node projections P = [xa | xb] Wnode^T + bnode
+    {
+        GemmArgs a = {};
+        a.ngroups = 1; a.N = d.pw; a.K = d.kx; a.ksplit = io.xb ? io.kxa : d.kx; a.relu = 0; a.m_upper = N;
+        GemmGroup& G = a.g[0];
+        init_group(G);
+        G.A = io.xa; G.lda = io.ldxa; G.A2 = io.xb; G.lda2 = io.ldxb;
+        G.B = Wnode; G.ldb = d.kx; G.bias = bnode; G.C = b.P; G.ldc = d.pw; G.m_static = N;
+        MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+    }
+    if (E > 0) {
+        // (2) edge MLP layer 0: relu([ea | eb] W1e^T + P_r[row] + P_c[col])      (EdgeModel, mpn.py:67-69)
+        {
+            GemmArgs a = {};
+            a.ngroups = 1; a.N = he; a.K = d.ke; a.ksplit = io.eb ? io.kea : d.ke; a.m_upper = E;
+            a.relu = he != 1;
+            GemmGroup& G = a.g[0];
+            init_group(G);
+            G.A = io.ea; G.lda = io.ldea; G.A2 = io.eb; G.lda2 = io.ldeb; G.a_idx = io.e_idx;
+            G.B = m.edge.weight[0] + 2 * d.kx; G.ldb = m.edge.in_dim;
+            G.G1 = b.P; G.g1_idx = g.srow; G.ldg1 = d.pw;
+            G.G2 = b.P + he; G.g2_idx = g.scol; G.ldg2 = d.pw;
+            bool last = m.edge.n_layers == 1;
+            G.C = last ? io.e_new : b.HE[0]; G.ldc = last ? d.de : he; G.c_idx = last ? io.e_new_idx : nullptr;
+            G.m_static = E;
+            MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+        }
+        MPN_TRY(mlp_tail(m.edge, nullptr, nullptr, b.HE, io.e_new, d.de, io.e_new_idx, E, s));
+        // (3) classifier on the NEW edge features (mpn.py:377 -> :114)
+        if (io.logits) {
+            const mpnhip_mlp& c = m.classifier;
+            GemmArgs a = {};
+            a.ngroups = 1; a.N = c.out_dims[0]; a.K = d.de; a.ksplit = d.de; a.relu = c.out_dims[0] != 1; a.m_upper = E;
+            GemmGroup& G = a.g[0];
+            init_group(G);
+            G.A = io.e_new; G.lda = d.de; G.a_idx = io.e_new_read_idx; G.B = c.weight[0]; G.ldb = d.de; G.bias = c.bias[0];
+            bool last = c.n_layers == 1;
+            G.C = last ? io.logits : b.HC[0]; G.ldc = last ? 1 : a.N; G.c_idx = last ? g.perm : nullptr; G.m_static = E;
+            MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+            MPN_TRY(mlp_tail(c, nullptr, nullptr, b.HC, io.logits, 1, g.perm, E, s));
+        }
+        // (4) flow MLP layer 0, both directions in one grouped launch (TimeAwareNodeModel, mpn.py:85-94)
+        {
+            GemmArgs a = {};
+            a.ngroups = 2; a.N = hn; a.K = d.de; a.ksplit = d.de; a.relu = hn != 1; a.m_upper = E;
+            bool last = m.flow_in.n_layers == 1;
+            for (int q = 0; q < 2; ++q) {
+                const mpnhip_mlp& f = q == 0 ? m.flow_out : m.flow_in;
+                GemmGroup& G = a.g[q];
+                init_group(G);
+                G.A = io.e_new; G.lda = d.de; G.a_idx = io.e_new_read_idx;
+                G.B = f.weight[0] + d.kx; G.ldb = f.in_dim;
+                G.G1 = b.P + 2 * he + q * hn; G.g1_idx = g.scol; G.ldg1 = d.pw;
+                G.C = last ? b.M : b.HF[0]; G.ldc = last ? d.dn : hn;
+                G.m_static = E;
+                G.row_begin = q == 0 ? nullptr : g.header + 4;
+                G.row_end = q == 0 ? g.header + 4 : g.header + 5;
+            }
+            MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+        }
+        MPN_TRY(mlp_tail(m.flow_out, &m.flow_in, &g, b.HF, b.M, d.dn, nullptr, E, s));
+    }
+    // (5) aggregation (node_agg_fn, mpn.py:89,96) and node update (mpn.py:97-99)
+    MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
+    MPN_TRY(linear(b.AGG, 2 * d.dn, m.node.weight[0], m.node.bias[0], io.x_new, d.dn, N, d.dn, 2 * d.dn, 1, s));
+    return MPNHIP_OK;
+}
+
+// full MLP (all layers) with ping-pong or per-layer hidden buffers; a_idx permutes the input rows
+static int mlp_forward(const mpnhip_mlp& m, const float* x, int64_t ldx, const int* a_idx, float* const* hidden, float* y,
+                       int64_t rows, hipStream_t s) {
+    for (int i = 0; i < m.n_layers; ++i) {
+        GemmArgs a = {};
+        a.ngroups = 1;
+        a.N = m.out_dims[i];
+        a.K = i == 0 ? m.in_dim : m.out_dims[i - 1];
+        a.ksplit = a.K;
+        a.relu = m.out_dims[i] != 1;
+        a.m_upper = rows;
+        GemmGroup& G = a.g[0];
+        init_group(G);
+        G.A = i == 0 ? x : hidden[i - 1];
+        G.lda = i == 0 ? ldx : a.K;
+        G.a_idx = i == 0 ? a_idx : nullptr;
+        G.B = m.weight[i];
+        G.ldb = a.K;
+        G.bias = m.bias[i];
+        G.C = i == m.n_layers - 1 ? y : hidden[i];
+        G.ldc = a.N;
+        G.m_static = rows;
+        MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+    }
+    return MPNHIP_OK;
+}
+
+static void hidden_ptrs(const mpnhip_mlp& m, float* const two[2], int64_t rows, bool per_layer, float** out) {
+    size_t off = 0;
+    for (int i = 0; i + 1 < m.n_layers; ++i) {
+        if (per_layer) {
+            out[i] = two[0] + off;
+            off += (size_t)rows * m.out_dims[i];
+        } else {
+            out[i] = two[i & 1];
+        }
+    }
+}
+
+}  // namespace mpnhip
+
+using namespace mpnhip;
+
+extern "C" const char* mpnhip_version(void) { return "mpnhip 0.1 (gfx950)"; }
+extern "C" const char* mpnhip_last_error(void) { return g_err; }
+
+extern "C" size_t mpnhip_forward_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges, int save) {
+    Dims d;
+    if (!model || check_full(*model, &d, false) != MPNHIP_OK) return 0;
+    return plan_forward(*model, d, n_nodes, n_edges, save, nullptr, nullptr);
+}
+
+extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
+                              const float* x, const float* edge_attr, float* logits, float* x_out, float* e_out,
+                              void* workspace, size_t workspace_bytes, int save, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(model && graph_buf, "forward: null model / graph");
+    const mpnhip_model& m = *model;
+    Dims d;
+    MPN_TRY(check_full(m, &d));
+    const int64_t N = n_nodes, E = n_edges;
+    MPN_CHECK_ARG(N >= 0 && E >= 0, "forward: negative sizes");
+    MPN_CHECK_ARG((x || N == 0) && (edge_attr || E == 0) && (logits || E == 0), "forward: null tensor");
+    FwdPlan p;
+    size_t need = plan_forward(m, d, N, E, save, workspace, &p);
+    if (!workspace || workspace_bytes < need) {
+        set_error("forward: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    GraphView g;
+    graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
+
+    MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
+    // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
+    // the sort permutation so that every per-edge tensor downstream lives in sorted order
+    float* hid[MPNHIP_MAX_LAYERS];
+    float* x0 = p.x_hist;
+    float* e0 = p.e_hist;
+    hidden_ptrs(m.enc_node, p.enc_n, N, save != 0, hid);
+    MPN_TRY(mlp_forward(m.enc_node, x, m.enc_node.in_dim, nullptr, hid, x0, N, s));
+    hidden_ptrs(m.enc_edge, p.enc_e, E, save != 0, hid);
+    MPN_TRY(mlp_forward(m.enc_edge, edge_attr, m.enc_edge.in_dim, g.perm, hid, e0, E, s));
+
+    const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
+    int prev = 0;
+    for (int step = 0; step < d.L; ++step) {
+        int cur = save ? step + 1 : 1 + (step & 1);
+        StepBufs b = step_at(p, step);
+        StepIO io = {};
+        const float* xp = p.x_hist + xs * prev;
+        const float* ep = p.e_hist + es * prev;
+        if (d.nf == 2) { io.xa = x0; io.ldxa = d.dn; io.xb = xp; io.ldxb = d.dn; io.kxa = d.dn; }
+        else { io.xa = xp; io.ldxa = d.dn; }
+        if (d.ef == 2) { io.ea = e0; io.ldea = d.de; io.eb = ep; io.ldeb = d.de; io.kea = d.de; }
+        else { io.ea = ep; io.ldea = d.de; }
+        io.e_new = p.e_hist + es * cur;
+        io.x_new = p.x_hist + xs * cur;
+        io.logits = logits + (size_t)step * E;
+        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s));
+        prev = cur;
+    }
+    if (d.L == 0 && E > 0) {
+        // mpn.py:387-389: classify the encoder output once
+        StepBufs b = p.step0;
+        const mpnhip_mlp& c = m.classifier;
+        float* hidc[MPNHIP_MAX_LAYERS];
+        for (int i = 0; i < MPNHIP_MAX_LAYERS; ++i) hidc[i] = b.HC[i];
+        if (c.n_layers == 1) {
+            GemmArgs a = {};
+            a.ngroups = 1; a.N = 1; a.K = d.de; a.ksplit = d.de; a.relu = 0; a.m_upper = E;
+            GemmGroup& G = a.g[0];
+            init_group(G);
+            G.A = e0; G.lda = d.de; G.B = c.weight[0]; G.ldb = d.de; G.bias = c.bias[0];
+            G.C = logits; G.ldc = 1; G.c_idx = g.perm; G.m_static = E;
+            MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+        } else {
+            MPN_TRY(linear(e0, d.de, c.weight[0], c.bias[0], hidc[0], c.out_dims[0], E, c.out_dims[0], d.de,
+                           c.out_dims[0] != 1, s));
+            MPN_TRY(mlp_tail(c, nullptr, nullptr, hidc, logits, 1, g.perm, E, s));
+        }
+    }
+    if (x_out && N > 0) MPN_HIP(hipMemcpyAsync(x_out, p.x_hist + xs * prev, xs * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (e_out) MPN_TRY(scatter_rows(p.e_hist + es * prev, g.perm, e_out, E, d.de, s));
+    return MPNHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ MetaLayer op
+static size_t plan_meta(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, void* base, float** Wnode,
+                        float** bnode, StepBufs* sb) {
+    Arena a = {static_cast<char*>(base), 0};
+    float* w = a.f((size_t)d.pw * d.kx);
+    float* b = a.f((size_t)d.pw);
+    carve_step(a, m, d, N, E, false, false, sb);
+    if (Wnode) *Wnode = w;
+    if (bnode) *bnode = b;
+    return a.off;
+}
+
+extern "C" size_t mpnhip_meta_layer_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges) {
+    Dims d;
+    if (!model || check_core(*model, &d, false) != MPNHIP_OK) return 0;
+    return plan_meta(*model, d, n_nodes, n_edges, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mpnhip_meta_layer_forward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
+                                         const float* x, const float* e, float* x_new, float* e_new, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(model && graph_buf, "meta_layer: null model / graph");
+    Dims d;
+    MPN_TRY(check_core(*model, &d));
+    const int64_t N = n_nodes, E = n_edges;
+    MPN_CHECK_ARG((x && x_new) || N == 0, "meta_layer: null node tensors");
+    MPN_CHECK_ARG((e && e_new) || E == 0, "meta_layer: null edge tensors");
+    float *Wnode, *bnode;
+    StepBufs b;
+    size_t need = plan_meta(*model, d, N, E, workspace, &Wnode, &bnode, &b);
+    if (!workspace || workspace_bytes < need) {
+        set_error("meta_layer: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    GraphView g;
+    graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
+    MPN_TRY(pack_node_weights(*model, d, Wnode, bnode, s));
+    StepIO io = {};
+    io.xa = x; io.ldxa = d.kx;
+    io.ea = e; io.ldea = d.ke; io.e_idx = g.perm;
+    io.e_new = e_new; io.e_new_idx = g.perm; io.e_new_read_idx = g.perm;
+    io.x_new = x_new;
+    io.logits = nullptr;
+    return run_step(*model, d, g, Wnode, bnode, io, b, false, s);
+}
+
+// ------------------------------------------------------------------------------------ Linear / MLP ops
+extern "C" int mpnhip_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                             int64_t m, int n, int k, int relu, void* stream_) {
+    MPN_CHECK_ARG(m >= 0 && n >= 1 && k >= 1, "linear: bad sizes");
+    if (m == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(x && w && y, "linear: null pointer");
+    return linear(x, ldx, w, b, y, ldy, m, n, k, relu, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m) {
+    if (!mlp) return 0;
+    int h = max_hidden(*mlp);
+    return 2 * align_up((size_t)(m > 0 ? m : 1) * (h > 0 ? h : 1) * sizeof(float), 256);
+}
+
+extern "C" int mpnhip_mlp_forward(const mpnhip_mlp* mlp, const float* x, float* y, int64_t m, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+    MPN_CHECK_ARG(mlp, "mlp_forward: null mlp");
+    MPN_TRY(mlp_ok(*mlp, "mlp", true));
+    if (m == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(x && y && m > 0, "mlp_forward: null pointer");
+    size_t need = mpnhip_mlp_workspace_bytes(mlp, m);
+    if (mlp->n_layers > 1 && (!workspace || workspace_bytes < need)) {
+        set_error("mlp_forward: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    float* two[2] = {static_cast<float*>(workspace), reinterpret_cast<float*>(static_cast<char*>(workspace) + need / 2)};
+    float* hid[MPNHIP_MAX_LAYERS];
+    hidden_ptrs(*mlp, two, m, false, hid);
+    return mlp_forward(*mlp, x, mlp->in_dim, nullptr, hid, y, m, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream_) {
+    MPN_CHECK_ARG(rows >= 0 && hw >= 1, "avgpool: bad sizes");
+    if (rows == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(x && y, "avgpool: null pointer");
+    int sub = 1;
+    while (sub < hw && sub < 64) sub <<= 1;
+    int64_t threads = rows * sub;
+    hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       x, rows, hw, y, sub);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_time_linear(const float* x, const float* w, const float* b, float* y, int64_t m, int n, int k,
+                                  int iters, float* avg_us, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(x && w && y && avg_us && iters > 0, "time_linear: bad argument");
+    hipEvent_t t0, t1;
+    MPN_HIP(hipEventCreate(&t0));
+    MPN_HIP(hipEventCreate(&t1));
+    MPN_TRY(linear(x, k, w, b, y, n, m, n, k, 1, s));
+    MPN_HIP(hipEventRecord(t0, s));
+    for (int i = 0; i < iters; ++i) MPN_TRY(linear(x, k, w, b, y, n, m, n, k, 1, s));
+    MPN_HIP(hipEventRecord(t1, s));
+    MPN_HIP(hipEventSynchronize(t1));
+    float ms = 0.f;
+    MPN_HIP(hipEventElapsedTime(&ms, t0, t1));
+    *avg_us = ms * 1000.f / iters;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return MPNHIP_OK;
+}

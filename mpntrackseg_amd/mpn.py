@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's message-passing modules
+(``/root/reference/src/mot_neural_solver/models/mpn.py``): same class names, constructor arguments,
+attribute names and ``state_dict`` keys, so ``mot_neural_solver`` can import
+``MOTMPNet`` / ``MetaLayer`` from here unchanged and reference checkpoints load -- but every
+``forward`` goes through the C ABI (``include/mpnhip.h``) into hand-written gfx950 kernels.
+
+There is no CPU fallback: tensors must live on a HIP device, and a missing ``libmpnhip.so`` raises.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import capi
+from .mlp import MLP
+
+
+def _prepared(edge_index, n_nodes, holder=None):
+    """Graph prep (``mpnhip_graph_prep``) cached on the object that owns edge_index (the reference's
+    ``Graph`` sample), validated by tensor identity and version counter."""
+    if holder is not None:
+        c = getattr(holder, "_mpnhip_prep", None)
+        if c is not None and c[0] is edge_index and c[1] == edge_index._version and c[2].N == n_nodes:
+            return c[2]
+    g = capi.PreparedGraph(edge_index, n_nodes)
+    if holder is not None:
+        try:
+            object.__setattr__(holder, "_mpnhip_prep", (edge_index, edge_index._version, g))
+        except Exception:
+            pass
+    return g
+
+
+class NodeAggFn:
+    """The reference's ``node_agg_fn`` lambdas (mpn.py:266-273): ``fn(out, row, x_size)``."""
+
+    def __init__(self, name):
+        assert name.lower() in ('mean', 'max', 'sum'), "node_agg_fn can only be 'max', 'mean' or 'sum'."
+        self.name = name
+
+    @property
+    def code(self):
+        return capi.AGG_CODE[self.name]
+
+    def __call__(self, out, row, x_size):
+        capi.require_device(out, row)
+        if torch.is_grad_enabled() and out.requires_grad:
+            raise capi.MpnhipError("operator-level node_agg_fn has no autograd; use MOTMPNet.forward for training")
+        lib = capi.load()
+        src = capi.f32c(out)
+        row = row.contiguous().to(torch.int64)
+        m = src.shape[0]
+        dim = 1
+        for v in src.shape[1:]:
+            dim *= int(v)
+        res = torch.empty((x_size,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            ws = capi.workspace(lib.mpnhip_segment_reduce_workspace_bytes(m, x_size), src.device, "seg")
+            capi.check(lib.mpnhip_segment_reduce(capi.ptr(src), capi.ptr(row), m, dim, x_size, self.code, capi.ptr(res),
+                                                 None, capi.ptr(ws), ws.numel(), capi.stream_ptr()),
+                       "mpnhip_segment_reduce")
+        return res
+
+
+class EdgeModel(nn.Module):
+    """mpn.py:59-69."""
+
+    def __init__(self, edge_model):
+        super(EdgeModel, self).__init__()
+        self.edge_model = edge_model
+
+    def forward(self, node_feats, edge_index, edge_attr):
+        raise capi.MpnhipError("EdgeModel is evaluated fused inside MetaLayer.forward / MOTMPNet.forward "
+                               "(project-then-gather); call those")
+
+
+class TimeAwareNodeModel(nn.Module):
+    """mpn.py:71-99."""
+
+    def __init__(self, flow_in_model, flow_out_model, node_model, node_agg_fn):
+        super(TimeAwareNodeModel, self).__init__()
+        self.flow_in_model = flow_in_model
+        self.flow_out_model = flow_out_model
+        self.node_model = node_model
+        self.node_agg_fn = node_agg_fn
+
+    def forward(self, x, edge_index, edge_attr):
+        raise capi.MpnhipError("TimeAwareNodeModel is evaluated fused inside MetaLayer.forward / MOTMPNet.forward; "
+                               "call those")
+
+
+class MetaLayer(nn.Module):
+    """mpn.py:11-57: ``forward(x, edge_index, edge_attr) -> (x, edge_attr)``: edge update, then node
+    update on the updated edges.  One fused native call (``mpnhip_meta_layer_forward``)."""
+
+    def __init__(self, edge_model=None, node_model=None):
+        super(MetaLayer, self).__init__()
+        self.edge_model = edge_model
+        self.node_model = node_model
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.node_model, self.edge_model]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def core_struct(self, keep, agg_name=None):
+        """Fill the MetaLayer part of an ``mpnhip_model``."""
+        if not isinstance(self.edge_model, EdgeModel) or not isinstance(self.node_model, TimeAwareNodeModel):
+            raise capi.MpnhipError("MetaLayer needs an EdgeModel and a TimeAwareNodeModel (as MOTMPNet builds them)")
+        nm = self.node_model
+        m = capi.Model()
+        m.edge = self.edge_model.edge_model.c_struct(keep)
+        m.flow_in = nm.flow_in_model.c_struct(keep)
+        m.flow_out = nm.flow_out_model.c_struct(keep)
+        lin = nm.node_model[0]
+        capi.require_device(lin.weight)
+        capi.fill_mlp(m.node, [(lin.weight.detach(), lin.bias.detach())], keep=keep)
+        m.dn = int(lin.weight.shape[0])
+        m.de = int(m.edge.out_dims[m.edge.n_layers - 1])
+        agg = nm.node_agg_fn
+        m.agg = agg.code if isinstance(agg, NodeAggFn) else capi.AGG_CODE[agg_name or 'sum']
+        return m
+
+    def forward(self, x, edge_index, edge_attr):
+        capi.require_device(x, edge_index, edge_attr)
+        if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            raise capi.MpnhipError("operator-level MetaLayer.forward has no autograd; use MOTMPNet.forward for "
+                                   "training or wrap the call in torch.no_grad()")
+        lib = capi.load()
+        keep = []
+        m = self.core_struct(keep)
+        x = capi.f32c(x)
+        e = capi.f32c(edge_attr)
+        N, E = x.shape[0], e.shape[0]
+        # reattach factors follow from the input widths (mpn.py:276-285)
+        if x.shape[1] not in (m.dn, 2 * m.dn) or e.shape[1] not in (m.de, 2 * m.de):
+            raise capi.MpnhipError("MetaLayer input widths do not match the edge / flow MLP dims")
+        m.reattach_nodes = int(x.shape[1] == 2 * m.dn)
+        m.reattach_edges = int(e.shape[1] == 2 * m.de)
+        g = _prepared(edge_index, N)
+        x_new = torch.empty((N, m.dn), dtype=torch.float32, device=x.device)
+        e_new = torch.empty((E, m.de), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = capi.workspace(lib.mpnhip_meta_layer_workspace_bytes(m, N, E), x.device, "meta")
+            capi.check(lib.mpnhip_meta_layer_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(e), capi.ptr(x_new),
+                                                     capi.ptr(e_new), capi.ptr(ws), ws.numel(), capi.stream_ptr()),
+                       "mpnhip_meta_layer_forward")
+        return x_new, e_new
+
+    def __repr__(self):
+        return '{}(edge_model={}, node_model={})'.format(self.__class__.__name__, self.edge_model, self.node_model)
+
+
+class MLPGraphIndependent(nn.Module):
+    """mpn.py:139-178: independent node / edge MLPs (encoder, classifier)."""
+
+    def __init__(self, edge_in_dim=None, node_in_dim=None, edge_out_dim=None, node_out_dim=None,
+                 node_dims=None, edge_dims=None, dropout_p=None, use_batchnorm=None):
+        super(MLPGraphIndependent, self).__init__()
+        if node_in_dim is not None:
+            self.node_model = MLP(input_dim=node_in_dim, fc_dims=list(node_dims) + [node_out_dim],
+                                  dropout_p=dropout_p, use_batchnorm=use_batchnorm)
+        else:
+            self.node_model = None
+        if edge_in_dim is not None:
+            self.edge_model = MLP(input_dim=edge_in_dim, fc_dims=list(edge_dims) + [edge_out_dim],
+                                  dropout_p=dropout_p, use_batchnorm=use_batchnorm)
+        else:
+            self.edge_model = None
+
+    def forward(self, edge_feats=None, nodes_feats=None):
+        out_node_feats = self.node_model(nodes_feats) if self.node_model is not None else nodes_feats
+        out_edge_feats = self.edge_model(edge_feats) if self.edge_model is not None else edge_feats
+        return out_edge_feats, out_node_feats
+
+
+class MOTMPNet(nn.Module):
+    """mpn.py:209-394.  ``MOTMPNet(model_params, bb_encoder=None)``; ``forward(data)`` returns
+    ``{'classified_edges': [Tensor[E,1]] * num_class_steps, 'mask_predictions': [...]}``.
+
+    The encoder -> message passing -> classifier loop (the hot path) is ONE native call.  The x_ext /
+    attention / mask branch of the reference (mpn.py:102-137,180-206) never feeds back into the edge
+    logits and is not part of this build yet: ``mask_predictions`` is an empty list.
+    """
+
+    def __init__(self, model_params, bb_encoder=None):
+        super(MOTMPNet, self).__init__()
+        self.node_cnn = bb_encoder
+        self.model_params = model_params
+        encoder_feats_dict = model_params['encoder_feats_dict']
+        classifier_feats_dict = model_params['classifier_feats_dict']
+        self.encoder = MLPGraphIndependent(**encoder_feats_dict)
+        self.classifier = MLPGraphIndependent(**classifier_feats_dict)
+        self.MPNet = self._build_core_MPNet(model_params=model_params, encoder_feats_dict=encoder_feats_dict)
+        self.num_enc_steps = model_params['num_enc_steps']
+        self.num_class_steps = model_params['num_class_steps']
+        self.last_logits = None  # [max(L,1), E]: classifier output of every step (the mask branch's input)
+
+    def _build_core_MPNet(self, model_params, encoder_feats_dict):
+        """mpn.py:254-317."""
+        node_agg_fn = model_params['node_agg_fn']
+        assert node_agg_fn.lower() in ('mean', 'max', 'sum'), "node_agg_fn can only be 'max', 'mean' or 'sum'."
+        node_agg_fn = NodeAggFn(node_agg_fn)
+        self.reattach_initial_nodes = model_params['reattach_initial_nodes']
+        self.reattach_initial_edges = model_params['reattach_initial_edges']
+        self.edge_factor = 2 if self.reattach_initial_edges else 1
+        self.node_factor = 2 if self.reattach_initial_nodes else 1
+        edge_model_in_dim = self.node_factor * 2 * encoder_feats_dict['node_out_dim'] + \
+            self.edge_factor * encoder_feats_dict['edge_out_dim']
+        node_model_in_dim = self.node_factor * encoder_feats_dict['node_out_dim'] + encoder_feats_dict['edge_out_dim']
+        edge_model_feats_dict = model_params['edge_model_feats_dict']
+        node_model_feats_dict = model_params['node_model_feats_dict']
+        edge_model = MLP(input_dim=edge_model_in_dim, fc_dims=edge_model_feats_dict['dims'],
+                         dropout_p=edge_model_feats_dict['dropout_p'],
+                         use_batchnorm=edge_model_feats_dict['use_batchnorm'])
+        flow_in_model = MLP(input_dim=node_model_in_dim, fc_dims=node_model_feats_dict['dims'],
+                            dropout_p=node_model_feats_dict['dropout_p'],
+                            use_batchnorm=node_model_feats_dict['use_batchnorm'])
+        flow_out_model = MLP(input_dim=node_model_in_dim, fc_dims=node_model_feats_dict['dims'],
+                             dropout_p=node_model_feats_dict['dropout_p'],
+                             use_batchnorm=node_model_feats_dict['use_batchnorm'])
+        node_model = nn.Sequential(*[nn.Linear(2 * encoder_feats_dict['node_out_dim'],
+                                               encoder_feats_dict['node_out_dim']), nn.ReLU(inplace=True)])
+        return MetaLayer(edge_model=EdgeModel(edge_model=edge_model),
+                         node_model=TimeAwareNodeModel(flow_in_model=flow_in_model, flow_out_model=flow_out_model,
+                                                       node_model=node_model, node_agg_fn=node_agg_fn))
+
+    # ------------------------------------------------------------------ native model description
+    def hot_path_parameters(self):
+        """Parameters of the hot path in ``state_dict`` order (what the native backward fills)."""
+        mods = [self.encoder.node_model, self.encoder.edge_model, self.MPNet.edge_model.edge_model,
+                self.MPNet.node_model.flow_in_model, self.MPNet.node_model.flow_out_model]
+        out = []
+        for m in mods:
+            for l in m.linears():
+                out += [l.weight, l.bias]
+        lin = self.MPNet.node_model.node_model[0]
+        out += [lin.weight, lin.bias]
+        for l in self.classifier.edge_model.linears():
+            out += [l.weight, l.bias]
+        return out
+
+    def c_model(self, keep):
+        if self.encoder.node_model is None or self.encoder.edge_model is None or self.classifier.edge_model is None:
+            raise capi.MpnhipError("MOTMPNet needs node and edge encoders and an edge classifier")
+        m = self.MPNet.core_struct(keep)
+        m.reattach_nodes = int(bool(self.reattach_initial_nodes))
+        m.reattach_edges = int(bool(self.reattach_initial_edges))
+        m.num_enc_steps = int(self.num_enc_steps)
+        m.enc_node = self.encoder.node_model.c_struct(keep)
+        m.enc_edge = self.encoder.edge_model.c_struct(keep)
+        m.classifier = self.classifier.edge_model.c_struct(keep)
+        return m
+
+    def hot_path(self, x, edge_index, edge_attr, holder=None, return_state=False):
+        """Encoder + L message-passing steps + per-step classifier: logits [max(L,1), E]."""
+        capi.require_device(x, edge_index, edge_attr)
+        if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
+                                        any(p.requires_grad for p in self.hot_path_parameters())):
+            from .autograd import mpn_hot_path_autograd
+            return mpn_hot_path_autograd(self, x, edge_index, edge_attr, holder)
+        lib = capi.load()
+        keep = []
+        m = self.c_model(keep)
+        x = capi.f32c(x)
+        ea = capi.f32c(edge_attr)
+        N, E = x.shape[0], ea.shape[0]
+        if x.dim() != 2 or x.shape[1] != m.enc_node.in_dim or ea.dim() != 2 or ea.shape[1] != m.enc_edge.in_dim:
+            raise capi.MpnhipError("input feature widths do not match the encoder (node %s, edge %s)"
+                                   % (tuple(x.shape), tuple(ea.shape)))
+        g = _prepared(edge_index, N, holder)
+        L = max(int(self.num_enc_steps), 1)
+        logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
+        x_out = torch.empty((N, m.dn), dtype=torch.float32, device=x.device) if return_state else None
+        e_out = torch.empty((E, m.de), dtype=torch.float32, device=x.device) if return_state else None
+        with torch.cuda.device(x.device):
+            ws = capi.workspace(lib.mpnhip_forward_workspace_bytes(m, N, E, 0), x.device, "fwd")
+            capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits),
+                                          capi.ptr(x_out), capi.ptr(e_out), capi.ptr(ws), ws.numel(), 0,
+                                          capi.stream_ptr()), "mpnhip_forward")
+        if return_state:
+            return logits, x_out, e_out
+        return logits
+
+    def forward(self, data):
+        """mpn.py:333-394 (hot path; see the class docstring for the mask branch)."""
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        if x.dim() == 4:
+            # global_avgpool + view (mpn.py:351-352)
+            x = avg_pool(x)
+        logits = self.hot_path(x, edge_index, edge_attr, holder=data)
+        self.last_logits = logits
+        E = logits.shape[1]
+        L, k = int(self.num_enc_steps), int(self.num_class_steps)
+        outputs_dict = {'classified_edges': [], 'mask_predictions': []}
+        first_class_step = L - k + 1
+        for step in range(1, L + 1):
+            if step >= first_class_step:
+                outputs_dict['classified_edges'].append(logits[step - 1].view(E, 1))
+        if L == 0:
+            outputs_dict['classified_edges'].append(logits[0].view(E, 1))
+        return outputs_dict
+
+
+def avg_pool(x):
+    """nn.AdaptiveAvgPool2d((1,1)) + view (mpn.py:252,351-352): [N,C,H,W] -> [N,C]."""
+    capi.require_device(x)
+    from .autograd import avg_pool_native
+    return avg_pool_native(x)

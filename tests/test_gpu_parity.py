@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
+generated from the reference.  Tolerance (BASELINE.json north_star): edge logits
+within 1e-4 in fp32; for `sum` aggregation, whose magnitudes grow with depth, relative to the
+largest reference logit of the step:  |d| <= 1e-4 * max(1, max|ref|)."""
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import capi, synth
+from mpntrackseg_amd.mpn import MOTMPNet, NodeAggFn
+from mpntrackseg_amd.mlp import MLP
+from oracle import mpn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(1.0, float(np.abs(b).max())))
+
+
+def make_model(params, W):
+    model = MOTMPNet(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    return model.to(dev()).eval()
+
+
+class Data:
+    pass
+
+
+def run_hot(model, x, ei, ea):
+    with torch.no_grad():
+        logits, xo, eo = model.hot_path(torch.from_numpy(x).to(dev()), torch.from_numpy(ei).to(dev()),
+                                        torch.from_numpy(ea).to(dev()), return_state=True)
+    torch.cuda.synchronize()
+    return logits.cpu().numpy(), xo.cpu().numpy(), eo.cpu().numpy()
+
+
+def test_library_is_the_native_one():
+    lib = capi.load()
+    assert lib.mpnhip_version().decode().startswith("mpnhip")
+
+
+# ------------------------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("m,n,k,relu", [(1, 1, 1, 0), (5, 3, 6, 1), (130, 80, 160, 1), (257, 1, 8, 0), (1000, 18, 6, 1),
+                                        (4000, 320, 128, 1), (513, 56, 80, 1), (300, 128, 2048, 1), (64, 33, 37, 0)])
+def test_linear_matches_torch(m, n, k, relu):
+    x = synth.normal(1, (m, k), stream=1)
+    w = synth.normal(1, (n, k), stream=2, std=(2.0 / k) ** 0.5)
+    b = synth.normal(1, (n,), stream=3, std=0.1)
+    lib = capi.load()
+    xd, wd, bd = (torch.from_numpy(t).to(dev()) for t in (x, w, b))
+    y = torch.full((m, n), float("nan"), device=dev())
+    capi.check(lib.mpnhip_linear(capi.ptr(xd), k, capi.ptr(wd), capi.ptr(bd), capi.ptr(y), n, m, n, k, relu,
+                                 capi.stream_ptr()), "linear")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.linear(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double())
+    if relu:
+        ref = ref.relu()
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-6
+
+
+def test_mlp_module_matches_oracle():
+    mlp = MLP(6, [18, 18, 16], dropout_p=0, use_batchnorm=False)
+    W = {"m." + k: v.detach().clone() for k, v in mlp.state_dict().items()}
+    x = torch.from_numpy(synth.normal(2, (777, 6)))
+    ref = O.mlp(x, W, "m")
+    with torch.no_grad():
+        y = mlp.to(dev())(x.to(dev()))
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_node_agg_fn_golden(golden, agg):
+    z = golden("g5_modules.npz")
+    fn = NodeAggFn(agg)
+    out = fn(torch.from_numpy(z["msg"]).to(dev()), torch.from_numpy(z["edge_index"][0]).to(dev()), 40)
+    got = out.cpu().numpy()
+    assert rel_err(got, z[f"agg_{agg}"]) < 1e-6
+    if agg == "max":
+        assert np.array_equal(got, z[f"agg_{agg}"])  # max is exact
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+@pytest.mark.parametrize("m,dim,x_size", [(0, 8, 5), (1, 1, 1), (1000, 32, 50), (5000, 128, 700), (333, 7, 40), (2000, 260, 3)])
+def test_node_agg_fn_random(agg, m, dim, x_size):
+    src = np.maximum(synth.normal(4, (m, dim), stream=1), 0)  # post-ReLU messages: ties at 0
+    row = (synth.uniform01(4, m, stream=2) * x_size).astype(np.int64)
+    if m > 10:
+        row[row == 1] = 0  # leave an empty segment
+    out = NodeAggFn(agg)(torch.from_numpy(src).to(dev()), torch.from_numpy(row).to(dev()), x_size).cpu().numpy()
+    ref = O.AGG[agg](torch.from_numpy(src), torch.from_numpy(row), x_size).numpy()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-6
+
+
+def test_graph_prep_order():
+    g = synth.batch_graphs([synth.make_graph(50, 300, T=6, seed=s, node_in_dim=4) for s in (1, 2, 3)])
+    ei = g["edge_index"].copy()
+    ei[:, 7] = [5, 5]  # a self loop
+    N, E = 150, ei.shape[1]
+    pg = capi.PreparedGraph(torch.from_numpy(ei).to(dev()), N, validate=True)
+    st = pg.status()
+    d = np.where(ei[0] < ei[1], 0, np.where(ei[0] > ei[1], 1, 2))
+    assert st == [0, int((d == 0).sum()), int((d == 1).sum()), int((d == 2).sum())]
+    # perm is the first int array after the 256-byte header
+    buf = pg.buf.cpu().numpy()
+    perm = buf[256:256 + 4 * E].view(np.int32)
+    key = d * N + ei[0]
+    assert np.array_equal(perm, np.argsort(key, kind="stable"))
+    bad = ei.copy()
+    bad[1, 3] = N + 4
+    with pytest.raises(capi.MpnhipError):
+        capi.PreparedGraph(torch.from_numpy(bad).to(dev()), N, validate=True)
+
+
+def test_avg_pool():
+    from mpntrackseg_amd.mpn import avg_pool
+    x = synth.normal(6, (37, 64, 8, 4))
+    y = avg_pool(torch.from_numpy(x).to(dev())).cpu().numpy()
+    assert rel_err(y, x.astype(np.float64).mean(axis=(2, 3))) < 1e-6
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_meta_layer_golden(golden, agg):
+    z = golden("g5_modules.npz")
+    params = synth.model_params(32, 1, agg, node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=9))
+    with torch.no_grad():
+        xo, eo = model.MPNet(torch.from_numpy(z["x_in"]).to(dev()), torch.from_numpy(z["edge_index"]).to(dev()),
+                             torch.from_numpy(z["e_in"]).to(dev()))
+    assert rel_err(eo.cpu().numpy(), z[f"meta_e_{agg}"]) < 1e-5
+    assert rel_err(xo.cpu().numpy(), z[f"meta_x_{agg}"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ full hot path
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g1_tiny_full_forward(golden, agg):
+    z = golden(f"g1_tiny_{agg}.npz")
+    L = int(z["L"])
+    params = synth.model_params(32, L, agg, num_class_steps=3, node_in_dim=int(z["node_in_dim"]))
+    W = {k[2:]: z[k] for k in z.files if k.startswith("W:")}
+    model = make_model(params, W)
+    d = Data()
+    d.x = torch.from_numpy(z["x4"]).to(dev())            # [N, C, 8, 4]: avg-pool runs natively too
+    d.x_ext = None
+    d.edge_index = torch.from_numpy(z["edge_index"]).to(dev())
+    d.edge_attr = torch.from_numpy(z["edge_attr"]).to(dev())
+    with torch.no_grad():
+        out = model(d)
+    cls = out["classified_edges"]
+    assert len(cls) == 3 and cls[0].shape == (int(z["E"]), 1)
+    for s in range(3):
+        assert rel_err(cls[s].cpu().numpy().reshape(-1), z["logits"][L - 3 + s]) < TOL
+    assert rel_err(model.last_logits.cpu().numpy(), z["logits"]) < TOL
+    logits, xo, eo = run_hot(model, z["x_pooled"], z["edge_index"], z["edge_attr"])
+    assert rel_err(xo, z["x_final"]) < TOL and rel_err(eo, z["e_final"]) < TOL
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g4_structure(golden, agg):
+    z = golden("g4_structure.npz")
+    params = synth.model_params(32, 3, agg, node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=8))
+    logits, xo, eo = run_hot(model, z["x"], z["edge_index"], z["edge_attr"])
+    assert rel_err(logits, z[f"logits_{agg}"]) < TOL
+    assert rel_err(xo, z[f"x_final_{agg}"]) < TOL
+    assert rel_err(eo, z[f"e_final_{agg}"]) < TOL
+
+
+def test_g4_empty_graph(golden):
+    z = golden("g4_structure.npz")
+    params = synth.model_params(32, 2, "sum", node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=8))
+    logits, xo, eo = run_hot(model, z["x"][:5], np.zeros((2, 0), np.int64), np.zeros((0, 6), np.float32))
+    assert logits.shape == (2, 0) and eo.shape == (0, 16)
+    assert rel_err(xo, z["empty_x_final"]) < TOL
+
+
+def test_g0_zero_steps(golden):
+    z = golden("g0_l0.npz")
+    params = synth.model_params(32, 0, "sum", num_class_steps=0, node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=7))
+    g = synth.make_graph(30, 100, T=5, seed=2, node_in_dim=64)
+    d = Data()
+    d.x = torch.from_numpy(g["x"]).view(30, 64, 1, 1).to(dev())
+    d.edge_index = torch.from_numpy(g["edge_index"]).to(dev())
+    d.edge_attr = torch.from_numpy(g["edge_attr"]).to(dev())
+    with torch.no_grad():
+        out = model(d)
+    assert len(out["classified_edges"]) == 1
+    assert rel_err(out["classified_edges"][0].cpu().numpy().reshape(-1), z["logits"]) < TOL
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g2_cfgA_golden(golden, agg):
+    z = golden(f"g2_cfgA_{agg}.npz")
+    c = synth.CONFIGS["A"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    assert synth.checksum(g["x"]) == int(z["cs_x"])
+    params = synth.model_params(c["d"], c["L"], agg)
+    model = make_model(params, synth.make_weights(params, seed=7))
+    logits, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    for s in range(c["L"]):
+        assert rel_err(logits[s], z["logits"][s]) < TOL, s
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g3_cfgB_golden(golden, agg):
+    """BASELINE.json configs[1]: 5k nodes / 50k edges / 128-d / 12 steps, fp32."""
+    z = golden(f"g3_cfgB_{agg}.npz")
+    c = synth.CONFIGS["B"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    assert synth.checksum(g["x"]) == int(z["cs_x"])
+    params = synth.model_params(c["d"], c["L"], agg)
+    W = synth.make_weights(params, seed=7)
+    assert synth.checksum(np.concatenate([v.ravel() for v in W.values()])) == int(z["cs_weights"])
+    model = make_model(params, W)
+    logits, xo, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    ids = z["edge_ids"]
+    for s in range(c["L"]):
+        scale = max(1.0, float(z["step_max"][s]))
+        assert float(np.abs(logits[s, ids] - z["logits"][s]).max()) / scale < TOL, s
+        # whole-tensor checksums of the reference run
+        assert abs(float(np.abs(logits[s]).max()) - float(z["step_max"][s])) / scale < TOL
+        assert abs(float(np.abs(logits[s]).astype(np.float64).sum()) - float(z["step_abssum"][s])) / (scale * c["E"]) < TOL
+    assert rel_err(xo[:64], z["x_final_rows"]) < TOL
+
+
+def test_permutation_equivariance_full_size():
+    """Size-independent property at the full cfg-B size: relabelling the edges permutes the logits.
+    (Node relabelling would change which edges are past / future, so only the edge order is shuffled.)"""
+    c = synth.CONFIGS["B"]
+    g = synth.make_graph(c["N"], c["E"], seed=3)
+    params = synth.model_params(c["d"], 3, "mean")
+    model = make_model(params, synth.make_weights(params, seed=7))
+    p = np.argsort(synth.uniform01(8, c["E"]), kind="stable")
+    a, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    b, _, _ = run_hot(model, g["x"], g["edge_index"][:, p], g["edge_attr"][p])
+    # mean aggregation sums in edge order, so allow re-association noise
+    assert rel_err(b, a[:, p]) < 1e-5
+
+
+def test_oracle_random_graph_with_hubs():
+    """Skewed degrees (a few hub nodes) + no reattach flags, against the oracle directly."""
+    N, E = 300, 6000
+    g = synth.make_graph(N, E, T=12, seed=9, node_in_dim=32)
+    ei = g["edge_index"].copy()
+    half = E // 2
+    hub = (synth.uniform01(10, half) < 0.3)
+    lo = np.where(hub, 0, ei[0, :half])
+    hi = np.where(hub & (ei[1, :half] == 0), 1, ei[1, :half])
+    ei = np.stack([np.concatenate([lo, hi]), np.concatenate([hi, lo])])
+    for agg in ("sum", "max"):
+        params = synth.model_params(32, 2, agg, node_in_dim=32)
+        params["reattach_initial_nodes"] = False
+        params["reattach_initial_edges"] = False
+        W = synth.make_weights(params, seed=12)
+        model = make_model(params, W)
+        logits, xo, eo = run_hot(model, g["x"], ei, g["edge_attr"])
+        with torch.no_grad():
+            _, ref, xr, er = O.forward(params, O.to_tensors(W), torch.from_numpy(g["x"]), torch.from_numpy(ei),
+                                       torch.from_numpy(g["edge_attr"]), return_state=True)
+        ref = torch.stack(ref).numpy().reshape(2, -1)
+        assert rel_err(logits, ref) < TOL
+        assert rel_err(xo, xr.numpy()) < TOL and rel_err(eo, er.numpy()) < TOL
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference interface: constructor arguments, attribute names and
+state_dict keys -- checked on CPU; forward refuses to run without a HIP device."""
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import capi, synth
+from mpntrackseg_amd.mpn import MOTMPNet, MetaLayer, EdgeModel, TimeAwareNodeModel, MLPGraphIndependent
+from mpntrackseg_amd.mlp import MLP
+
+REFERENCE_DEFAULT_KEYS = [
+    # [probe] list of SURVEY.md section 8b for configs/tracking_cfg.yaml:134-168
+    "encoder.node_model.fc_layers.0.weight", "encoder.node_model.fc_layers.0.bias",
+    "encoder.node_model.fc_layers.2.weight", "encoder.node_model.fc_layers.2.bias",
+    "encoder.edge_model.fc_layers.0.weight", "encoder.edge_model.fc_layers.0.bias",
+    "encoder.edge_model.fc_layers.2.weight", "encoder.edge_model.fc_layers.2.bias",
+    "encoder.edge_model.fc_layers.4.weight", "encoder.edge_model.fc_layers.4.bias",
+    "MPNet.edge_model.edge_model.fc_layers.0.weight", "MPNet.edge_model.edge_model.fc_layers.0.bias",
+    "MPNet.edge_model.edge_model.fc_layers.2.weight", "MPNet.edge_model.edge_model.fc_layers.2.bias",
+    "MPNet.node_model.flow_in_model.fc_layers.0.weight", "MPNet.node_model.flow_in_model.fc_layers.0.bias",
+    "MPNet.node_model.flow_in_model.fc_layers.2.weight", "MPNet.node_model.flow_in_model.fc_layers.2.bias",
+    "MPNet.node_model.flow_out_model.fc_layers.0.weight", "MPNet.node_model.flow_out_model.fc_layers.0.bias",
+    "MPNet.node_model.flow_out_model.fc_layers.2.weight", "MPNet.node_model.flow_out_model.fc_layers.2.bias",
+    "MPNet.node_model.node_model.0.weight", "MPNet.node_model.node_model.0.bias",
+    "classifier.edge_model.fc_layers.0.weight", "classifier.edge_model.fc_layers.0.bias",
+    "classifier.edge_model.fc_layers.2.weight", "classifier.edge_model.fc_layers.2.bias",
+]
+
+
+def default_params():
+    p = synth.model_params(32, 4, "sum", num_class_steps=3)
+    return p
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    model = MOTMPNet(default_params())
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == sorted(REFERENCE_DEFAULT_KEYS)
+    shapes = synth.hot_path_param_shapes(default_params())
+    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes
+    assert sd["MPNet.edge_model.edge_model.fc_layers.0.weight"].shape == (80, 160)
+    assert sd["MPNet.node_model.flow_in_model.fc_layers.0.weight"].shape == (56, 80)
+    assert sd["encoder.node_model.fc_layers.0.weight"].shape == (128, 2048)
+    assert sum(v.numel() for v in sd.values()) == 296293  # hot-path parameter count
+
+
+def test_attributes_like_reference():
+    m = MOTMPNet(default_params())
+    assert m.num_enc_steps == 4 and m.num_class_steps == 3
+    assert m.edge_factor == 2 and m.node_factor == 2
+    assert isinstance(m.MPNet, MetaLayer) and isinstance(m.MPNet.edge_model, EdgeModel)
+    assert isinstance(m.MPNet.node_model, TimeAwareNodeModel)
+    assert isinstance(m.encoder, MLPGraphIndependent) and isinstance(m.classifier.edge_model, MLP)
+    assert m.classifier.node_model is None
+    assert m.MPNet.node_model.node_agg_fn.name == "sum"
+    p = default_params()
+    p["reattach_initial_nodes"] = False
+    p["reattach_initial_edges"] = False
+    m2 = MOTMPNet(p)
+    assert m2.MPNet.edge_model.edge_model.fc_layers[0].weight.shape == (80, 2 * 32 + 16)
+
+
+def test_bad_agg_asserts_like_reference():
+    p = default_params()
+    p["node_agg_fn"] = "median"
+    with pytest.raises(AssertionError):
+        MOTMPNet(p)
+    with pytest.raises(AssertionError):
+        MLP(4, 8)
+
+
+def test_mlp_layer_rule():
+    # ReLU after every layer whose out dim != 1 (mlp.py:17); BN / dropout as requested
+    m = MLP(6, [18, 1, 4], dropout_p=0.5, use_batchnorm=True)
+    kinds = [type(l).__name__ for l in m.fc_layers]
+    assert kinds == ["Linear", "BatchNorm1d", "ReLU", "Dropout", "Linear", "Linear", "BatchNorm1d", "ReLU", "Dropout"]
+    assert not m.fast_path
+
+
+def test_forward_refuses_cpu_tensors():
+    model = MOTMPNet(default_params())
+
+    class D:
+        pass
+    d = D()
+    d.x = torch.zeros(4, 2048)
+    d.edge_index = torch.zeros(2, 0, dtype=torch.int64)
+    d.edge_attr = torch.zeros(0, 6)
+    with pytest.raises(capi.MpnhipError):
+        model(d)
+    with pytest.raises(capi.MpnhipError):
+        model.MPNet(torch.zeros(4, 64), d.edge_index, torch.zeros(0, 32))
+    with pytest.raises(capi.MpnhipError):
+        model.encoder.node_model(torch.zeros(4, 2048))
+
+
+def test_synth_is_deterministic_and_structured():
+    g = synth.make_graph(100, 600, seed=3, node_in_dim=8)
+    g2 = synth.make_graph(100, 600, seed=3, node_in_dim=8)
+    assert all(np.array_equal(g[k], g2[k]) for k in g)
+    ei = g["edge_index"]
+    assert ei.shape == (2, 600)
+    assert (ei[0, :300] < ei[1, :300]).all() and np.array_equal(ei[0, :300], ei[1, 300:])
+    assert np.array_equal(g["edge_attr"][:300], g["edge_attr"][300:])
+    assert (g["frame"][ei[0]] != g["frame"][ei[1]]).all()
+    assert len({(a, b) for a, b in ei[:, :300].T.tolist()}) == 300
+    v = synth.normal(5, (200000,))
+    assert abs(float(v.mean())) < 0.01 and abs(float(v.std()) - 1.0) < 0.01
