@@ -304,6 +304,7 @@ int launch_gemm(const GemmArgs& a, int al, int bl, hipStream_t s) {
     MPN_CHECK_ARG(a.ngroups == 1 || a.ngroups == 2, "gemm: ngroups %d", a.ngroups);
     MPN_CHECK_ARG(a.K >= 0 && a.N >= 0 && a.ksplit >= 0 && a.ksplit <= a.K, "gemm: bad N/K/ksplit");
     MPN_CHECK_ARG(a.m_upper < (int64_t)2147483647 - 256, "gemm: too many rows for int32 indexing");
+    if (a.m_upper <= 0 || a.N == 0) return MPNHIP_OK;  // nothing to compute (empty graph)
     for (int i = 0; i < a.ngroups; ++i) {
         MPN_CHECK_ARG(a.g[i].A && a.g[i].B && a.g[i].C, "gemm: null operand");
         MPN_CHECK_ARG(a.ksplit == a.K || a.g[i].A2, "gemm: ksplit without a second A segment");
