@@ -81,10 +81,7 @@ struct GemmArgs {
     int relu;              // max(.,0) at the end
     int accumulate;        // C += result (after mask / relu)
     int64_t m_upper;       // host-side upper bound of the total row count (sizes the grid)
-    // split-K over the k range (used by the weight-gradient products): the grid's z dimension
-    // enumerates slices of `kslice` consecutive k; slice z writes C + z * c_slice_stride
-    int kslice;
-    int64_t c_slice_stride;
+    int epi_vec;           // set by launch_gemm: epilogue operands allow 16-byte vector access
 };
 
 int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);

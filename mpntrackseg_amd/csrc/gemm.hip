@@ -1,15 +1,26 @@
 // fp32 MFMA GEMM with fused prologue / epilogue for the MPN hot path (gfx950).
 //
-// One kernel template covers every dense product of the path:
+// One kernel template covers every dense product of the forward path (SURVEY.md section 2.4,
+// K2/K4/K6/K8/K9) and the activation-gradient products of the backward path:
 //   C[m, n] = act( sum_k A[m, k] * B[k, n] + bias[n] + G1[i1(m)][n] + G2[i2(m)][n] ) (* mask) (+ C)
-// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD).
-// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 32; operands are staged
-// global -> registers -> LDS in k-major images As[k][m], Bs[k][n] (pitch == 1 mod 8 dwords), so
-//   * the transposing ds_write_b32 of a K-contiguous operand hits 32 distinct banks per half wave,
-//   * every MFMA operand fetch is one conflict-free ds_read_b32 (lanes 0-31 consecutive m, lanes
-//     32-63 the next k),
-// double buffered with one barrier per K step; the next tile's global loads are in flight while the
-// current tile's MFMAs issue.
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the fp32 peak).
+//
+// Geometry: 256 threads = 4 waves arranged WM x WN; every wave owns a 32 x (32 TN) strip of C
+// (TN accumulator tiles of 16 VGPRs), so the block tile is (32 WM) x (32 TN WN).  TN is chosen per
+// launch so that the MLP widths of the model (320, 224, 128, 64, 1088 ...) are covered without padding.
+// K step 32: both operands are staged global -> registers -> LDS as k-major images As[k][m], Bs[k][n]
+//   * K-contiguous operands are written transposed with ds_write_b32 at pitch == 1 (mod 8) dwords:
+//     32 distinct banks per half wave;
+//   * every MFMA operand fetch is one conflict-free ds_read_b32 (lanes 0-31 consecutive m / n,
+//     lanes 32-63 the next k).
+// The next K step's global loads are issued before the current step's MFMAs and written to LDS after
+// them (register prefetch); fp32 MFMAs are slow enough (64 clk each) that one LDS stage suffices and
+// the smaller footprint buys 3-4 resident blocks per CU.  All global loads are unconditional (clamped
+// addresses, zero-selected values): no branch, hence no vmcnt(0) serialisation between them.
+//
+// Epilogue: each wave passes its 32x32 accumulator tiles through a private LDS patch and leaves it
+// as whole 128-byte row segments: bias, the two row gathers, ReLU(-mask) and the store are all 16-byte
+// vector accesses of contiguous row pieces -- the access shape gathers of whole rows want.
 //
 // The gather-add epilogue is what makes "project-then-gather" possible: the node
 // halves of the edge / flow MLP's first layer are computed once per NODE and added per edge here,
@@ -24,21 +35,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
-template <int BM, int BN, int WM, int WN, int ALAY, int BLAY>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
-    constexpr int PA = BM + 1;  // LDS pitches (dwords); BM, BN are multiples of 8 -> pitch % 8 == 1
-    constexpr int PB = BN + 1;
-    constexpr int TM = BM / WM / 32;  // 32x32 MFMA tiles per wave
-    constexpr int TN = BN / WN / 32;
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(TM >= 1 && TN >= 1, "tile too small");
-    constexpr int A_F4 = BM * BK / 4 / NTHREADS;  // float4 loads per thread (K-contiguous A)
-    constexpr int B_F4 = BN * BK / 4 / NTHREADS;
-    constexpr int A_DW = BM * BK / NTHREADS;  // dword loads per thread (M-contiguous A)
-    constexpr int B_DW = BN * BK / NTHREADS;
-    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for the loader");
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-    __shared__ float smem[2 * BK * (PA + PB)];
+template <int WM, int WN, int TN, int BLAY>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int PA = BM + 1;                                 // pitch % 8 == 1 (transposing stores)
+    constexpr int PB = BLAY == B_KCONTIG ? BN + 1 : BN + 4;    // N-contiguous B keeps 16-byte rows
+    constexpr int A_F4 = BM / 32;                              // float4 loads per thread and K step
+    constexpr int B_F4 = BN / 32;
+    constexpr int PATCH = 32 * 36;                             // per-wave epilogue patch [32][36]
+    constexpr int TILE_FLOATS = BK * (PA + PB);
+    constexpr int SMEM_FLOATS = TILE_FLOATS > 4 * PATCH ? TILE_FLOATS : 4 * PATCH;
+
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float* As = smem;
+    float* Bs = smem + BK * PA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,257 +88,294 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
     const int col0 = blockIdx.x * BN;
     const int N = args.N, K = args.K, ksplit = args.ksplit;
 
-    // ---- loader set-up --------------------------------------------------------------------------
-    // K-contiguous operand: thread covers rows (tid/8 + 32 j), k offset (tid%8)*4 of each K step.
+    // ---- loader set-up: thread covers tile rows (tid/8 + 32 j) at k offset (tid%8)*4 --------------
     const int ld_r = tid >> 3, ld_k4 = (tid & 7) * 4;
-    int64_t a_off[ALAY == A_KCONTIG ? A_F4 : 1], a_off2[ALAY == A_KCONTIG ? A_F4 : 1];
-    bool a_ok[ALAY == A_KCONTIG ? A_F4 : 1];
-    if (ALAY == A_KCONTIG) {
+    const float* a_p1[A_F4];
+    const float* a_p2[A_F4];
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) {
-            int r = row0 + ld_r + 32 * j;
-            a_ok[j] = r < row_end;
-            int64_t ri = a_ok[j] ? (G.a_idx ? (int64_t)G.a_idx[r] : (int64_t)r) : 0;
-            a_off[j] = ri * G.lda;
-            a_off2[j] = ri * G.lda2;
-        }
+    for (int j = 0; j < A_F4; ++j) {
+        int r = row0 + ld_r + 32 * j;
+        r = r < row_end ? r : row_end - 1;  // rows past the end are computed but never stored
+        int64_t ri = G.a_idx ? (int64_t)G.a_idx[r] : (int64_t)r;
+        a_p1[j] = G.A + ri * G.lda;
+        a_p2[j] = G.A2 ? G.A2 + ri * G.lda2 - ksplit : a_p1[j];
     }
-    int64_t b_off[BLAY == B_KCONTIG ? B_F4 : 1];
-    bool b_ok[BLAY == B_KCONTIG ? B_F4 : 1];
-    if (BLAY == B_KCONTIG) {
+    // B_KCONTIG: rows are output columns n (weight rows); B_NCONTIG: thread covers k = tid/(BN/4) + .., n4
+    const float* b_p[B_F4];
+    int b_k[B_F4];  // B_NCONTIG: k row inside the tile
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) {
+    for (int j = 0; j < B_F4; ++j) {
+        if (BLAY == B_KCONTIG) {
             int n = col0 + ld_r + 32 * j;
-            b_ok[j] = n < N;
-            b_off[j] = (int64_t)(b_ok[j] ? n : 0) * G.ldb;
+            n = n < N ? n : N - 1;
+            b_p[j] = G.B + (int64_t)n * G.ldb;
+            b_k[j] = 0;
+        } else {
+            int f = tid + NTHREADS * j;          // float4 index inside the [BK][BN/4] tile
+            int kr = f / (BN / 4), n4 = f % (BN / 4);
+            int n = col0 + n4 * 4;
+            n = n + 3 < N ? n : (N - 4);          // N % 4 == 0 on this path; clamped columns are never stored
+            b_p[j] = G.B + n;
+            b_k[j] = kr;
         }
     }
-    const bool a_vec = ((G.lda & 3) == 0) && ((G.lda2 & 3) == 0) && ((ksplit & 3) == 0) &&
-                       ((((uintptr_t)G.A) & 15) == 0) && ((((uintptr_t)G.A2) & 15) == 0);
-    const bool b_vec = ((G.ldb & 3) == 0) && ((((uintptr_t)G.B) & 15) == 0);
 
-    float4 a_reg[ALAY == A_KCONTIG ? A_F4 : (A_DW + 3) / 4];
-    float4 b_reg[BLAY == B_KCONTIG ? B_F4 : (B_DW + 3) / 4];
+    float4 a_reg[A_F4], b_reg[B_F4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int kt) {
-        const int kbase = kt * BK;
-        if (ALAY == A_KCONTIG) {
-            const int k = kbase + ld_k4;
-            const bool seg2 = k >= ksplit;
-            const float* base = seg2 ? G.A2 : G.A;
-            const int kk = seg2 ? k - ksplit : k;
-            const int klim = seg2 ? K - ksplit : ksplit;  // elements available in this segment
+        const int k = kt * BK + ld_k4;
+        const bool k_ok = k < K;                 // K % 4 == 0: a float4 is entirely in or out
+        const int kc = k_ok ? k : 0;
+        const bool seg2 = kc >= ksplit;
 #pragma unroll
-            for (int j = 0; j < A_F4; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a_ok[j] && kk < klim) {
-                    const float* p = base + (seg2 ? a_off2[j] : a_off[j]) + kk;
-                    if (a_vec && kk + 3 < klim) {
-                        v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        // ragged tail (or unaligned operand): element-wise, may cross into segment 2
-                        float t[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            int kq = k + q;
-                            float val = 0.f;
-                            if (kq < K) {
-                                bool s2 = kq >= ksplit;
-                                const float* bq = s2 ? G.A2 : G.A;
-                                val = bq[(s2 ? a_off2[j] : a_off[j]) + (s2 ? kq - ksplit : kq)];
-                            }
-                            t[q] = val;
-                        }
-                        v = make_float4(t[0], t[1], t[2], t[3]);
-                    }
-                }
-                a_reg[j] = v;
-            }
-        } else {
-            // A stored [k][m]: thread covers m = tid % BM, k = tid / BM + (256/BM) * j
-            constexpr int KSTEP = NTHREADS / BM;
-            const int m = row0 + (tid % BM);
-            float* ar = reinterpret_cast<float*>(a_reg);
-#pragma unroll
-            for (int j = 0; j < A_DW; ++j) {
-                int k = kbase + tid / BM + KSTEP * j;
-                ar[j] = (m < row_end && k < K) ? G.A[(int64_t)k * G.lda + m] : 0.f;
-            }
+        for (int j = 0; j < A_F4; ++j) {
+            float4 v = ld4((seg2 ? a_p2[j] : a_p1[j]) + kc);
+            a_reg[j] = k_ok ? v : zero4;
         }
-        if (BLAY == B_KCONTIG) {
-            const int k = kbase + ld_k4;
 #pragma unroll
-            for (int j = 0; j < B_F4; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b_ok[j] && k < K) {
-                    const float* p = G.B + b_off[j] + k;
-                    if (b_vec && k + 3 < K) {
-                        v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        v.x = p[0];
-                        v.y = (k + 1 < K) ? p[1] : 0.f;
-                        v.z = (k + 2 < K) ? p[2] : 0.f;
-                        v.w = (k + 3 < K) ? p[3] : 0.f;
-                    }
-                }
-                b_reg[j] = v;
-            }
-        } else {
-            constexpr int KSTEP = NTHREADS / BN;
-            const int n = col0 + (tid % BN);
-            float* br = reinterpret_cast<float*>(b_reg);
-#pragma unroll
-            for (int j = 0; j < B_DW; ++j) {
-                int k = kbase + tid / BN + KSTEP * j;
-                br[j] = (n < N && k < K) ? G.B[(int64_t)k * G.ldb + n] : 0.f;
+        for (int j = 0; j < B_F4; ++j) {
+            if (BLAY == B_KCONTIG) {
+                b_reg[j] = ld4(b_p[j] + kc);     // A is zero beyond K, B may hold anything finite there
+                if (!k_ok) b_reg[j] = zero4;
+            } else {
+                int kk = kt * BK + b_k[j];
+                bool ok = kk < K;
+                float4 v = ld4(b_p[j] + (int64_t)(ok ? kk : 0) * G.ldb);
+                b_reg[j] = ok ? v : zero4;
             }
         }
     };
 
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * BK * (PA + PB);
-        float* Bs = As + BK * PA;
-        if (ALAY == A_KCONTIG) {
+    auto store_tile = [&]() {
 #pragma unroll
-            for (int j = 0; j < A_F4; ++j) {
-                int r = ld_r + 32 * j;
-                As[(ld_k4 + 0) * PA + r] = a_reg[j].x;
-                As[(ld_k4 + 1) * PA + r] = a_reg[j].y;
-                As[(ld_k4 + 2) * PA + r] = a_reg[j].z;
-                As[(ld_k4 + 3) * PA + r] = a_reg[j].w;
-            }
-        } else {
-            constexpr int KSTEP = NTHREADS / BM;
-            const float* ar = reinterpret_cast<const float*>(a_reg);
-#pragma unroll
-            for (int j = 0; j < A_DW; ++j) As[(tid / BM + KSTEP * j) * PA + (tid % BM)] = ar[j];
+        for (int j = 0; j < A_F4; ++j) {
+            int r = ld_r + 32 * j;
+            As[(ld_k4 + 0) * PA + r] = a_reg[j].x;
+            As[(ld_k4 + 1) * PA + r] = a_reg[j].y;
+            As[(ld_k4 + 2) * PA + r] = a_reg[j].z;
+            As[(ld_k4 + 3) * PA + r] = a_reg[j].w;
         }
-        if (BLAY == B_KCONTIG) {
 #pragma unroll
-            for (int j = 0; j < B_F4; ++j) {
+        for (int j = 0; j < B_F4; ++j) {
+            if (BLAY == B_KCONTIG) {
                 int r = ld_r + 32 * j;
                 Bs[(ld_k4 + 0) * PB + r] = b_reg[j].x;
                 Bs[(ld_k4 + 1) * PB + r] = b_reg[j].y;
                 Bs[(ld_k4 + 2) * PB + r] = b_reg[j].z;
                 Bs[(ld_k4 + 3) * PB + r] = b_reg[j].w;
+            } else {
+                int f = tid + NTHREADS * j;
+                int kr = f / (BN / 4), n4 = f % (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[kr * PB + n4 * 4]) = b_reg[j];
             }
-        } else {
-            constexpr int KSTEP = NTHREADS / BN;
-            const float* br = reinterpret_cast<const float*>(b_reg);
-#pragma unroll
-            for (int j = 0; j < B_DW; ++j) Bs[(tid / BN + KSTEP * j) * PB + (tid % BN)] = br[j];
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    const int a_base = wm * (BM / WM) + li;
-    const int b_base = wn * (BN / WN) + li;
+    load_tile(0);
+    const int a_base = wm * 32 + li;
+    const int b_base = wn * 32 * TN + li;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        store_tile();
+        __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
-        const float* As = smem + buf * BK * (PA + PB);
-        const float* Bs = As + BK * PA;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lh) * PA + a_base + 32 * i];
+            const float a = As[(kk + lh) * PA + a_base];
+            float b[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lh) * PB + b_base + 32 * j];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: D[i][j] of a 32x32 tile: j = lane & 31, i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // ---- epilogue ------------------------------------------------------------------------------
+    // D[i][j] of a 32x32 tile: j = lane & 31, i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // The wave's patch is [32 rows][36]: written column-wise (conflict free), read back as float4 rows:
+    // lane -> row (lane / 8 + 8 p), columns 4 (lane % 8) .. +3.
+    float* patch = smem + wave * PATCH;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const bool vec_ok = args.epi_vec != 0;
+    int m_row[4];
+    int64_t g1_off[4], g2_off[4], c_off[4];
+    bool m_ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int m = row0 + wm * 32 + er + 8 * p;
+        m_ok[p] = m < row_end;
+        int mc = m_ok[p] ? m : row_end - 1;
+        m_row[p] = mc;
+        g1_off[p] = (int64_t)(G.g1_idx ? G.g1_idx[mc] : mc) * G.ldg1;
+        g2_off[p] = (int64_t)(G.g2_idx ? G.g2_idx[mc] : mc) * G.ldg2;
+        c_off[p] = (int64_t)(G.c_idx ? G.c_idx[mc] : mc) * G.ldc;
+    }
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
-        const int n = col0 + wn * (BN / WN) + tj * 32 + li;
-        const bool n_ok = n < N;
-        const float bias = (n_ok && G.bias) ? G.bias[n] : 0.f;
+        const int ncol0 = col0 + wn * 32 * TN + tj * 32;
+        if (ncol0 >= N) break;  // wave-uniform
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti) {
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[tj][r];
+        // same wave wrote and reads: LDS operations of one wave complete in order
+        const int n = ncol0 + ec;
+        if (vec_ok) {
+            const bool n_ok = n < N;          // N % 4 == 0 here
+            const int nc = n_ok ? n : N - 4;
+            float4 bias = G.bias ? ld4(G.bias + nc) : zero4;
+            float4 v[4], g1[4], g2[4], mk[4], old[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + wm * (BM / WM) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < row_end && n_ok) {
-                    float v = acc[ti][tj][r] + bias;
-                    if (G.G1) v += G.G1[(int64_t)(G.g1_idx ? G.g1_idx[m] : m) * G.ldg1 + n];
-                    if (G.G2) v += G.G2[(int64_t)(G.g2_idx ? G.g2_idx[m] : m) * G.ldg2 + n];
-                    if (args.relu) v = fmaxf(v, 0.f);
-                    if (G.mask) v = (G.mask[(int64_t)m * G.ldmask + n] > 0.f) ? v : 0.f;
-                    float* cp = G.C + (int64_t)(G.c_idx ? G.c_idx[m] : m) * G.ldc + n;
-                    if (args.accumulate) v += *cp;
-                    *cp = v;
+            for (int p = 0; p < 4; ++p) {
+                v[p] = *reinterpret_cast<const float4*>(&patch[(er + 8 * p) * 36 + ec]);
+                g1[p] = G.G1 ? ld4(G.G1 + g1_off[p] + nc) : zero4;
+                g2[p] = G.G2 ? ld4(G.G2 + g2_off[p] + nc) : zero4;
+                mk[p] = G.mask ? ld4(G.mask + (int64_t)m_row[p] * G.ldmask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                old[p] = args.accumulate ? ld4(G.C + c_off[p] + nc) : zero4;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 o;
+                o.x = v[p].x + bias.x + g1[p].x + g2[p].x;
+                o.y = v[p].y + bias.y + g1[p].y + g2[p].y;
+                o.z = v[p].z + bias.z + g1[p].z + g2[p].z;
+                o.w = v[p].w + bias.w + g1[p].w + g2[p].w;
+                if (args.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                o.x = mk[p].x > 0.f ? o.x : 0.f; o.y = mk[p].y > 0.f ? o.y : 0.f;
+                o.z = mk[p].z > 0.f ? o.z : 0.f; o.w = mk[p].w > 0.f ? o.w : 0.f;
+                o.x += old[p].x; o.y += old[p].y; o.z += old[p].z; o.w += old[p].w;
+                if (m_ok[p] && n_ok) *reinterpret_cast<float4*>(G.C + c_off[p] + nc) = o;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nq = n + q;
+                    const bool ok = m_ok[p] && nq < N;
+                    const int nc = nq < N ? nq : N - 1;
+                    float o = patch[(er + 8 * p) * 36 + ec + q];
+                    if (G.bias) o += G.bias[nc];
+                    if (G.G1) o += G.G1[g1_off[p] + nc];
+                    if (G.G2) o += G.G2[g2_off[p] + nc];
+                    if (args.relu) o = fmaxf(o, 0.f);
+                    if (G.mask) o = G.mask[(int64_t)m_row[p] * G.ldmask + nc] > 0.f ? o : 0.f;
+                    if (args.accumulate) o += G.C[c_off[p] + nc];
+                    if (ok) G.C[c_off[p] + nc] = o;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmArgs& a, int al, int bl, hipStream_t s) {
-    int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
-    if (nby <= 0 || a.N <= 0) return MPNHIP_OK;
-    dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
-    if (al == A_KCONTIG && bl == B_KCONTIG)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KCONTIG, B_KCONTIG>), grid, dim3(NTHREADS), 0, s, a);
-    else if (al == A_KCONTIG && bl == B_NCONTIG)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KCONTIG, B_NCONTIG>), grid, dim3(NTHREADS), 0, s, a);
-    else if (al == A_MCONTIG && bl == B_NCONTIG)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_MCONTIG, B_NCONTIG>), grid, dim3(NTHREADS), 0, s, a);
-    else {
-        set_error("gemm: unsupported operand layout %d/%d", al, bl);
-        return MPNHIP_ERR_UNSUPPORTED;
+// Any shape / alignment, one thread per output element: the K = 6 / 18-wide encoder layers of the
+// d = 32 configuration and other operands that are not 16-byte aligned.  Not a hot kernel.
+__global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, int b_layout) {
+    const int N = args.N, K = args.K, ksplit = args.ksplit;
+    for (int grp = 0; grp < args.ngroups; ++grp) {
+        const GemmGroup& G = args.g[grp];
+        const int b = G.row_begin ? *G.row_begin : 0;
+        const int e = G.row_end ? *G.row_end : (int)G.m_static;
+        const int64_t total = (int64_t)(e - b) * N;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int m = b + (int)(t / N), n = (int)(t % N);
+            const int64_t ri = G.a_idx ? G.a_idx[m] : m;
+            const float* a1 = G.A + ri * G.lda;
+            const float* a2 = G.A2 ? G.A2 + ri * G.lda2 - ksplit : a1;
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float av = (k >= ksplit ? a2 : a1)[k];
+                float bv = b_layout == B_KCONTIG ? G.B[(int64_t)n * G.ldb + k] : G.B[(int64_t)k * G.ldb + n];
+                acc = fmaf(av, bv, acc);
+            }
+            if (G.bias) acc += G.bias[n];
+            if (G.G1) acc += G.G1[(int64_t)(G.g1_idx ? G.g1_idx[m] : m) * G.ldg1 + n];
+            if (G.G2) acc += G.G2[(int64_t)(G.g2_idx ? G.g2_idx[m] : m) * G.ldg2 + n];
+            if (args.relu) acc = fmaxf(acc, 0.f);
+            if (G.mask) acc = G.mask[(int64_t)m * G.ldmask + n] > 0.f ? acc : 0.f;
+            float* cp = G.C + (int64_t)(G.c_idx ? G.c_idx[m] : m) * G.ldc + n;
+            if (args.accumulate) acc += *cp;
+            *cp = acc;
+        }
     }
+}
+
+template <int WM, int WN, int TN>
+static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * TN * WN;
+    int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
+    dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
+    if (bl == B_KCONTIG)
+        hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_KCONTIG>), grid, dim3(NTHREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_NCONTIG>), grid, dim3(NTHREADS), 0, s, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
 
-int launch_gemm(const GemmArgs& a, int al, int bl, hipStream_t s) {
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
+    GemmArgs a = a_in;
     MPN_CHECK_ARG(a.ngroups == 1 || a.ngroups == 2, "gemm: ngroups %d", a.ngroups);
     MPN_CHECK_ARG(a.K >= 0 && a.N >= 0 && a.ksplit >= 0 && a.ksplit <= a.K, "gemm: bad N/K/ksplit");
     MPN_CHECK_ARG(a.m_upper < (int64_t)2147483647 - 256, "gemm: too many rows for int32 indexing");
+    MPN_CHECK_ARG(al == A_KCONTIG, "gemm: A must be K-contiguous (weight-gradient products use gemm_tn)");
     if (a.m_upper <= 0 || a.N == 0) return MPNHIP_OK;  // nothing to compute (empty graph)
+    bool fast = (a.K % 4 == 0) && (a.ksplit % 4 == 0) && a.K > 0;
+    bool epi_vec = (a.N % 4 == 0);
     for (int i = 0; i < a.ngroups; ++i) {
-        MPN_CHECK_ARG(a.g[i].A && a.g[i].B && a.g[i].C, "gemm: null operand");
-        MPN_CHECK_ARG(a.ksplit == a.K || a.g[i].A2, "gemm: ksplit without a second A segment");
-        MPN_CHECK_ARG(al == A_KCONTIG || (!a.g[i].a_idx && a.ksplit == a.K), "gemm: M-contiguous A is plain");
+        const GemmGroup& g = a.g[i];
+        MPN_CHECK_ARG(g.A && g.B && g.C, "gemm: null operand");
+        MPN_CHECK_ARG(a.ksplit == a.K || g.A2, "gemm: ksplit without a second A segment");
+        fast = fast && al16(g.A) && (g.lda % 4 == 0) && (!g.A2 || (al16(g.A2) && g.lda2 % 4 == 0)) && al16(g.B) && (g.ldb % 4 == 0);
+        if (bl == B_NCONTIG) fast = fast && (a.N % 4 == 0);
+        epi_vec = epi_vec && al16(g.C) && (g.ldc % 4 == 0) && (!g.bias || al16(g.bias)) &&
+                  (!g.G1 || (al16(g.G1) && g.ldg1 % 4 == 0)) && (!g.G2 || (al16(g.G2) && g.ldg2 % 4 == 0)) &&
+                  (!g.mask || (al16(g.mask) && g.ldmask % 4 == 0));
     }
-    // tile choice: widest N tile that is not mostly padding; shrink M tile when the grid would not
-    // cover the 256 CUs.
+    a.epi_vec = epi_vec ? 1 : 0;
+    if (!fast) {
+        int64_t total = a.m_upper * a.N;
+        unsigned blocks = (unsigned)((total + NTHREADS - 1) / NTHREADS);
+        if (blocks > 65535u * 16) blocks = 65535u * 16;
+        hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks), dim3(NTHREADS), 0, s, a, bl);
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
     const int N = a.N;
     const int64_t M = a.m_upper;
-    if (N > 64) {
-        int64_t blocks = ((M + 127) / 128) * ((N + 127) / 128);
-        if (blocks >= 192 || M > 4096) return launch_cfg<128, 128, 2, 2>(a, al, bl, s);
-        return launch_cfg<64, 64, 2, 2>(a, al, bl, s);
+    const int nt = (N + 31) / 32;  // 32-wide column tiles needed
+    if (M >= 8192) {
+        // waves stacked along M (block 128 x 32 TN): pick the strip width that wastes the fewest tiles,
+        // widest first (A is then re-read from L2 the fewest times)
+        int best = 1, best_cost = 1 << 30;
+        for (int tn = 8; tn >= 1; --tn) {
+            int cost = ((nt + tn - 1) / tn) * tn;
+            if (cost < best_cost) { best_cost = cost; best = tn; }
+        }
+        switch (best) {
+            case 8: return launch_cfg<4, 1, 8>(a, bl, s);
+            case 7: return launch_cfg<4, 1, 7>(a, bl, s);
+            case 6: return launch_cfg<4, 1, 6>(a, bl, s);
+            case 5: return launch_cfg<4, 1, 5>(a, bl, s);
+            case 4: return launch_cfg<4, 1, 4>(a, bl, s);
+            case 3: return launch_cfg<4, 1, 3>(a, bl, s);
+            case 2: return launch_cfg<4, 1, 2>(a, bl, s);
+            default: return launch_cfg<4, 1, 1>(a, bl, s);
+        }
     }
-    if (N > 32) {
-        int64_t blocks = (M + 127) / 128;
-        if (blocks >= 192) return launch_cfg<128, 64, 2, 2>(a, al, bl, s);
-        return launch_cfg<64, 64, 2, 2>(a, al, bl, s);
-    }
-    return launch_cfg<128, 32, 4, 1>(a, al, bl, s);
+    // few rows (node-level products): spread the columns over the waves so that the grid fills the chip
+    if (nt >= 8) return launch_cfg<1, 4, 2>(a, bl, s);
+    if (nt >= 4) return launch_cfg<1, 4, 1>(a, bl, s);
+    if (nt >= 2) return launch_cfg<2, 2, 1>(a, bl, s);
+    return launch_cfg<4, 1, 1>(a, bl, s);
 }
 
 int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k,
