@@ -1,4 +1,5 @@
-"""torch.autograd glue around the native forward / backward entry points (plumbing only)."""
+"""torch.autograd glue around the native forward / backward entry points (plumbing only: every
+gradient is computed by ``mpnhip_backward``)."""
 import torch
 
 from . import capi
@@ -16,5 +17,62 @@ def avg_pool_native(x):
     return y
 
 
+def native_forward_saved(model, g, x, ea, logits):
+    """mpnhip_forward(save_for_backward=1) into a private workspace; returns that workspace."""
+    lib = capi.load()
+    keep = []
+    m = model.c_model(keep)
+    N, E = x.shape[0], ea.shape[0]
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(lib.mpnhip_forward_workspace_bytes(m, N, E, 1), 256), dtype=torch.uint8, device=x.device)
+        capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits), None, None,
+                                      capi.ptr(ws), ws.numel(), 1, capi.stream_ptr()), "mpnhip_forward")
+    return ws
+
+
+def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, need_gea=False):
+    """mpnhip_backward; ``grads``: id(param) -> buffer the parameter gradient is ACCUMULATED into."""
+    lib = capi.load()
+    keep = []
+    m = model.c_model(keep, grads=grads)
+    N, E = x.shape[0], ea.shape[0]
+    gx = torch.empty_like(x) if need_gx else None
+    gea = torch.empty_like(ea) if need_gea else None
+    gl = capi.f32c(grad_logits)
+    with torch.cuda.device(x.device):
+        bws = capi.workspace(lib.mpnhip_backward_workspace_bytes(m, N, E), x.device, "bwd")
+        capi.check(lib.mpnhip_backward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(gl), None, None,
+                                       capi.ptr(gx), capi.ptr(gea), capi.ptr(fwd_ws), fwd_ws.numel(), capi.ptr(bws),
+                                       bws.numel(), capi.stream_ptr()), "mpnhip_backward")
+    return gx, gea
+
+
+class _HotPath(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, g, x, edge_attr, *params):
+        x = capi.f32c(x.detach())
+        ea = capi.f32c(edge_attr.detach())
+        L = max(int(model.num_enc_steps), 1)
+        logits = torch.empty((L, ea.shape[0]), dtype=torch.float32, device=x.device)
+        ctx.fwd_ws = native_forward_saved(model, g, x, ea, logits)
+        ctx.model, ctx.g, ctx.x, ctx.ea = model, g, x, ea
+        ctx.params = params
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        grads = {id(p): torch.zeros_like(p) for p in ctx.params}
+        gx, gea = native_backward(ctx.model, ctx.g, ctx.x, ctx.ea, grad_logits, ctx.fwd_ws, grads,
+                                  need_gx=ctx.needs_input_grad[2], need_gea=ctx.needs_input_grad[3])
+        ctx.fwd_ws = None
+        return (None, None, gx, gea) + tuple(grads[id(p)] if p.requires_grad else None for p in ctx.params)
+
+
 def mpn_hot_path_autograd(model, x, edge_index, edge_attr, holder=None):
-    raise capi.MpnhipError("training through the native path needs mpnhip_backward, which this build does not have yet")
+    from .mpn import _prepared
+    capi.require_device(x, edge_index, edge_attr)
+    g = _prepared(edge_index, x.shape[0], holder)
+    params = model.hot_path_parameters()
+    for p in params:
+        capi.require_device(p)
+    return _HotPath.apply(model, g, x, edge_attr, *params)

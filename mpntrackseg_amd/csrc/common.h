@@ -65,7 +65,7 @@ struct GemmGroup {
     const int* g1_idx;     // nullptr -> identity (row m - row_begin + g_row0)
     const float* G2;
     const int* g2_idx;
-    const float* mask;     // ReLU-backward mask: value *= (mask[m][n] > 0); leading dim ldmask
+    const float* mask;     // ReLU-backward mask, applied last: value = mask[m][n] > 0 ? value : 0 (ld = ldmask)
     float* C;
     const int* c_idx;      // optional row scatter for C
     const int* row_begin;  // device int: first row of this group (nullptr -> 0)
@@ -79,12 +79,38 @@ struct GemmArgs {
     int ngroups;
     int N, K, ksplit;      // ksplit == K when A2 is unused
     int relu;              // max(.,0) at the end
-    int accumulate;        // C += result (after mask / relu)
+    int accumulate;        // C += result (after relu, before the mask)
     int64_t m_upper;       // host-side upper bound of the total row count (sizes the grid)
     int epi_vec;           // set by launch_gemm: epilogue operands allow 16-byte vector access
 };
 
 int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------ weight gradients
+// dW[o, c] += sum_m dZ[m, o] * H[m, c], db[o] += sum_m dZ[m, o] over a (device-resident) row range.
+struct TnGroup {
+    const float* dZ;       // [rows, n_out], leading dim ldz
+    const int* dz_idx;     // optional row gather
+    const float* H;        // [rows, csplit] first column segment of the layer input
+    const float* H2;       // columns >= csplit (nullptr when csplit == k_in)
+    const int* h_idx;      // optional row gather
+    const int* row_begin;  // device ints (nullptr -> 0 / m_static)
+    const int* row_end;
+    float* slab;           // split partials, tn_slab_floats() floats
+    float* grad_w;         // += ; leading dim ldw (may point into a wider matrix)
+    float* grad_b;         // += ; may be nullptr
+    int64_t ldz, ldh, ldh2, ldw, m_static;
+};
+struct TnArgs {
+    TnGroup g[2];
+    int ngroups;
+    int n_out, k_in, csplit;
+    int64_t m_upper;
+    int chunk, nsplit;     // filled by tn_plan
+};
+void tn_plan(TnArgs& a);
+size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper);
+int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 
 // Convenience: y = act(x W^T + b)
 int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k,
@@ -117,6 +143,9 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
 // generic: out[s][:] = AGG_{j in [ptr[s], ptr[s+1])} src[list ? list[j] : j][:]; out leading dim ldo
 int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, int agg,
                        float* out, int64_t ldo, int* argmax, int accumulate, hipStream_t stream);
+
+int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
+                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

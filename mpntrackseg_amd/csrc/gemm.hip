@@ -2,7 +2,7 @@
 //
 // One kernel template covers every dense product of the forward path (SURVEY.md section 2.4,
 // K2/K4/K6/K8/K9) and the activation-gradient products of the backward path:
-//   C[m, n] = act( sum_k A[m, k] * B[k, n] + bias[n] + G1[i1(m)][n] + G2[i2(m)][n] ) (* mask) (+ C)
+//   C[m, n] = mask( act( sum_k A[m, k] * B[k, n] + bias[n] + G1[i1(m)][n] + G2[i2(m)][n] ) (+ C) )
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the fp32 peak).
 //
 // Geometry: 256 threads = 4 waves arranged WM x WN; every wave owns a 32 x (32 TN) strip of C
@@ -247,9 +247,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
                 o.z = v[p].z + bias.z + g1[p].z + g2[p].z;
                 o.w = v[p].w + bias.w + g1[p].w + g2[p].w;
                 if (args.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                o.x += old[p].x; o.y += old[p].y; o.z += old[p].z; o.w += old[p].w;
                 o.x = mk[p].x > 0.f ? o.x : 0.f; o.y = mk[p].y > 0.f ? o.y : 0.f;
                 o.z = mk[p].z > 0.f ? o.z : 0.f; o.w = mk[p].w > 0.f ? o.w : 0.f;
-                o.x += old[p].x; o.y += old[p].y; o.z += old[p].z; o.w += old[p].w;
                 if (m_ok[p] && n_ok) *reinterpret_cast<float4*>(G.C + c_off[p] + nc) = o;
             }
         } else {
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
                     if (G.G1) o += G.G1[g1_off[p] + nc];
                     if (G.G2) o += G.G2[g2_off[p] + nc];
                     if (args.relu) o = fmaxf(o, 0.f);
-                    if (G.mask) o = G.mask[(int64_t)m_row[p] * G.ldmask + nc] > 0.f ? o : 0.f;
                     if (args.accumulate) o += G.C[c_off[p] + nc];
+                    if (G.mask) o = G.mask[(int64_t)m_row[p] * G.ldmask + nc] > 0.f ? o : 0.f;
                     if (ok) G.C[c_off[p] + nc] = o;
                 }
             }
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, i
             if (G.G1) acc += G.G1[(int64_t)(G.g1_idx ? G.g1_idx[m] : m) * G.ldg1 + n];
             if (G.G2) acc += G.G2[(int64_t)(G.g2_idx ? G.g2_idx[m] : m) * G.ldg2 + n];
             if (args.relu) acc = fmaxf(acc, 0.f);
-            if (G.mask) acc = G.mask[(int64_t)m * G.ldmask + n] > 0.f ? acc : 0.f;
             float* cp = G.C + (int64_t)(G.c_idx ? G.c_idx[m] : m) * G.ldc + n;
             if (args.accumulate) acc += *cp;
+            if (G.mask) acc = G.mask[(int64_t)m * G.ldmask + n] > 0.f ? acc : 0.f;
             *cp = acc;
         }
     }

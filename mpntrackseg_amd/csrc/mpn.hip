@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "plan.h"
 
 namespace mpnhip {
 
@@ -85,175 +86,7 @@ static int scatter_rows(const float* src, const int* idx, float* dst, int64_t ro
     return MPNHIP_OK;
 }
 
-// ------------------------------------------------------------------------------------ model checks
-struct Dims {
-    int dn, de, nf, ef;
-    int he;   // first hidden width of the edge MLP
-    int hn;   // first hidden width of the flow MLPs
-    int pw;   // width of the per-node projection block: 2 he + 2 hn
-    int kx;   // nf * dn
-    int ke;   // ef * de
-    int L;
-};
-
-static int mlp_ok(const mpnhip_mlp& m, const char* name, bool need_ptrs) {
-    MPN_CHECK_ARG(m.n_layers >= 1 && m.n_layers <= MPNHIP_MAX_LAYERS, "%s: n_layers %d", name, m.n_layers);
-    MPN_CHECK_ARG(m.in_dim >= 1, "%s: in_dim %d", name, m.in_dim);
-    for (int i = 0; i < m.n_layers; ++i) {
-        MPN_CHECK_ARG(m.out_dims[i] >= 1, "%s: out_dims[%d] = %d", name, i, m.out_dims[i]);
-        if (need_ptrs) MPN_CHECK_ARG(m.weight[i] && m.bias[i], "%s: null weight/bias in layer %d", name, i);
-    }
-    return MPNHIP_OK;
-}
-
-static int check_core(const mpnhip_model& m, Dims* d, bool ptrs = true) {
-    MPN_CHECK_ARG(m.dn >= 1 && m.de >= 1, "model: dn/de");
-    MPN_CHECK_ARG(m.agg >= 0 && m.agg <= 2, "model: node_agg_fn code %d (reference asserts 'mean'|'max'|'sum', mpn.py:264)", m.agg);
-    d->dn = m.dn;
-    d->de = m.de;
-    d->nf = m.reattach_nodes ? 2 : 1;
-    d->ef = m.reattach_edges ? 2 : 1;
-    d->kx = d->nf * d->dn;
-    d->ke = d->ef * d->de;
-    d->L = m.num_enc_steps;
-    MPN_TRY(mlp_ok(m.edge, "edge_model", ptrs));
-    MPN_TRY(mlp_ok(m.flow_in, "flow_in_model", ptrs));
-    MPN_TRY(mlp_ok(m.flow_out, "flow_out_model", ptrs));
-    MPN_TRY(mlp_ok(m.node, "node_model", ptrs));
-    MPN_CHECK_ARG(m.edge.in_dim == 2 * d->kx + d->ke, "edge_model in_dim %d != %d (mpn.py:282-283)", m.edge.in_dim, 2 * d->kx + d->ke);
-    MPN_CHECK_ARG(m.edge.out_dims[m.edge.n_layers - 1] == d->de, "edge_model must end at edge_out_dim");
-    MPN_CHECK_ARG(m.flow_in.in_dim == d->kx + d->de && m.flow_out.in_dim == d->kx + d->de, "flow model in_dim != %d (mpn.py:285)", d->kx + d->de);
-    MPN_CHECK_ARG(m.flow_in.n_layers == m.flow_out.n_layers, "flow_in / flow_out depth differ");
-    for (int i = 0; i < m.flow_in.n_layers; ++i)
-        MPN_CHECK_ARG(m.flow_in.out_dims[i] == m.flow_out.out_dims[i], "flow_in / flow_out dims differ");
-    MPN_CHECK_ARG(m.flow_in.out_dims[m.flow_in.n_layers - 1] == d->dn, "flow models must end at node_out_dim");
-    MPN_CHECK_ARG(m.node.n_layers == 1 && m.node.in_dim == 2 * d->dn && m.node.out_dims[0] == d->dn, "node_model must be Linear(2dn, dn) (mpn.py:309)");
-    d->he = m.edge.out_dims[0];
-    d->hn = m.flow_in.out_dims[0];
-    d->pw = 2 * d->he + 2 * d->hn;
-    return MPNHIP_OK;
-}
-
-static int check_full(const mpnhip_model& m, Dims* d, bool ptrs = true) {
-    MPN_TRY(check_core(m, d, ptrs));
-    MPN_CHECK_ARG(m.num_enc_steps >= 0, "model: num_enc_steps");
-    MPN_TRY(mlp_ok(m.enc_node, "encoder.node_model", ptrs));
-    MPN_TRY(mlp_ok(m.enc_edge, "encoder.edge_model", ptrs));
-    MPN_TRY(mlp_ok(m.classifier, "classifier.edge_model", ptrs));
-    MPN_CHECK_ARG(m.enc_node.out_dims[m.enc_node.n_layers - 1] == d->dn, "encoder node_out_dim mismatch");
-    MPN_CHECK_ARG(m.enc_edge.out_dims[m.enc_edge.n_layers - 1] == d->de, "encoder edge_out_dim mismatch");
-    MPN_CHECK_ARG(m.classifier.in_dim == d->de, "classifier edge_in_dim != edge_out_dim");
-    MPN_CHECK_ARG(m.classifier.out_dims[m.classifier.n_layers - 1] == 1, "classifier must end with out dim 1");
-    return MPNHIP_OK;
-}
-
-static int max_hidden(const mpnhip_mlp& m) {
-    int mx = 0;
-    for (int i = 0; i + 1 < m.n_layers; ++i) mx = m.out_dims[i] > mx ? m.out_dims[i] : mx;
-    return mx;
-}
-static int64_t sum_hidden(const mpnhip_mlp& m) {
-    int64_t s = 0;
-    for (int i = 0; i + 1 < m.n_layers; ++i) s += m.out_dims[i];
-    return s;
-}
-
-// ------------------------------------------------------------------------------------ workspace
-struct Arena {
-    char* base;
-    size_t off;
-    float* f(size_t n) {
-        size_t o = off;
-        off = align_up(off + n * sizeof(float), 256);
-        return base ? reinterpret_cast<float*>(base + o) : nullptr;
-    }
-    int* i(size_t n) { return reinterpret_cast<int*>(f(n)); }
-};
-
-// per-step activation buffers of one MetaLayer + classifier evaluation
-struct StepBufs {
-    float* P;                          // [N, pw]   per-node projections (+ folded biases)
-    float* HE[MPNHIP_MAX_LAYERS];      // hidden activations of the edge MLP   [E, edge.out_dims[i]]
-    float* HC[MPNHIP_MAX_LAYERS];      // hidden activations of the classifier [E, cls.out_dims[i]]
-    float* HF[MPNHIP_MAX_LAYERS];      // hidden activations of the flow MLPs  [E, flow.out_dims[i]]
-    float* M;                          // [E, dn]   messages (post-ReLU), sorted order
-    float* AGG;                        // [N, 2dn]  [flow_in | flow_out]
-    int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
-};
-
-struct FwdPlan {
-    float* Wnode;  // [pw, kx]
-    float* bnode;  // [pw]
-    float* enc_n[2];
-    float* enc_e[2];
-    float* x_hist;  // [(L+1) or 3][N, dn]   x_hist[0] = encoder output
-    float* e_hist;  // [(L+1) or 3][E, de]   sorted order
-    int hist_slots;
-    StepBufs step0;
-    size_t step_stride_bytes;  // 0 when the step buffers are reused (inference)
-    size_t total;
-};
-
-static void carve_step(Arena& a, const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, bool with_cls, bool with_arg,
-                       StepBufs* sb) {
-    StepBufs s = {};
-    s.P = a.f((size_t)N * d.pw);
-    for (int i = 0; i + 1 < m.edge.n_layers; ++i) s.HE[i] = a.f((size_t)E * m.edge.out_dims[i]);
-    if (with_cls)
-        for (int i = 0; i + 1 < m.classifier.n_layers; ++i) s.HC[i] = a.f((size_t)E * m.classifier.out_dims[i]);
-    for (int i = 0; i + 1 < m.flow_in.n_layers; ++i) s.HF[i] = a.f((size_t)E * m.flow_in.out_dims[i]);
-    s.M = a.f((size_t)E * d.dn);
-    s.AGG = a.f((size_t)N * 2 * d.dn);
-    s.ARG = with_arg ? a.i((size_t)N * 2 * d.dn) : nullptr;
-    if (sb) *sb = s;
-}
-
-static StepBufs step_at(const FwdPlan& p, int s) {
-    StepBufs b = p.step0;
-    size_t sh = p.step_stride_bytes * (size_t)s;
-    auto mv = [&](float*& q) { if (q) q = reinterpret_cast<float*>(reinterpret_cast<char*>(q) + sh); };
-    mv(b.P);
-    for (int i = 0; i < MPNHIP_MAX_LAYERS; ++i) { mv(b.HE[i]); mv(b.HC[i]); mv(b.HF[i]); }
-    mv(b.M);
-    mv(b.AGG);
-    if (b.ARG) b.ARG = reinterpret_cast<int*>(reinterpret_cast<char*>(b.ARG) + sh);
-    return b;
-}
-
-static size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, int save, void* base, FwdPlan* out) {
-    Arena a = {static_cast<char*>(base), 0};
-    FwdPlan p = {};
-    p.Wnode = a.f((size_t)d.pw * d.kx);
-    p.bnode = a.f((size_t)d.pw);
-    int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
-    if (save) {
-        // keep every encoder activation for the backward pass: one buffer per hidden layer
-        p.enc_n[0] = a.f((size_t)N * (sum_hidden(m.enc_node) > 0 ? sum_hidden(m.enc_node) : 1));
-        p.enc_e[0] = a.f((size_t)E * (sum_hidden(m.enc_edge) > 0 ? sum_hidden(m.enc_edge) : 1));
-        p.enc_n[1] = p.enc_e[1] = nullptr;
-    } else {
-        for (int i = 0; i < 2; ++i) {
-            p.enc_n[i] = a.f((size_t)N * (hn_ > 0 ? hn_ : 1));
-            p.enc_e[i] = a.f((size_t)E * (he_ > 0 ? he_ : 1));
-        }
-    }
-    p.hist_slots = save ? d.L + 1 : 3;
-    p.x_hist = a.f((size_t)p.hist_slots * N * d.dn);
-    p.e_hist = a.f((size_t)p.hist_slots * E * d.de);
-    size_t before = a.off;
-    carve_step(a, m, d, N, E, true, save && m.agg == MPNHIP_AGG_MAX, &p.step0);
-    p.step_stride_bytes = 0;
-    if (save && d.L > 1) {
-        p.step_stride_bytes = a.off - before;
-        a.off = before + p.step_stride_bytes * (size_t)d.L;
-    }
-    p.total = a.off;
-    if (out) *out = p;
-    return p.total;
-}
-
 // ------------------------------------------------------------------------------------ building blocks
-static void init_group(GemmGroup& g) { memset(&g, 0, sizeof(g)); }
 
 // hidden / output layers i >= 1 of an MLP on [rows, :] activations; `two` = direction-grouped run
 // of the flow MLPs (group 0: flow_out weights on rows [0, E_out), group 1: flow_in on [E_out, E_out+E_in)).
@@ -415,17 +248,6 @@ static int mlp_forward(const mpnhip_mlp& m, const float* x, int64_t ldx, const i
     return MPNHIP_OK;
 }
 
-static void hidden_ptrs(const mpnhip_mlp& m, float* const two[2], int64_t rows, bool per_layer, float** out) {
-    size_t off = 0;
-    for (int i = 0; i + 1 < m.n_layers; ++i) {
-        if (per_layer) {
-            out[i] = two[0] + off;
-            off += (size_t)rows * m.out_dims[i];
-        } else {
-            out[i] = two[i & 1];
-        }
-    }
-}
 
 }  // namespace mpnhip
 

@@ -168,6 +168,25 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
     return launch_seg(a, stream);
 }
 
+// segments [0, nmod) go to column offset off0, segments [nmod, 2 nmod) to off1 of out row (s % nmod)
+int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
+                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream) {
+    SegArgs a = {};
+    a.src = src;
+    a.lds = lds;
+    a.list = list;
+    a.ptr = ptr;
+    a.nseg = nseg;
+    a.dim = dim;
+    a.agg = MPNHIP_AGG_SUM;
+    a.out = out;
+    a.ldo = ldo;
+    a.nmod = nmod > 0 ? nmod : 1;
+    a.off0 = off0;
+    a.off1 = off1;
+    return launch_seg(a, stream);
+}
+
 // ---- stand-alone node_agg_fn with an arbitrary (unsorted) int64 index ---------------------------
 __global__ void k_row_keys(const int64_t* __restrict__ row, int64_t M, int x_size, unsigned* __restrict__ keys,
                            int* __restrict__ vals) {

@@ -38,13 +38,19 @@ class MLP(nn.Module):
                 "BatchNorm / Dropout inside the MPN MLPs is not covered by the HIP path "
                 "(all shipped reference configs use use_batchnorm=False, dropout_p=0: configs/tracking_cfg.yaml:150-167)")
 
-    def c_struct(self, keep):
+    def c_struct(self, keep, grads=None):
+        """``mpnhip_mlp`` for this module; ``grads`` maps id(param) -> gradient buffer (same shape)."""
         self.require_fast_path()
         s = capi.Mlp()
         lin = [(l.weight.detach(), l.bias.detach()) for l in self.linears()]
         for w, b in lin:
             capi.require_device(w, b)
-        return capi.fill_mlp(s, lin, keep=keep)
+        capi.fill_mlp(s, lin, keep=keep)
+        if grads is not None:
+            for i, l in enumerate(self.linears()):
+                s.grad_weight[i] = grads[id(l.weight)].data_ptr()
+                s.grad_bias[i] = grads[id(l.bias)].data_ptr()
+        return s
 
     def forward(self, input):
         """models/mlp.py:27-28.  Inference-only at operator level (the fused MOTMPNet path owns autograd)."""

@@ -104,18 +104,21 @@ class MetaLayer(nn.Module):
             if hasattr(item, 'reset_parameters'):
                 item.reset_parameters()
 
-    def core_struct(self, keep, agg_name=None):
+    def core_struct(self, keep, agg_name=None, grads=None):
         """Fill the MetaLayer part of an ``mpnhip_model``."""
         if not isinstance(self.edge_model, EdgeModel) or not isinstance(self.node_model, TimeAwareNodeModel):
             raise capi.MpnhipError("MetaLayer needs an EdgeModel and a TimeAwareNodeModel (as MOTMPNet builds them)")
         nm = self.node_model
         m = capi.Model()
-        m.edge = self.edge_model.edge_model.c_struct(keep)
-        m.flow_in = nm.flow_in_model.c_struct(keep)
-        m.flow_out = nm.flow_out_model.c_struct(keep)
+        m.edge = self.edge_model.edge_model.c_struct(keep, grads)
+        m.flow_in = nm.flow_in_model.c_struct(keep, grads)
+        m.flow_out = nm.flow_out_model.c_struct(keep, grads)
         lin = nm.node_model[0]
         capi.require_device(lin.weight)
         capi.fill_mlp(m.node, [(lin.weight.detach(), lin.bias.detach())], keep=keep)
+        if grads is not None:
+            m.node.grad_weight[0] = grads[id(lin.weight)].data_ptr()
+            m.node.grad_bias[0] = grads[id(lin.bias)].data_ptr()
         m.dn = int(lin.weight.shape[0])
         m.de = int(m.edge.out_dims[m.edge.n_layers - 1])
         agg = nm.node_agg_fn
@@ -242,16 +245,16 @@ class MOTMPNet(nn.Module):
             out += [l.weight, l.bias]
         return out
 
-    def c_model(self, keep):
+    def c_model(self, keep, grads=None):
         if self.encoder.node_model is None or self.encoder.edge_model is None or self.classifier.edge_model is None:
             raise capi.MpnhipError("MOTMPNet needs node and edge encoders and an edge classifier")
-        m = self.MPNet.core_struct(keep)
+        m = self.MPNet.core_struct(keep, grads=grads)
         m.reattach_nodes = int(bool(self.reattach_initial_nodes))
         m.reattach_edges = int(bool(self.reattach_initial_edges))
         m.num_enc_steps = int(self.num_enc_steps)
-        m.enc_node = self.encoder.node_model.c_struct(keep)
-        m.enc_edge = self.encoder.edge_model.c_struct(keep)
-        m.classifier = self.classifier.edge_model.c_struct(keep)
+        m.enc_node = self.encoder.node_model.c_struct(keep, grads)
+        m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
+        m.classifier = self.classifier.edge_model.c_struct(keep, grads)
         return m
 
     def hot_path(self, x, edge_index, edge_attr, holder=None, return_state=False):

@@ -1,16 +1,20 @@
 """Data-parallel training step: one graph per GPU, flat gradient bucket, one RCCL all-reduce.
 
 The reference trains on one GPU with ``accumulate_grad_batches: 8`` (configs/tracking_cfg.yaml:4,
-scripts/train.py:76); 8 GPUs x 1 graph with gradient averaging is the same optimisation step executed
-in space instead of time."""
+scripts/train.py:76); W GPUs x 1 graph with gradient averaging is the same optimisation step executed
+in space instead of time.  The graphs share nothing but the weights, so the
+data path has no collective; the only exchange is ONE all-reduce(sum) of the flat fp32 gradient bucket
+per optimizer step (1.2 MB at the reference dims: latency-bound, hence a single bucket)."""
+import torch
+
 from . import capi
+from .autograd import native_backward, native_forward_saved
 
 
 def backward_available():
     """True when libmpnhip.so carries the hand-written backward."""
     lib = capi.load()
-    m = capi.Model()
-    return lib.mpnhip_backward_workspace_bytes(m, 0, 0) != 0 or getattr(lib, "_has_bwd", False)
+    return lib.mpnhip_backward_workspace_bytes(None, 0, 0) != 0
 
 
 def shard_indices(n_items, rank, world_size):
@@ -18,6 +22,72 @@ def shard_indices(n_items, rank, world_size):
     return list(range(rank, n_items, world_size))
 
 
+def bce_logits_grad(logits, labels, first_step=0):
+    """d/dlogits of the reference loss (pl_module.py:88-120): sum over the classified steps of
+    BCEWithLogits(pos_weight = #neg/#pos), mean over edges.  logits [L,E], labels [E] in {0,1}."""
+    E = labels.numel()
+    pos = labels.sum()
+    pw = (E - pos) / pos.clamp(min=1)
+    w = torch.where(labels > 0, pw, torch.ones_like(pw))
+    g = (torch.sigmoid(logits) * (1 + (pw - 1) * labels) - pw * labels) / max(E, 1)
+    if first_step > 0:
+        g[:first_step] = 0
+    return g, w
+
+
+class FlatBucket:
+    """Parameters' gradients as views of one flat fp32 buffer (one collective per step)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = {}
+        off = 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self.views[id(p)] = v
+            p.grad = v
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+
 class TrainStep:
-    def __init__(self, model, world_size=1):
-        raise capi.MpnhipError("TrainStep needs mpnhip_backward")
+    """fwd (saving activations) -> loss gradient -> hand-written bwd into the flat bucket ->
+    all-reduce(sum)/W over RCCL (world_size > 1) -> Adam.  Graph prep is cached on `holder`."""
+
+    def __init__(self, model, world_size=1, lr=1e-3, process_group=None):
+        if not backward_available():
+            raise capi.MpnhipError("TrainStep needs mpnhip_backward")
+        self.model = model
+        self.world_size = world_size
+        self.pg = process_group
+        self.bucket = FlatBucket(model.hot_path_parameters())
+        self.opt = torch.optim.Adam(self.bucket.params, lr=lr)
+        self.first_class_step = max(int(model.num_enc_steps) - int(model.num_class_steps), 0)
+
+    def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True):
+        from .mpn import _prepared
+        model = self.model
+        g = _prepared(edge_index, x.shape[0], holder)
+        x = capi.f32c(x)
+        ea = capi.f32c(edge_attr)
+        E = ea.shape[0]
+        L = max(int(model.num_enc_steps), 1)
+        logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
+        ws = native_forward_saved(model, g, x, ea, logits)
+        if labels is None:
+            labels = (torch.arange(E, device=x.device) % 7 == 0).float()
+        glog, _ = bce_logits_grad(logits, labels, self.first_class_step)
+        self.bucket.zero_()
+        native_backward(model, g, x, ea, glog, ws, self.bucket.views)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            self.bucket.flat.mul_(1.0 / self.world_size)
+        if optimizer_step:
+            self.opt.step()
+        return logits

@@ -1,0 +1,169 @@
+"""Gradients of the hand-written backward (mpnhip_backward through torch.autograd.Function) against
+(a) the reference's own autograd results stored in tests/golden/g1_tiny_*.npz and (b) torch autograd of
+the CPU oracle.  Loss = sum_steps sum_edges logit * r (r seeded), so every step's logits receive a
+gradient, as the mask branch does in the reference.
+Tolerance: max |d| <= 2e-4 * max|ref| per tensor (fp32 re-association over up to 50k-term sums)."""
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import capi, synth
+from mpntrackseg_amd.mpn import MOTMPNet
+from oracle import mpn_oracle as O
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def nerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if b.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-6))
+
+
+def make_model(params, W):
+    model = MOTMPNet(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    return model.to(dev()).train()
+
+
+def native_grads(model, x, ei, ea, r):
+    xd = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    ead = torch.from_numpy(ea).to(dev()).requires_grad_(True)
+    model.zero_grad()
+    logits = model.hot_path(xd, torch.from_numpy(ei).to(dev()), ead)
+    loss = (logits * torch.from_numpy(r).to(dev())).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    pg = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+    return logits.detach().cpu().numpy(), xd.grad.cpu().numpy(), ead.grad.cpu().numpy(), pg
+
+
+def oracle_grads(params, W, x, ei, ea, r):
+    Wt = O.to_tensors(W, requires_grad=True)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    eat = torch.from_numpy(ea).requires_grad_(True)
+    _, logits, _, _ = O.forward(params, Wt, xt, torch.from_numpy(ei), eat, return_state=True)
+    lg = torch.stack([l.view(-1) for l in logits])
+    loss = (lg * torch.from_numpy(r)).sum()
+    keys = list(Wt.keys())
+    gr = torch.autograd.grad(loss, [xt, eat] + [Wt[k] for k in keys], allow_unused=True)
+    pg = {k: (g.numpy() if g is not None else np.zeros(Wt[k].shape, np.float32)) for k, g in zip(keys, gr[2:])}
+    return lg.detach().numpy(), gr[0].numpy(), gr[1].numpy(), pg
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g1_reference_autograd(golden, agg):
+    z = golden(f"g1_tiny_{agg}.npz")
+    L = int(z["L"])
+    params = synth.model_params(32, L, agg, num_class_steps=3, node_in_dim=int(z["node_in_dim"]))
+    W = {k[2:]: z[k] for k in z.files if k.startswith("W:")}
+    model = make_model(params, W)
+    logits, gx, gea, pg = native_grads(model, z["x_pooled"], z["edge_index"], z["edge_attr"], z["r"])
+    assert nerr(logits, z["logits"]) < 1e-4
+    assert nerr(gx, z["grad_x"]) < GTOL
+    assert nerr(gea, z["grad_edge_attr"]) < GTOL
+    for k in W:
+        assert nerr(pg[k], z["G:" + k]) < GTOL, k
+
+
+def check_against_oracle(params, W, g, seed=11, tol=GTOL):
+    L = max(params["num_enc_steps"], 1)
+    E = g["edge_index"].shape[1]
+    r = synth.normal(seed, (L, E))
+    model = make_model(params, W)
+    lo, gx, gea, pg = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r)
+    lr, rx, rea, rpg = oracle_grads(params, W, g["x"], g["edge_index"], g["edge_attr"], r)
+    assert nerr(lo, lr) < 1e-4
+    assert nerr(gx, rx) < tol
+    assert nerr(gea, rea) < tol
+    for k in W:
+        assert nerr(pg[k], rpg[k]) < tol, k
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_structure_graph(golden, agg):
+    z = golden("g4_structure.npz")
+    params = synth.model_params(32, 3, agg, node_in_dim=64)
+    g = {"x": z["x"], "edge_index": z["edge_index"], "edge_attr": z["edge_attr"]}
+    check_against_oracle(params, synth.make_weights(params, seed=8), g)
+
+
+@pytest.mark.parametrize("agg", ["sum", "max"])
+def test_no_reattach(agg):
+    params = synth.model_params(32, 2, agg, node_in_dim=32)
+    params["reattach_initial_nodes"] = False
+    params["reattach_initial_edges"] = False
+    g = synth.make_graph(80, 500, T=8, seed=4, node_in_dim=32)
+    check_against_oracle(params, synth.make_weights(params, seed=12), g)
+
+
+def test_zero_steps():
+    params = synth.model_params(32, 0, "sum", num_class_steps=0, node_in_dim=64)
+    g = synth.make_graph(30, 100, T=5, seed=2, node_in_dim=64)
+    check_against_oracle(params, synth.make_weights(params, seed=7), g)
+
+
+def test_deeper_mlps_and_odd_dims():
+    """MLP depths other than the shipped 2-layer ones, widths that are not multiples of 4."""
+    params = synth.model_params(32, 2, "mean", node_in_dim=20)
+    params["encoder_feats_dict"]["edge_dims"] = [10]
+    params["encoder_feats_dict"]["node_dims"] = [24, 12]
+    params["edge_model_feats_dict"]["dims"] = [40, 24, 16]
+    params["node_model_feats_dict"]["dims"] = [32]
+    params["classifier_feats_dict"]["edge_dims"] = [6, 5]
+    g = synth.make_graph(50, 300, T=6, seed=6, node_in_dim=20)
+    check_against_oracle(params, synth.make_weights(params, seed=3), g)
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_cfgA(agg):
+    c = synth.CONFIGS["A"]
+    params = synth.model_params(c["d"], c["L"], agg)
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    check_against_oracle(params, synth.make_weights(params, seed=7), g)
+
+
+def test_cfgB_mean():
+    """Full BASELINE.json configs[1] size, fwd+bwd, against oracle autograd (about 10 s of CPU)."""
+    c = synth.CONFIGS["B"]
+    params = synth.model_params(c["d"], c["L"], "mean")
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    check_against_oracle(params, synth.make_weights(params, seed=7), g, tol=5e-4)
+
+
+def test_linearity_in_upstream_gradient():
+    """Size-independent property at full size: backward is linear in grad_logits."""
+    c = synth.CONFIGS["B"]
+    params = synth.model_params(c["d"], 4, "sum")
+    g = synth.make_graph(c["N"], c["E"], seed=2)
+    model = make_model(params, synth.make_weights(params, seed=7))
+    r1 = synth.normal(1, (4, c["E"]))
+    r2 = synth.normal(2, (4, c["E"]))
+    _, gx1, _, pg1 = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r1)
+    _, gx2, _, pg2 = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r2)
+    _, gx3, _, pg3 = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], (2 * r1 - r2).astype(np.float32))
+    assert nerr(gx3, 2 * gx1 - gx2) < 1e-4
+    k = "MPNet.edge_model.edge_model.fc_layers.0.weight"
+    assert nerr(pg3[k], 2 * pg1[k] - pg2[k]) < 1e-4
+
+
+def test_train_step_runs_and_updates():
+    from mpntrackseg_amd.train import TrainStep
+    c = synth.CONFIGS["A"]
+    params = synth.model_params(c["d"], c["L"], "sum")
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    model = make_model(params, synth.make_weights(params, seed=7, gain=0.5))
+    before = model.classifier.edge_model.fc_layers[0].weight.detach().clone()
+    step = TrainStep(model, world_size=1, lr=1e-3)
+    x, ei, ea = (torch.from_numpy(g[k]).to(dev()) for k in ("x", "edge_index", "edge_attr"))
+    step(x, ei, ea)
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.bucket.flat).all()
+    assert float(step.bucket.flat.abs().max()) > 0
+    assert not torch.equal(before, model.classifier.edge_model.fc_layers[0].weight.detach())
