@@ -65,6 +65,23 @@ __global__ void k_add_block(const float* __restrict__ src, int64_t lds, float* _
     dst[(int64_t)r * ldd + c0 + c] += src[(int64_t)r * lds + c];
 }
 
+// src [rows, 2d] (or [rows, d] when !two): acc[r][c] += src[r][c]; other[r][c] (=|+=) src[r][d + c]
+__global__ void k_split_cat(const float* __restrict__ src, int64_t rows, int d, int two, float* __restrict__ acc,
+                            float* __restrict__ other, int other_accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    int64_t r = i / d;
+    int c = (int)(i % d);
+    if (two) {
+        acc[i] += src[r * 2 * d + c];
+        float v = src[r * 2 * d + d + c];
+        other[i] = other_accumulate ? other[i] + v : v;
+    } else {
+        float v = src[i];
+        other[i] = other_accumulate ? other[i] + v : v;
+    }
+}
+
 // dst[i][:] = src[idx[i]][:]
 __global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
                               int64_t rows, int cols) {
@@ -91,6 +108,7 @@ struct BwdPlan {
     float* dP;
     float* dAGG;
     float* dZn;
+    float* dCat;     // [max(E ke, N kx)] gradient w.r.t. the concatenated [initial | current] features
     float* T[2];     // [max(E,N), maxw] scratch for the dZ chain of the MLPs
     float* gWnode;   // [pw, kx] gradient of the packed node-projection weights, accumulated over steps
     float* slab;     // split partials of the weight-gradient products (2 groups)
@@ -125,6 +143,10 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     p.dP = a.f((size_t)N * d.pw);
     p.dAGG = a.f((size_t)N * 2 * d.dn);
     p.dZn = a.f((size_t)N * d.dn);
+    {
+        size_t a1 = (size_t)E * d.ke, a2 = (size_t)N * d.kx;
+        p.dCat = a.f(a1 > a2 ? a1 : a2);
+    }
     int64_t rows = E > N ? E : N;
     int mw = maxw_of(m, d);
     for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
@@ -398,22 +420,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
                 // dPr / dPc: index_put_(accumulate) of x[row], x[col] (mpn.py:69)
                 MPN_TRY(segment_reduce_csr2(dz, he, g.rperm, g.rseg_ptr, (int)N, he, p.dP, pw, (int)N, 0, 0, s));
                 MPN_TRY(segment_reduce_csr2(dz, he, g.cperm_all, g.cseg_all, (int)N, he, p.dP, pw, (int)N, he, he, s));
-                // gradient w.r.t. [e0 | e_{s-1}]
+                // gradient w.r.t. [e0 | e_{s-1}]: one product, then split (e_0 IS e0 at step 1)
                 float* dEp = p.dE[ce ^ 1];
-                const float* W1e = m.edge.weight[0] + 2 * kx;
-                if (two) {
-                    const float* Wa[2] = {W1e, nullptr};
-                    MPN_TRY(act_grad(1, dzq, he, nullptr, Wa, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s));
-                    const float* Wb[2] = {W1e + de, nullptr};
-                    if (step == 1)  // e_{0} IS e0: its gradient joins dE0
-                        MPN_TRY(act_grad(1, dzq, he, nullptr, Wb, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s));
-                    else
-                        MPN_TRY(act_grad(1, dzq, he, nullptr, Wb, m.edge.in_dim, he, de, dEp, de, nullptr, nullptr, 0, 0, nullptr, E, s));
-                } else {
-                    const float* Wa[2] = {W1e, nullptr};
-                    MPN_TRY(act_grad(1, dzq, he, nullptr, Wa, m.edge.in_dim, he, de, step == 1 ? p.dE0 : dEp, de, nullptr,
-                                     nullptr, 0, step == 1 ? 1 : 0, nullptr, E, s));
-                }
+                const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
+                MPN_TRY(act_grad(1, dzq, he, nullptr, Wa, m.edge.in_dim, he, ke, p.dCat, ke, nullptr, nullptr, 0, 0, nullptr, E, s));
+                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, p.dCat, E, de, two ? 1 : 0,
+                                   p.dE0, step == 1 ? p.dE0 : dEp, step == 1 ? 1 : 0);
+                MPN_LAUNCH_CHECK();
             }
         } else {
             MPN_HIP(hipMemsetAsync(p.dP, 0, (size_t)N * pw * 4, s));
@@ -426,16 +439,12 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             MPN_TRY(weight_grad(p, 1, dzq, pw, nullptr, two ? x0 : x_p, dn, two ? x_p : nullptr, dn, dn, nullptr, pw, kx, gw,
                                 kx, nullptr, nullptr, N, s));
             float* dXp = p.dX[cx ^ 1];
-            if (two) {
-                const float* Wa[2] = {f.Wnode, nullptr};
-                MPN_TRY(act_grad(1, dzq, pw, nullptr, Wa, kx, pw, dn, p.dX0, dn, nullptr, nullptr, 0, 1, nullptr, N, s));
-                const float* Wb[2] = {f.Wnode + dn, nullptr};
-                MPN_TRY(act_grad(1, dzq, pw, nullptr, Wb, kx, pw, dn, step == 1 ? p.dX0 : dXp, dn, nullptr, nullptr, 0,
-                                 step == 1 ? 1 : 0, nullptr, N, s));
-            } else {
-                const float* Wa[2] = {f.Wnode, nullptr};
-                MPN_TRY(act_grad(1, dzq, pw, nullptr, Wa, kx, pw, dn, step == 1 ? p.dX0 : dXp, dn, nullptr, nullptr, 0,
-                                 step == 1 ? 1 : 0, nullptr, N, s));
+            const float* Wa[2] = {f.Wnode, nullptr};
+            MPN_TRY(act_grad(1, dzq, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
+            if (xs) {
+                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dCat, N, dn, two ? 1 : 0,
+                                   p.dX0, step == 1 ? p.dX0 : dXp, step == 1 ? 1 : 0);
+                MPN_LAUNCH_CHECK();
             }
         }
         cx ^= 1;

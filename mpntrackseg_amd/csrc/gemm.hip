@@ -36,6 +36,11 @@ constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// component-wise select (a float4 ?: makes hipcc spill both operands to scratch and select the address)
+__device__ __forceinline__ float4 keep4(bool ok, float4 v) {
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
 
 template <int WM, int WN, int TN, int BLAY>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
@@ -130,19 +135,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
         const bool seg2 = kc >= ksplit;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
-            float4 v = ld4((seg2 ? a_p2[j] : a_p1[j]) + kc);
-            a_reg[j] = k_ok ? v : zero4;
+            a_reg[j] = keep4(k_ok, ld4((seg2 ? a_p2[j] : a_p1[j]) + kc));
         }
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             if (BLAY == B_KCONTIG) {
-                b_reg[j] = ld4(b_p[j] + kc);     // A is zero beyond K, B may hold anything finite there
-                if (!k_ok) b_reg[j] = zero4;
+                b_reg[j] = keep4(k_ok, ld4(b_p[j] + kc));
             } else {
                 int kk = kt * BK + b_k[j];
                 bool ok = kk < K;
-                float4 v = ld4(b_p[j] + (int64_t)(ok ? kk : 0) * G.ldb);
-                b_reg[j] = ok ? v : zero4;
+                b_reg[j] = keep4(ok, ld4(b_p[j] + (int64_t)(ok ? kk : 0) * G.ldb));
             }
         }
     };

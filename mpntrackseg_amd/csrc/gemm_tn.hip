@@ -22,12 +22,18 @@ constexpr int TBN = 128;   // k_in tile
 constexpr int TNT = 256;
 
 __device__ __forceinline__ float4 ld4t(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 keep4t(bool ok, float4 v) {
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+// field-wise select of the group (indexing the by-value kernel argument with blockIdx.z would force
+// the whole struct into scratch memory)
+#define TN_G(field) (blockIdx.z == 0 ? args.g[0].field : args.g[1].field)
 
 __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     constexpr int PA = TBM + 4, PB = TBN + 4;
     __shared__ __attribute__((aligned(16))) float As[TBK * PA];
     __shared__ __attribute__((aligned(16))) float Bs[TBK * PB];
-    const TnGroup& G = args.g[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -36,11 +42,14 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     const int o0 = (blockIdx.x / ntile_c) * TBM;
     const int c0 = (blockIdx.x % ntile_c) * TBN;
 
-    const int rb = G.row_begin ? *G.row_begin : 0;
-    const int re = G.row_end ? *G.row_end : (int)G.m_static;
-    int r0 = rb + blockIdx.y * args.chunk;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    const int r0 = rb + blockIdx.y * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;  // empty chunk: the reduce kernel skips it too
 
     // loader geometry: A' tile [32 rows][64 cols] = 512 float4 (2 / thread); B' tile [32][128] = 1024 (4 / thread)
     const int ar = tid >> 4, ac = (tid & 15) * 4;        // + 16 rows for the second
@@ -50,9 +59,10 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     int cc = c0 + bc;
     cc = cc + 3 < k_in ? cc : k_in - 4;
     const bool bseg2 = cc >= csplit;                     // csplit % 4 == 0: a float4 lies in one segment
-    const float* hbase = bseg2 ? G.H2 : G.H;
-    const int64_t ldh = bseg2 ? G.ldh2 : G.ldh;
-    const int hcol = bseg2 ? cc - csplit : cc;
+    const float* hbase = (bseg2 ? TN_G(H2) : TN_G(H)) + (bseg2 ? cc - csplit : cc);
+    const int64_t ldh = bseg2 ? TN_G(ldh2) : TN_G(ldh);
+    const float* zbase = TN_G(dZ) + oc;
+    const int64_t ldz = TN_G(ldz);
 
     f32x16 acc[2];
 #pragma unroll
@@ -60,7 +70,6 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 a_reg[2], b_reg[4];
 
     auto load = [&](int m0) {
@@ -68,19 +77,13 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
         for (int j = 0; j < 2; ++j) {
             int m = m0 + ar + 16 * j;
             bool ok = m < r1;
-            int mc = ok ? m : r1 - 1;
-            int64_t ri = G.dz_idx ? G.dz_idx[mc] : mc;
-            float4 v = ld4t(G.dZ + ri * G.ldz + oc);
-            a_reg[j] = ok ? v : z4;
+            a_reg[j] = keep4t(ok, ld4t(zbase + (int64_t)(ok ? m : r1 - 1) * ldz));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int m = m0 + br + 8 * j;
             bool ok = m < r1;
-            int mc = ok ? m : r1 - 1;
-            int64_t ri = G.h_idx ? G.h_idx[mc] : mc;
-            float4 v = ld4t(hbase + ri * ldh + hcol);
-            b_reg[j] = ok ? v : z4;
+            b_reg[j] = keep4t(ok, ld4t(hbase + (int64_t)(ok ? m : r1 - 1) * ldh));
         }
     };
     auto store = [&]() {
@@ -90,30 +93,28 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Bs[(br + 8 * j) * PB + bc]) = b_reg[j];
     };
 
-    if (r0 < r1) {
-        load(r0);
-        for (int m0 = r0; m0 < r1; m0 += TBK) {
-            store();
-            __syncthreads();
-            if (m0 + TBK < r1) load(m0 + TBK);
+    load(r0);
+    for (int m0 = r0; m0 < r1; m0 += TBK) {
+        store();
+        __syncthreads();
+        if (m0 + TBK < r1) load(m0 + TBK);
 #pragma unroll
-            for (int kk = 0; kk < TBK; kk += 2) {
-                const float a = As[(kk + lh) * PA + wm * 32 + li];
-                const float b0 = Bs[(kk + lh) * PB + wn * 64 + li];
-                const float b1 = Bs[(kk + lh) * PB + wn * 64 + 32 + li];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-            }
-            if (c0 == 0 && tid < TBM) {
-#pragma unroll
-                for (int kk = 0; kk < TBK; ++kk) bsum += As[kk * PA + tid];
-            }
-            __syncthreads();
+        for (int kk = 0; kk < TBK; kk += 2) {
+            const float a = As[(kk + lh) * PA + wm * 32 + li];
+            const float b0 = Bs[(kk + lh) * PB + wn * 64 + li];
+            const float b1 = Bs[(kk + lh) * PB + wn * 64 + 32 + li];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
         }
+        if (c0 == 0 && tid < TBM) {
+#pragma unroll
+            for (int kk = 0; kk < TBK; ++kk) bsum += As[kk * PA + tid];
+        }
+        __syncthreads();
     }
-    // ---- write the partial tile into this chunk's slab (zeros when the chunk is empty) ------------
+    // ---- write the partial tile into this chunk's slab --------------------------------------------
     const int kpad = k_in + 4;
-    float* slab = G.slab + (size_t)blockIdx.y * n_out * kpad;
+    float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * kpad;
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int c = c0 + wn * 64 + tj * 32 + li;
@@ -126,39 +127,31 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     if (c0 == 0 && tid < TBM && o0 + tid < n_out) slab[(size_t)(o0 + tid) * kpad + k_in] = bsum;
 }
 
-// grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]
-__global__ void slab_reduce_kernel(TnArgs args) {
-    const TnGroup& G = args.g[blockIdx.z];
-    const int kpad = args.k_in + 4;
-    const int64_t total = (int64_t)args.n_out * (args.k_in + 1);
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int o = (int)(t / (args.k_in + 1)), c = (int)(t % (args.k_in + 1));
-    const float* p = G.slab + (size_t)o * kpad + (c < args.k_in ? c : args.k_in);
-    const size_t stride = (size_t)args.n_out * kpad;
-    float s = 0.f;
-    for (int i = 0; i < args.nsplit; ++i) s += p[i * stride];
-    if (c < args.k_in) {
-        if (G.grad_w) G.grad_w[(int64_t)o * G.ldw + c] += s;
-    } else if (G.grad_b) {
-        G.grad_b[o] += s;
-    }
-}
-
-// Any shape / alignment: one block per output element (o, c), c == k_in is the bias column.
+// Any shape / alignment / row gathers: grid (output element (o, c), chunk); c == k_in is the bias column.
 __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
-    const TnGroup& G = args.g[blockIdx.z];
     const int o = blockIdx.x / (args.k_in + 1), c = blockIdx.x % (args.k_in + 1);
-    const int rb = G.row_begin ? *G.row_begin : 0;
-    const int re = G.row_end ? *G.row_end : (int)G.m_static;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    const int r0 = rb + blockIdx.y * args.chunk;
+    int r1 = r0 + args.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;
+    const float* dZ = TN_G(dZ);
+    const float* H = TN_G(H);
+    const float* H2 = TN_G(H2);
+    const int* zi = TN_G(dz_idx);
+    const int* hi = TN_G(h_idx);
+    const int64_t ldz = TN_G(ldz), ldh = TN_G(ldh), ldh2 = TN_G(ldh2);
     float s = 0.f;
-    for (int m = rb + threadIdx.x; m < re; m += blockDim.x) {
-        int64_t rz = G.dz_idx ? G.dz_idx[m] : m;
-        float z = G.dZ[rz * G.ldz + o];
+    for (int m = r0 + threadIdx.x; m < r1; m += blockDim.x) {
+        int64_t rz = zi ? zi[m] : m;
+        float z = dZ[rz * ldz + o];
         float h = 1.f;
         if (c < args.k_in) {
-            int64_t rh = G.h_idx ? G.h_idx[m] : m;
-            h = c >= args.csplit ? G.H2[rh * G.ldh2 + c - args.csplit] : G.H[rh * G.ldh + c];
+            int64_t rh = hi ? hi[m] : m;
+            h = c >= args.csplit ? H2[rh * ldh2 + c - args.csplit] : H[rh * ldh + c];
         }
         s = fmaf(z, h, s);
     }
@@ -169,11 +162,41 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
         if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = red[0];
+}
+
+// grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]
+// over the non-empty chunks, in chunk order; 8 lanes share one output element.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
+    const int kpad = args.k_in + 4;
+    const int64_t total = (int64_t)args.n_out * (args.k_in + 1);
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int l = threadIdx.x & 7;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    int nvalid = (re - rb + args.chunk - 1) / args.chunk;
+    nvalid = nvalid < 0 ? 0 : (nvalid > args.nsplit ? args.nsplit : nvalid);
+    float s = 0.f;
+    int o = 0, c = 0;
+    if (t < total) {
+        o = (int)(t / (args.k_in + 1));
+        c = (int)(t % (args.k_in + 1));
+        const float* p = TN_G(slab) + (size_t)o * kpad + c;
+        const size_t stride = (size_t)args.n_out * kpad;
+        for (int i = l; i < nvalid; i += 8) s += p[i * stride];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (t < total && l == 0) {
         if (c < args.k_in) {
-            if (G.grad_w) G.grad_w[(int64_t)o * G.ldw + c] += red[0];
-        } else if (G.grad_b) {
-            G.grad_b[o] += red[0];
+            float* gw = TN_G(grad_w);
+            if (gw) gw[(int64_t)o * TN_G(ldw) + c] += s;
+        } else {
+            float* gb = TN_G(grad_b);
+            if (gb) gb[o] += s;
         }
     }
 }
@@ -190,13 +213,15 @@ size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper) {
 }
 
 void tn_plan(TnArgs& a) {
+    // enough row chunks that tiles x chunks fills the chip about three times over, but never chunks so
+    // short that the slab traffic (nsplit n_out k_in) rivals the operand traffic (rows (n_out + k_in))
     int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
-    int target = 1024 / (tiles > 0 ? tiles : 1);
+    int target = 768 / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
-    if (target > 256) target = 256;
+    if (target > 128) target = 128;
     int64_t chunk = (a.m_upper + target - 1) / target;
     chunk = (chunk + TBK - 1) / TBK * TBK;
-    if (chunk < 256) chunk = 256;
+    if (chunk < 128) chunk = 128;
     a.chunk = (int)chunk;
     a.nsplit = (int)((a.m_upper + chunk - 1) / chunk);
     if (a.nsplit < 1) a.nsplit = 1;
@@ -210,21 +235,20 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
     bool fast = (a.n_out % 4 == 0) && (a.k_in % 4 == 0) && (a.csplit % 4 == 0);
     for (int i = 0; i < a.ngroups; ++i) {
         const TnGroup& g = a.g[i];
-        MPN_CHECK_ARG(g.dZ && g.H && (a.csplit == a.k_in || g.H2), "gemm_tn: null operand");
-        fast = fast && al16t(g.dZ) && g.ldz % 4 == 0 && al16t(g.H) && g.ldh % 4 == 0 &&
-               (!g.H2 || (al16t(g.H2) && g.ldh2 % 4 == 0)) && g.slab;
-    }
-    if (!fast) {
-        dim3 grid((unsigned)(a.n_out * (a.k_in + 1)), 1, a.ngroups);
-        hipLaunchKernelGGL(gemm_tn_generic_kernel, grid, dim3(256), 0, s, a);
-        MPN_LAUNCH_CHECK();
-        return MPNHIP_OK;
+        MPN_CHECK_ARG(g.dZ && g.H && (a.csplit == a.k_in || g.H2) && g.slab, "gemm_tn: null operand");
+        fast = fast && !g.dz_idx && !g.h_idx && al16t(g.dZ) && g.ldz % 4 == 0 && al16t(g.H) && g.ldh % 4 == 0 &&
+               (!g.H2 || (al16t(g.H2) && g.ldh2 % 4 == 0));
     }
     tn_plan(a);
-    int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, a.nsplit, a.ngroups), dim3(TNT), 0, s, a);
+    if (fast) {
+        int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, a.nsplit, a.ngroups), dim3(TNT), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)(a.n_out * (a.k_in + 1)), a.nsplit, a.ngroups), dim3(256),
+                           0, s, a);
+    }
     MPN_LAUNCH_CHECK();
-    int64_t total = (int64_t)a.n_out * (a.k_in + 1);
+    int64_t total = (int64_t)a.n_out * (a.k_in + 1) * 8;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, a.ngroups), dim3(256), 0, s, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
