@@ -42,8 +42,11 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v) {
     return v;
 }
 
+// waves per SIMD the register allocation must leave room for (accumulators: 16 TN registers)
+constexpr int min_waves(int tn) { return tn <= 2 ? 4 : (tn <= 4 ? 3 : 2); }
+
 template <int WM, int WN, int TN, int BLAY>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
+__global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs args) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
@@ -94,33 +97,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
     const int N = args.N, K = args.K, ksplit = args.ksplit;
 
     // ---- loader set-up: thread covers tile rows (tid/8 + 32 j) at k offset (tid%8)*4 --------------
+    // 32-bit element offsets from the (scalar) operand bases keep the address state small
     const int ld_r = tid >> 3, ld_k4 = (tid & 7) * 4;
-    const float* a_p1[A_F4];
-    const float* a_p2[A_F4];
+    const float* const Abase = G.A;
+    const float* const A2base = G.A2 ? G.A2 - ksplit : G.A;
+    const float* const Bbase = G.B;
+    int a_o1[A_F4], a_o2[A_F4];
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
         int r = row0 + ld_r + 32 * j;
         r = r < row_end ? r : row_end - 1;  // rows past the end are computed but never stored
-        int64_t ri = G.a_idx ? (int64_t)G.a_idx[r] : (int64_t)r;
-        a_p1[j] = G.A + ri * G.lda;
-        a_p2[j] = G.A2 ? G.A2 + ri * G.lda2 - ksplit : a_p1[j];
+        int ri = G.a_idx ? G.a_idx[r] : r;
+        a_o1[j] = ri * (int)G.lda;
+        a_o2[j] = G.A2 ? ri * (int)G.lda2 : a_o1[j];
     }
     // B_KCONTIG: rows are output columns n (weight rows); B_NCONTIG: thread covers k = tid/(BN/4) + .., n4
-    const float* b_p[B_F4];
+    int b_o[B_F4];
     int b_k[B_F4];  // B_NCONTIG: k row inside the tile
 #pragma unroll
     for (int j = 0; j < B_F4; ++j) {
         if (BLAY == B_KCONTIG) {
             int n = col0 + ld_r + 32 * j;
             n = n < N ? n : N - 1;
-            b_p[j] = G.B + (int64_t)n * G.ldb;
+            b_o[j] = n * (int)G.ldb;
             b_k[j] = 0;
         } else {
             int f = tid + NTHREADS * j;          // float4 index inside the [BK][BN/4] tile
             int kr = f / (BN / 4), n4 = f % (BN / 4);
             int n = col0 + n4 * 4;
             n = n + 3 < N ? n : (N - 4);          // N % 4 == 0 on this path; clamped columns are never stored
-            b_p[j] = G.B + n;
+            b_o[j] = n;
             b_k[j] = kr;
         }
     }
@@ -135,16 +141,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
         const bool seg2 = kc >= ksplit;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
-            a_reg[j] = keep4(k_ok, ld4((seg2 ? a_p2[j] : a_p1[j]) + kc));
+            a_reg[j] = keep4(k_ok, ld4((seg2 ? A2base : Abase) + (seg2 ? a_o2[j] : a_o1[j]) + kc));
         }
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             if (BLAY == B_KCONTIG) {
-                b_reg[j] = keep4(k_ok, ld4(b_p[j] + kc));
+                b_reg[j] = keep4(k_ok, ld4(Bbase + b_o[j] + kc));
             } else {
                 int kk = kt * BK + b_k[j];
                 bool ok = kk < K;
-                b_reg[j] = keep4(ok, ld4(b_p[j] + (int64_t)(ok ? kk : 0) * G.ldb));
+                b_reg[j] = keep4(ok, ld4(Bbase + b_o[j] + (ok ? kk : 0) * (int)G.ldb));
             }
         }
     };
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool vec_ok = args.epi_vec != 0;
     int m_row[4];
-    int64_t g1_off[4], g2_off[4], c_off[4];
+    int g1_off[4], g2_off[4], c_off[4];
     bool m_ok[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -216,9 +222,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
         m_ok[p] = m < row_end;
         int mc = m_ok[p] ? m : row_end - 1;
         m_row[p] = mc;
-        g1_off[p] = (int64_t)(G.g1_idx ? G.g1_idx[mc] : mc) * G.ldg1;
-        g2_off[p] = (int64_t)(G.g2_idx ? G.g2_idx[mc] : mc) * G.ldg2;
-        c_off[p] = (int64_t)(G.c_idx ? G.c_idx[mc] : mc) * G.ldc;
+        g1_off[p] = (G.g1_idx ? G.g1_idx[mc] : mc) * (int)G.ldg1;
+        g2_off[p] = (G.g2_idx ? G.g2_idx[mc] : mc) * (int)G.ldg2;
+        c_off[p] = (G.c_idx ? G.c_idx[mc] : mc) * (int)G.ldc;
     }
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) {
@@ -231,28 +237,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
         if (vec_ok) {
             const bool n_ok = n < N;          // N % 4 == 0 here
             const int nc = n_ok ? n : N - 4;
-            float4 bias = G.bias ? ld4(G.bias + nc) : zero4;
-            float4 v[4], g1[4], g2[4], mk[4], old[4];
+            const float4 bias = G.bias ? ld4(G.bias + nc) : zero4;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                v[p] = *reinterpret_cast<const float4*>(&patch[(er + 8 * p) * 36 + ec]);
-                g1[p] = G.G1 ? ld4(G.G1 + g1_off[p] + nc) : zero4;
-                g2[p] = G.G2 ? ld4(G.G2 + g2_off[p] + nc) : zero4;
-                mk[p] = G.mask ? ld4(G.mask + (int64_t)m_row[p] * G.ldmask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-                old[p] = args.accumulate ? ld4(G.C + c_off[p] + nc) : zero4;
-            }
+            for (int ph = 0; ph < 4; ph += 2) {
+                float4 v[2], g1[2], g2[2], mk[2], old[2];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float4 o;
-                o.x = v[p].x + bias.x + g1[p].x + g2[p].x;
-                o.y = v[p].y + bias.y + g1[p].y + g2[p].y;
-                o.z = v[p].z + bias.z + g1[p].z + g2[p].z;
-                o.w = v[p].w + bias.w + g1[p].w + g2[p].w;
-                if (args.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                o.x += old[p].x; o.y += old[p].y; o.z += old[p].z; o.w += old[p].w;
-                o.x = mk[p].x > 0.f ? o.x : 0.f; o.y = mk[p].y > 0.f ? o.y : 0.f;
-                o.z = mk[p].z > 0.f ? o.z : 0.f; o.w = mk[p].w > 0.f ? o.w : 0.f;
-                if (m_ok[p] && n_ok) *reinterpret_cast<float4*>(G.C + c_off[p] + nc) = o;
+                for (int q = 0; q < 2; ++q) {
+                    const int p = ph + q;
+                    v[q] = *reinterpret_cast<const float4*>(&patch[(er + 8 * p) * 36 + ec]);
+                    g1[q] = G.G1 ? ld4(G.G1 + g1_off[p] + nc) : zero4;
+                    g2[q] = G.G2 ? ld4(G.G2 + g2_off[p] + nc) : zero4;
+                    mk[q] = G.mask ? ld4(G.mask + m_row[p] * (int)G.ldmask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    old[q] = args.accumulate ? ld4(G.C + c_off[p] + nc) : zero4;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = ph + q;
+                    float4 o;
+                    o.x = v[q].x + bias.x + g1[q].x + g2[q].x;
+                    o.y = v[q].y + bias.y + g1[q].y + g2[q].y;
+                    o.z = v[q].z + bias.z + g1[q].z + g2[q].z;
+                    o.w = v[q].w + bias.w + g1[q].w + g2[q].w;
+                    if (args.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    o.x += old[q].x; o.y += old[q].y; o.z += old[q].z; o.w += old[q].w;
+                    o.x = mk[q].x > 0.f ? o.x : 0.f; o.y = mk[q].y > 0.f ? o.y : 0.f;
+                    o.z = mk[q].z > 0.f ? o.z : 0.f; o.w = mk[q].w > 0.f ? o.w : 0.f;
+                    if (m_ok[p] && n_ok) *reinterpret_cast<float4*>(G.C + c_off[p] + nc) = o;
+                }
             }
         } else {
 #pragma unroll
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs args) {
                     if (G.G2) o += G.G2[g2_off[p] + nc];
                     if (args.relu) o = fmaxf(o, 0.f);
                     if (args.accumulate) o += G.C[c_off[p] + nc];
-                    if (G.mask) o = G.mask[(int64_t)m_row[p] * G.ldmask + nc] > 0.f ? o : 0.f;
+                    if (G.mask) o = G.mask[m_row[p] * (int)G.ldmask + nc] > 0.f ? o : 0.f;
                     if (ok) G.C[c_off[p] + nc] = o;
                 }
             }
@@ -331,6 +342,8 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
     MPN_CHECK_ARG(al == A_KCONTIG, "gemm: A must be K-contiguous (weight-gradient products use gemm_tn)");
     if (a.m_upper <= 0 || a.N == 0) return MPNHIP_OK;  // nothing to compute (empty graph)
     bool fast = (a.K % 4 == 0) && (a.ksplit % 4 == 0) && a.K > 0;
+    // the MFMA kernel addresses operands with 32-bit element offsets
+    const int64_t lim = (int64_t)1 << 31;
     bool epi_vec = (a.N % 4 == 0);
     for (int i = 0; i < a.ngroups; ++i) {
         const GemmGroup& g = a.g[i];
@@ -338,6 +351,10 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         MPN_CHECK_ARG(a.ksplit == a.K || g.A2, "gemm: ksplit without a second A segment");
         fast = fast && al16(g.A) && (g.lda % 4 == 0) && (!g.A2 || (al16(g.A2) && g.lda2 % 4 == 0)) && al16(g.B) && (g.ldb % 4 == 0);
         if (bl == B_NCONTIG) fast = fast && (a.N % 4 == 0);
+        const int64_t rows = a.m_upper + 1;
+        MPN_CHECK_ARG(rows * g.lda < lim && rows * g.lda2 < lim && rows * g.ldc < lim && rows * g.ldg1 < lim &&
+                          rows * g.ldg2 < lim && rows * g.ldmask < lim && (int64_t)(a.N + a.K) * g.ldb < lim,
+                      "gemm: operand too large for 32-bit element offsets");
         epi_vec = epi_vec && al16(g.C) && (g.ldc % 4 == 0) && (!g.bias || al16(g.bias)) &&
                   (!g.G1 || (al16(g.G1) && g.ldg1 % 4 == 0)) && (!g.G2 || (al16(g.G2) && g.ldg2 % 4 == 0)) &&
                   (!g.mask || (al16(g.mask) && g.ldmask % 4 == 0));
