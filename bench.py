@@ -38,26 +38,56 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(params, W, g, budget_s=15.0):
-    """The CPU oracle (torch-CPU restatement of the reference path) timed on this box's host cores:
-    forward over the same graph, as many runs as fit ~budget_s (at least 2, first one discarded)."""
+def usable_cores():
+    """Host cores this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(params, W, g, train, budget_s=20.0):
+    """The CPU oracle (torch-CPU restatement of the reference path: same ops as the reference's PyTorch CPU
+    path) timed on this box's host cores on the SAME graph: forward, or forward+backward with the bench's loss
+    gradient when `train`.  Bounded sample: first run discarded, then runs until ~budget_s (2..10 runs)."""
     from oracle import mpn_oracle as O
-    nthreads = os.cpu_count() or 1
+    nthreads = usable_cores()
     torch.set_num_threads(nthreads)
-    Wt = O.to_tensors(W)
+    Wt = O.to_tensors(W, requires_grad=train)
     x, ei, ea = (torch.from_numpy(g[k]) for k in ("x", "edge_index", "edge_attr"))
+    E = ei.shape[1]
+    labels = (torch.arange(E) % 7 == 0).float()
+
+    def run():
+        if not train:
+            with torch.no_grad():
+                O.forward(params, Wt, x, ei, ea)
+            return
+        _, logits, _, _ = O.forward(params, Wt, x, ei, ea, return_state=True)
+        lg = torch.stack([l.view(-1) for l in logits])
+        pos = labels.sum()
+        pw = (E - pos) / pos.clamp(min=1)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, labels.expand_as(lg), pos_weight=pw, reduction="sum") / E
+        torch.autograd.grad(loss, list(Wt.values()))
+
     times = []
     t_start = time.time()
-    with torch.no_grad():
-        while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 20):
-            t0 = time.perf_counter()
-            O.forward(params, Wt, x, ei, ea)
-            times.append(time.perf_counter() - t0)
+    while len(times) < 3 and (len(times) < 2 or time.time() - t_start < budget_s):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    while time.time() - t_start < budget_s and len(times) < 11:
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
-    E = ei.shape[1]
     return {"value": E / (t * 1e3), "unit": "edges/ms", "cores": nthreads, "kind": "port",
-            "sample": "oracle/mpn_oracle.py forward (torch %s CPU, %d threads) on the same graph, median of %d runs, %.0f ms each"
-                      % (torch.__version__, nthreads, len(times) - 1, t * 1e3)}
+            "sample": "oracle/mpn_oracle.py %s (torch %s CPU ops, %d threads) on the same cfg graph, median of %d runs after 1 warm-up, %.0f ms each"
+                      % ("forward+backward" if train else "forward", torch.__version__, nthreads, len(times) - 1, t * 1e3)}
 
 
 def main():
@@ -125,8 +155,12 @@ def main():
         def step():
             return stepper(x, ei, ea, holder=holder)
 
+    lib = capi.load()
     for _ in range(args.warmup):
         step()
+    profiled = rank == 0 and not args.no_roofline
+    if profiled:
+        lib.mpnhip_profile_enable(1)  # HIP events around the dominant GEMM and the aggregation kernel, in-stream
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -136,6 +170,12 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    prof = None
+    if profiled:
+        gu, gc, au, ac = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_float(0), ctypes.c_int(0)
+        capi.check(lib.mpnhip_profile_read(ctypes.byref(gu), ctypes.byref(gc), ctypes.byref(au), ctypes.byref(ac)), "profile_read")
+        lib.mpnhip_profile_enable(0)
+        prof = (gu.value, gc.value, au.value, ac.value)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -159,10 +199,10 @@ def main():
         "edge_steps_per_ms": value * c["L"],
     }
 
-    if rank == 0 and not args.no_roofline:
-        out.update(measure_rooflines(capi, synth, model, c, args, dev, x, ei, ea, holder, N, E))
+    if prof is not None:
+        out.update(rooflines(prof, c, args, N, E))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(params, W, g)
+        out["cpu_baseline"] = cpu_baseline(params, W, g, mode == "train")
     if mode == "train":
         # forward-only rate beside the training rate (the north-star target is quoted on forward)
         model.eval()
@@ -182,38 +222,40 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_rooflines(capi, synth, model, c, args, dev, x, ei, ea, holder, N, E):
-    """Live HIP-event timing (on the launch stream) of the two kernels that bound the path:
-    the fp32 MFMA GEMM at the edge-MLP layer-1 shape (dominant by time) and the aggregation kernel."""
-    lib = capi.load()
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
+    tools/pmc_summary.py with the MI355X guide's corrections), or None."""
+    path = os.path.join(REPO, "profiles", "r01", "pmc_summary.json")
+    try:
+        return json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def rooflines(prof, c, args, N, E):
+    """Roofline fractions from the in-stream HIP-event timings taken over the timed region:
+    dominant kernel = first-layer edge-MLP GEMM (fp32 MFMA); HBM-bound kernel = segmented aggregation."""
+    gemm_us, gemm_n, agg_us, agg_n = prof
     d = c["d"]
     dn, de, he = d, d // 2, 5 * d // 2
     res = {}
-    # --- dominant kernel: edge MLP first layer  [E, 2de] x [2de, he]  (+bias, ReLU), fp32 MFMA
-    K, Nn = 2 * de, he
-    a = torch.from_numpy(synth.normal(3, (E, K))).to(dev)
-    w = torch.from_numpy(synth.normal(3, (Nn, K), stream=1, std=(2.0 / K) ** 0.5)).to(dev)
-    b = torch.zeros(Nn, device=dev)
-    y = torch.empty((E, Nn), device=dev)
-    us = ctypes.c_float(0)
-    capi.check(lib.mpnhip_time_linear(capi.ptr(a), capi.ptr(w), capi.ptr(b), capi.ptr(y), E, Nn, K, 50,
-                                      ctypes.byref(us), capi.stream_ptr()), "time_linear")
-    flops = 2.0 * E * K * Nn
-    res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (edge MLP layer 1: [%d,%d]x[%d,%d] fp32 MFMA 32x32x2)" % (E, K, K, Nn),
-                       "achieved": flops / (us.value * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                       "frac": flops / (us.value * 1e-6) / 1e12 / 157.3, "traffic": None, "avg_us": us.value}
-    # --- aggregation kernel: M (dn*4 + 4) + N dn 4 bytes per direction (SURVEY.md section 8d (i)), both directions
-    from mpntrackseg_amd.mpn import _prepared
-    g = _prepared(ei, N, holder)
-    msg = torch.from_numpy(np.maximum(synth.normal(4, (E, dn)), 0)).to(dev)
-    out = torch.empty((N, 2 * dn), device=dev)
-    capi.check(lib.mpnhip_time_aggregate(capi.ptr(g.buf), N, E, capi.ptr(msg), dn, capi.AGG_CODE[args.agg], capi.ptr(out),
-                                         100, ctypes.byref(us), capi.stream_ptr()), "time_aggregate")
-    bytes_agg = E * (dn * 4 + 4) + 2 * N * dn * 4 + (2 * N + 1) * 4
-    res["roofline_aggregation"] = {"bound": "hbm", "kernel": "k_segment_reduce (both directions, %d messages x %d-d)" % (E, dn),
-                                   "achieved": bytes_agg / (us.value * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                   "frac": bytes_agg / (us.value * 1e-6) / 1e9 / 8000.0, "traffic": None,
-                                   "avg_us": us.value, "algorithmic_bytes": bytes_agg}
+    if gemm_n:
+        K, Nn = 2 * de, he
+        flops = 2.0 * E * K * Nn  # algorithmic: E rows x [e0|e] (2 de) x he outputs (DESIGN.md section 4)
+        ach = flops / (gemm_us * 1e-6) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (B K-contiguous): edge-MLP layer 1 [%d,%d]x[%d,%d] fp32, "
+                                                      "v_mfma_f32_32x32x2_f32, gather-add epilogue" % (E, K, K, Nn),
+                           "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                           "traffic": pmc_traffic("gemm_edge_l1"), "avg_us": gemm_us, "launches": gemm_n,
+                           "algorithmic_flops": flops}
+    if agg_n:
+        # SURVEY.md section 8d (i): M (dn s + 4) + N dn s per direction (+ CSR offsets), both directions in one launch
+        bytes_agg = E * (dn * 4 + 4) + 2 * N * dn * 4 + (2 * N + 1) * 4
+        ach = bytes_agg / (agg_us * 1e-6) / 1e9
+        res["roofline_aggregation"] = {"bound": "hbm", "kernel": "k_segment_reduce<4> (both directions, %d messages x %d-d, %s)" % (E, dn, args.agg),
+                                       "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                                       "traffic": pmc_traffic("segment_reduce"), "avg_us": agg_us, "launches": agg_n,
+                                       "algorithmic_bytes": bytes_agg}
     return res
 
 

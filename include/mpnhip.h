@@ -150,6 +150,13 @@ int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream)
 /* ---------------------------------------------------------------------------------------------
  * Measurement helpers used by bench.py (HIP events on the launch stream; these synchronise).
  * ------------------------------------------------------------------------------------------- */
+/* In-stream kernel timing of the real hot path: while enabled, mpnhip_forward brackets (a) the first-layer
+ * edge-MLP GEMM (the dominant MFMA kernel) and (b) the aggregation kernel (the HBM-bound one) of every
+ * message-passing step with HIP events on the launch stream.  mpnhip_profile_read synchronises, returns
+ * the average duration (us) and launch count of each since the last read, and resets the counters. */
+int mpnhip_profile_enable(int on);
+int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches);
+
 /* Average duration in microseconds of `iters` back-to-back launches of the aggregation kernel on
  * a prepared graph: src [E, dim] in SORTED edge order, out [N, 2*dim]. */
 int mpnhip_time_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, const float* src, int dim, int agg,

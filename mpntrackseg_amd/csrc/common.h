@@ -147,6 +147,11 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
                         int64_t ldo, int nmod, int off0, int off1, hipStream_t stream);
 
+// in-stream event timing of two designated kernels (see mpnhip_profile_enable)
+enum { PROF_GEMM = 0, PROF_AGG = 1 };
+void prof_begin(int kind, hipStream_t s);
+void prof_end(int kind, hipStream_t s);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace mpnhip

@@ -26,6 +26,38 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ------------------------------------------------------------------------------------ event profiling
+namespace {
+constexpr int PROF_MAX = 2048;
+struct ProfState {
+    bool on = false;
+    hipEvent_t ev[2][PROF_MAX][2];
+    bool made[2] = {false, false};
+    int n[2] = {0, 0};
+    int open_kind = -1;
+} g_prof;
+}  // namespace
+
+void prof_begin(int kind, hipStream_t s) {
+    if (!g_prof.on || g_prof.n[kind] >= PROF_MAX) return;
+    if (!g_prof.made[kind]) {
+        for (int i = 0; i < PROF_MAX; ++i) {
+            (void)hipEventCreate(&g_prof.ev[kind][i][0]);
+            (void)hipEventCreate(&g_prof.ev[kind][i][1]);
+        }
+        g_prof.made[kind] = true;
+    }
+    (void)hipEventRecord(g_prof.ev[kind][g_prof.n[kind]][0], s);
+    g_prof.open_kind = kind;
+}
+
+void prof_end(int kind, hipStream_t s) {
+    if (!g_prof.on || g_prof.open_kind != kind || g_prof.n[kind] >= PROF_MAX) return;
+    (void)hipEventRecord(g_prof.ev[kind][g_prof.n[kind]][1], s);
+    g_prof.n[kind]++;
+    g_prof.open_kind = -1;
+}
+
 // ------------------------------------------------------------------------------------ small kernels
 // dst[r][c] = src[r][c0 + c] for r < rows, c < cols  (weight sub-block copy)
 __global__ void k_copy_block(const float* __restrict__ src, int64_t lds, int c0, float* __restrict__ dst, int64_t ldd,
@@ -178,7 +210,9 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
             bool last = m.edge.n_layers == 1;
             G.C = last ? io.e_new : b.HE[0]; G.ldc = last ? d.de : he; G.c_idx = last ? io.e_new_idx : nullptr;
             G.m_static = E;
+            prof_begin(PROF_GEMM, s);
             MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+            prof_end(PROF_GEMM, s);
         }
         MPN_TRY(mlp_tail(m.edge, nullptr, nullptr, b.HE, io.e_new, d.de, io.e_new_idx, E, s));
         // (3) classifier on the NEW edge features (mpn.py:377 -> :114)
@@ -216,7 +250,9 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         MPN_TRY(mlp_tail(m.flow_out, &m.flow_in, &g, b.HF, b.M, d.dn, nullptr, E, s));
     }
     // (5) aggregation (node_agg_fn, mpn.py:89,96) and node update (mpn.py:97-99)
+    prof_begin(PROF_AGG, s);
     MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
+    prof_end(PROF_AGG, s);
     MPN_TRY(linear(b.AGG, 2 * d.dn, m.node.weight[0], m.node.bias[0], io.x_new, d.dn, N, d.dn, 2 * d.dn, 1, s));
     return MPNHIP_OK;
 }
@@ -425,6 +461,31 @@ extern "C" int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, vo
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        x, rows, hw, y, sub);
     MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_profile_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.n[0] = g_prof.n[1] = 0;
+    g_prof.open_kind = -1;
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches) {
+    MPN_HIP(hipDeviceSynchronize());
+    float* outs[2] = {gemm_avg_us, agg_avg_us};
+    int* cnts[2] = {gemm_launches, agg_launches};
+    for (int k = 0; k < 2; ++k) {
+        double tot = 0.0;
+        for (int i = 0; i < g_prof.n[k]; ++i) {
+            float ms = 0.f;
+            MPN_HIP(hipEventElapsedTime(&ms, g_prof.ev[k][i][0], g_prof.ev[k][i][1]));
+            tot += ms;
+        }
+        if (outs[k]) *outs[k] = g_prof.n[k] ? (float)(tot * 1000.0 / g_prof.n[k]) : 0.f;
+        if (cnts[k]) *cnts[k] = g_prof.n[k];
+        g_prof.n[k] = 0;
+    }
     return MPNHIP_OK;
 }
 

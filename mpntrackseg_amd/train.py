@@ -35,6 +35,15 @@ def bce_logits_grad(logits, labels, first_step=0):
     return g, w
 
 
+def allreduce_mean_(flat, world_size, group=None):
+    """In-place all-reduce(sum) / W of a flat gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world_size)
+    return flat
+
+
 class FlatBucket:
     """Parameters' gradients as views of one flat fp32 buffer (one collective per step)."""
 
@@ -84,10 +93,7 @@ class TrainStep:
         glog, _ = bce_logits_grad(logits, labels, self.first_class_step)
         self.bucket.zero_()
         native_backward(model, g, x, ea, glog, ws, self.bucket.views)
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
-            self.bucket.flat.mul_(1.0 / self.world_size)
+        allreduce_mean_(self.bucket.flat, self.world_size, self.pg)
         if optimizer_step:
             self.opt.step()
         return logits
