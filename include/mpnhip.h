@@ -153,9 +153,11 @@ int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream)
 /* In-stream kernel timing of the real hot path: while enabled, mpnhip_forward brackets (a) the first-layer
  * edge-MLP GEMM (the dominant MFMA kernel) and (b) the aggregation kernel (the HBM-bound one) of every
  * message-passing step with HIP events on the launch stream.  mpnhip_profile_read synchronises, returns
- * the average duration (us) and launch count of each since the last read, and resets the counters. */
+ * the average duration (us) and launch count of each since the last read, and resets the counters.
+ * The empty-pair cost applies to the default (NULL) stream the calibration pairs are recorded on. */
 int mpnhip_profile_enable(int on);
-int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches);
+int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches,
+                        float* empty_pair_us /* cost of an event pair with nothing between, for calibration */);
 
 /* Average duration in microseconds of `iters` back-to-back launches of the aggregation kernel on
  * a prepared graph: src [E, dim] in SORTED edge order, out [N, 2*dim]. */

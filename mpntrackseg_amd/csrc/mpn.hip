@@ -39,7 +39,7 @@ struct ProfState {
 }  // namespace
 
 void prof_begin(int kind, hipStream_t s) {
-    if (!g_prof.on || g_prof.n[kind] >= PROF_MAX) return;
+    if (!g_prof.on || g_prof.n[kind] >= PROF_MAX - 64) return;
     if (!g_prof.made[kind]) {
         for (int i = 0; i < PROF_MAX; ++i) {
             (void)hipEventCreate(&g_prof.ev[kind][i][0]);
@@ -52,7 +52,7 @@ void prof_begin(int kind, hipStream_t s) {
 }
 
 void prof_end(int kind, hipStream_t s) {
-    if (!g_prof.on || g_prof.open_kind != kind || g_prof.n[kind] >= PROF_MAX) return;
+    if (!g_prof.on || g_prof.open_kind != kind || g_prof.n[kind] >= PROF_MAX - 64) return;
     (void)hipEventRecord(g_prof.ev[kind][g_prof.n[kind]][1], s);
     g_prof.n[kind]++;
     g_prof.open_kind = -1;
@@ -471,8 +471,29 @@ extern "C" int mpnhip_profile_enable(int on) {
     return MPNHIP_OK;
 }
 
-extern "C" int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches) {
+extern "C" int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches,
+                                   float* empty_pair_us) {
     MPN_HIP(hipDeviceSynchronize());
+    if (empty_pair_us) {
+        // what a begin/end event pair costs with NO kernel between them (same stream, same API calls)
+        *empty_pair_us = 0.f;
+        if (g_prof.made[PROF_AGG] || g_prof.made[PROF_GEMM]) {
+            const int k = g_prof.made[PROF_AGG] ? PROF_AGG : PROF_GEMM;
+            const int reps = 64;
+            for (int i = 0; i < reps; ++i) {
+                MPN_HIP(hipEventRecord(g_prof.ev[k][PROF_MAX - 1 - i][0], 0));
+                MPN_HIP(hipEventRecord(g_prof.ev[k][PROF_MAX - 1 - i][1], 0));
+            }
+            MPN_HIP(hipDeviceSynchronize());
+            double tot = 0.0;
+            for (int i = 0; i < reps; ++i) {
+                float ms = 0.f;
+                MPN_HIP(hipEventElapsedTime(&ms, g_prof.ev[k][PROF_MAX - 1 - i][0], g_prof.ev[k][PROF_MAX - 1 - i][1]));
+                tot += ms;
+            }
+            *empty_pair_us = (float)(tot * 1000.0 / reps);
+        }
+    }
     float* outs[2] = {gemm_avg_us, agg_avg_us};
     int* cnts[2] = {gemm_launches, agg_launches};
     for (int k = 0; k < 2; ++k) {

@@ -116,6 +116,54 @@ __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
     }
 }
 
+// Forward neighbour aggregation of one message-passing step (the kernel the HBM-roofline target of
+// BASELINE.json is quoted on).  Same arithmetic as k_segment_reduce<4> on the (direction, row) CSR of
+// the sorted edges -- rows of a segment are contiguous, no index list -- with eight independent 16-byte
+// row loads in flight per lane, so the typical segment (E/N = 10: five rows per direction) costs ONE
+// memory round trip after the CSR offsets.  dim % 4 == 0.
+__global__ __launch_bounds__(256) void k_aggregate(SegArgs a) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = gtid / a.sub;
+    const int l = gtid % a.sub;
+    if (s >= a.nseg) return;
+    const int beg = a.ptr[s], end = a.ptr[s + 1];
+    const int64_t orow = (int64_t)(s % a.nmod) * a.ldo + ((s / a.nmod) == 0 ? a.off0 : a.off1);
+    const bool is_max = a.agg == MPNHIP_AGG_MAX;
+    for (int c = l * 4; c < a.dim; c += a.sub * 4) {
+        float4 acc;
+        vset(acc, is_max ? -INFINITY : 0.f);
+        int arg_s[4] = {-1, -1, -1, -1};
+        const float* base = a.src + c;
+        for (int j = beg; j < end; j += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u < end ? j + u : end - 1;  // clamped: unconditional loads
+                v[u] = *reinterpret_cast<const float4*>(base + (int64_t)jj * a.lds);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j + u < end) {
+                    if (is_max) vmax(acc, arg_s, v[u], j + u);
+                    else vadd(acc, v[u]);
+                }
+            }
+        }
+        if (a.agg == MPNHIP_AGG_MEAN) {
+            const int cnt = end - beg;
+            vdiv(acc, (float)(cnt > 0 ? cnt : 1));
+        } else if (is_max && end == beg) {
+            vset(acc, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.out + orow + c) = acc;
+        if (a.argmax) {
+            int* ap = a.argmax + orow + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ap[q] = arg_s[q];
+        }
+    }
+}
+
 static int launch_seg(SegArgs a, hipStream_t stream) {
     if (a.nseg <= 0 || a.dim <= 0) return MPNHIP_OK;
     bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
@@ -147,6 +195,15 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
     a.nmod = g.N > 0 ? g.N : 1;
     a.off0 = dim;  // flow_out goes to the right half: torch.cat((flow_in, flow_out)) (mpn.py:97)
     a.off1 = 0;
+    if (dim % 4 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0 && a.nseg > 0) {
+        int sub = 1;
+        while (sub < dim / 4 && sub < 64) sub <<= 1;
+        a.sub = sub;
+        const int64_t threads = (int64_t)a.nseg * sub;
+        hipLaunchKernelGGL(k_aggregate, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
     return launch_seg(a, stream);
 }
 
