@@ -30,30 +30,39 @@ __global__ void k_relu_mask(const float* __restrict__ g, const float* __restrict
 // Backward of node_agg_fn followed by the ReLU of the last flow layer:
 //   dZM[j][c] = [M[j][c] > 0] * dAGG[srow[j]][half(j) + c] (* 1/cnt for mean) (* [ARG == j] for max)
 // j in sorted order; half = dn for flow_out rows (j < E_out), 0 for flow_in rows; self-loop rows -> 0.
+// One thread per 4 columns (dn % 4 == 0) or per column.
 __global__ void k_agg_bwd(const float* __restrict__ dagg, const float* __restrict__ msg, const int* __restrict__ arg,
                           const int* __restrict__ srow, const int* __restrict__ seg_ptr, const int* __restrict__ header,
                           int N, int64_t E, int dn, int agg, int has_relu, float* __restrict__ out) {
+    const bool vec = (dn & 3) == 0;
+    const int per = vec ? dn >> 2 : dn;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t j = t / dn;
-    int c = (int)(t % dn);
+    int64_t j = t / per;
+    int c = (int)(t % per) * (vec ? 4 : 1);
     if (j >= E) return;
     const int e_out = header[1], e_in = header[2];
-    float v = 0.f;
+    const int w = vec ? 4 : 1;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (j < e_out + e_in) {
         const int dir = j < e_out ? 0 : 1;
         const int row = srow[j];
         const int64_t o = (int64_t)row * 2 * dn + (dir == 0 ? dn : 0) + c;
-        v = dagg[o];
+        float scale = 1.f;
         if (agg == MPNHIP_AGG_MEAN) {
             const int key = dir * N + row;
             const int cnt = seg_ptr[key + 1] - seg_ptr[key];
-            v = v / (float)(cnt > 0 ? cnt : 1);
-        } else if (agg == MPNHIP_AGG_MAX) {
-            v = arg[o] == (int)j ? v : 0.f;
+            scale = (float)(cnt > 0 ? cnt : 1);
         }
-        if (has_relu) v = msg[j * dn + c] > 0.f ? v : 0.f;
+        for (int q = 0; q < w; ++q) {
+            float x = dagg[o + q];
+            if (agg == MPNHIP_AGG_MEAN) x = x / scale;
+            else if (agg == MPNHIP_AGG_MAX) x = arg[o + q] == (int)j ? x : 0.f;
+            if (has_relu) x = msg[j * dn + c + q] > 0.f ? x : 0.f;
+            v[q] = x;
+        }
     }
-    out[j * dn + c] = v;
+    if (vec) *reinterpret_cast<float4*>(out + j * dn + c) = make_float4(v[0], v[1], v[2], v[3]);
+    else out[j * dn + c] = v[0];
 }
 
 // dst[r][c0 + c] += src[r][c]
@@ -100,34 +109,40 @@ static int relu_mask(const float* g, const float* act, float* out, int64_t n, hi
 }
 
 // ------------------------------------------------------------------------------------ plan
+// Pre-activation gradients (dZ) of EVERY step are kept ([L][rows][width] blocks): the activation-gradient
+// chain of a step reads its predecessor's block, and after the step loop each weight's gradient is ONE
+// batched split-row product over all L steps (12x fewer launches and slab reductions than per step).
 struct BwdPlan {
-    float* dX[2];
-    float* dX0;
-    float* dE[2];
-    float* dE0;
-    float* dP;
-    float* dAGG;
-    float* dZn;
-    float* dCat;     // [max(E ke, N kx)] gradient w.r.t. the concatenated [initial | current] features
-    float* T[2];     // [max(E,N), maxw] scratch for the dZ chain of the MLPs
-    float* gWnode;   // [pw, kx] gradient of the packed node-projection weights, accumulated over steps
-    float* slab;     // split partials of the weight-gradient products (2 groups)
+    float* dX[2];                       // [N, dn] ping-pong: gradient w.r.t. x_s
+    float* dX0;                         // [N, dn] gradient w.r.t. the encoder's node output
+    float* dE0;                         // [E, de]
+    float* dAGG;                        // [N, 2dn]
+    float* dCat;                        // [max(E ke, N kx)] gradient w.r.t. the concatenated [initial | current] features
+    float* dZn;                         // [L][N, dn]
+    float* dP;                          // [L][N, pw]
+    float* dZfl[MPNHIP_MAX_LAYERS];     // flow MLP layer i:   [L][E, out_i]
+    float* dZed[MPNHIP_MAX_LAYERS];     // edge MLP layer i:   [L][E, out_i]  (last layer: the masked dE_s)
+    float* dZcl[MPNHIP_MAX_LAYERS];     // classifier layer i: [L][E, out_i]  (i < n-1; the last one is grad_logits)
+    float* T[2];                        // encoder chain scratch [max(E,N), max encoder width]
+    float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
+    float* slab;                        // split partials of the weight-gradient products (2 groups)
     size_t slab_floats_per_group;
     size_t total;
 };
 
-static int maxw_of(const mpnhip_model& m, const Dims& d) {
+static int enc_maxw(const mpnhip_model& m, const Dims& d) {
     int w = d.dn > d.de ? d.dn : d.de;
-    const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge, &m.edge, &m.flow_in, &m.classifier};
+    const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge};
     for (const mpnhip_mlp* p : all)
         for (int i = 0; i < p->n_layers; ++i) w = p->out_dims[i] > w ? p->out_dims[i] : w;
     return w;
 }
 
-static size_t mlp_slab(const mpnhip_mlp& m, int64_t rows) {
+// slab floats of the weight-gradient products of layers first..n-1 of an MLP (layer 0's k_in given)
+static size_t mlp_slab(const mpnhip_mlp& m, int k_in0, int64_t rows, int nbatch) {
     size_t mx = 0;
     for (int i = 0; i < m.n_layers; ++i) {
-        size_t f = tn_slab_floats(m.out_dims[i], i == 0 ? m.in_dim : m.out_dims[i - 1], rows);
+        size_t f = tn_slab_floats(m.out_dims[i], i == 0 ? k_in0 : m.out_dims[i - 1], rows, nbatch);
         mx = f > mx ? f : mx;
     }
     return mx;
@@ -136,30 +151,34 @@ static size_t mlp_slab(const mpnhip_mlp& m, int64_t rows) {
 static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, void* base, BwdPlan* out) {
     Arena a = {static_cast<char*>(base), 0};
     BwdPlan p = {};
+    const size_t L = d.L > 0 ? d.L : 1;
     for (int i = 0; i < 2; ++i) p.dX[i] = a.f((size_t)N * d.dn);
     p.dX0 = a.f((size_t)N * d.dn);
-    for (int i = 0; i < 2; ++i) p.dE[i] = a.f((size_t)E * d.de);
     p.dE0 = a.f((size_t)E * d.de);
-    p.dP = a.f((size_t)N * d.pw);
     p.dAGG = a.f((size_t)N * 2 * d.dn);
-    p.dZn = a.f((size_t)N * d.dn);
     {
         size_t a1 = (size_t)E * d.ke, a2 = (size_t)N * d.kx;
         p.dCat = a.f(a1 > a2 ? a1 : a2);
     }
+    p.dZn = a.f(L * N * d.dn);
+    p.dP = a.f(L * N * d.pw);
+    for (int i = 0; i < m.flow_in.n_layers; ++i) p.dZfl[i] = a.f(L * E * m.flow_in.out_dims[i]);
+    for (int i = 0; i < m.edge.n_layers; ++i) p.dZed[i] = a.f(L * E * m.edge.out_dims[i]);
+    for (int i = 0; i + 1 < m.classifier.n_layers; ++i) p.dZcl[i] = a.f(L * E * m.classifier.out_dims[i]);
     int64_t rows = E > N ? E : N;
-    int mw = maxw_of(m, d);
+    int mw = enc_maxw(m, d);
     for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
     p.gWnode = a.f((size_t)d.pw * d.kx);
     size_t sl = 0;
     auto upd = [&](size_t f) { sl = f > sl ? f : sl; };
-    upd(mlp_slab(m.enc_node, N));
-    upd(mlp_slab(m.enc_edge, E));
-    upd(mlp_slab(m.edge, E));
-    upd(mlp_slab(m.flow_in, E));
-    upd(mlp_slab(m.classifier, E));
-    upd(tn_slab_floats(d.dn, 2 * d.dn, N));
-    upd(tn_slab_floats(d.pw, d.kx, N));
+    // exactly the products mpnhip_backward launches (the slab size depends on the shape through tn_plan)
+    upd(mlp_slab(m.enc_node, m.enc_node.in_dim, N, 1));
+    upd(mlp_slab(m.enc_edge, m.enc_edge.in_dim, E, 1));
+    upd(mlp_slab(m.edge, d.ke, E, (int)L));
+    upd(mlp_slab(m.flow_in, d.de, E, (int)L));
+    upd(mlp_slab(m.classifier, d.de, E, (int)L));
+    upd(tn_slab_floats(d.dn, 2 * d.dn, N, (int)L));
+    upd(tn_slab_floats(d.pw, d.kx, N, (int)L));
     p.slab_floats_per_group = sl;
     p.slab = a.f(2 * sl);
     p.total = a.off;
@@ -173,26 +192,35 @@ struct RowRange {
     const int* end;
 };
 
-// dW += dZ^T H (+ bias) for one or two groups
-static int weight_grad(const BwdPlan& p, int ngroups, const float* const dZ[2], int64_t ldz, const int* dz_idx,
-                       const float* H, int64_t ldh, const float* H2, int64_t ldh2, int csplit, const int* h_idx,
-                       int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2], const RowRange rr[2],
-                       int64_t rows, hipStream_t s) {
+struct Operand {        // one side of a (batched) weight-gradient product
+    const float* p;
+    int64_t ld;
+    int64_t bstride;    // floats between consecutive batches (0: same block every batch)
+};
+
+// dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
+static int weight_grad(const BwdPlan& p, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
+                       const int* h_idx, int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2],
+                       const RowRange rr[2], int64_t rows, int nbatch, hipStream_t s) {
     TnArgs a = {};
     a.ngroups = ngroups;
     a.n_out = n_out;
     a.k_in = k_in;
-    a.csplit = H2 ? csplit : k_in;
+    a.csplit = H2.p ? csplit : k_in;
     a.m_upper = rows;
+    a.nbatch = nbatch;
     for (int q = 0; q < ngroups; ++q) {
         TnGroup& g = a.g[q];
-        g.dZ = dZ[q];
-        g.ldz = ldz;
+        g.dZ = dZ.p;
+        g.ldz = dZ.ld;
+        g.z_bstride = dZ.bstride;
         g.dz_idx = dz_idx;
-        g.H = H;
-        g.ldh = ldh;
-        g.H2 = H2;
-        g.ldh2 = ldh2;
+        g.H = H.p;
+        g.ldh = H.ld;
+        g.h_bstride = H.bstride;
+        g.H2 = H2.p;
+        g.ldh2 = H2.ld;
+        g.h2_bstride = H2.bstride;
         g.h_idx = h_idx;
         g.row_begin = rr ? rr[q].begin : nullptr;
         g.row_end = rr ? rr[q].end : nullptr;
@@ -206,9 +234,9 @@ static int weight_grad(const BwdPlan& p, int ngroups, const float* const dZ[2], 
 }
 
 // C = mask( A B (+ C) ) with B given as weight rows: B[k][n] = W[k * ldw + n]  (dH = dZ W)
-static int act_grad(int ngroups, const float* const A[2], int64_t lda, const int* a_idx, const float* const W[2],
-                    int64_t ldw, int K, int N, float* C, int64_t ldc, const int* c_idx, const float* mask, int64_t ldmask,
-                    int accumulate, const RowRange rr[2], int64_t rows, hipStream_t s) {
+static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, const float* const W[2], int64_t ldw, int K,
+                    int N, float* C, int64_t ldc, const int* c_idx, const float* mask, int64_t ldmask, int accumulate,
+                    const RowRange rr[2], int64_t rows, hipStream_t s) {
     GemmArgs a = {};
     a.ngroups = ngroups;
     a.N = N;
@@ -220,7 +248,7 @@ static int act_grad(int ngroups, const float* const A[2], int64_t lda, const int
     for (int q = 0; q < ngroups; ++q) {
         GemmGroup& g = a.g[q];
         init_group(g);
-        g.A = A[q];
+        g.A = A;
         g.lda = lda;
         g.a_idx = a_idx;
         g.B = W[q];
@@ -237,24 +265,46 @@ static int act_grad(int ngroups, const float* const A[2], int64_t lda, const int
     return launch_gemm(a, A_KCONTIG, B_NCONTIG, s);
 }
 
-// Backward through layers n-1 .. 1 of an MLP (optionally the two direction-specific flow MLPs).
-// On entry *dz holds dZ of the LAST layer (pre-activation gradient) in buffer `cur_buf`; on exit it
-// holds dZ of layer 0 [rows, out_dims[0]].  hidden[i] = saved post-activation output of layer i.
-static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, const mpnhip_mlp* m1, float* const* hidden,
-                             const float** dz, int* cur_buf, const RowRange* rr, int64_t rows, hipStream_t s) {
+// dZ_{i-1} = (dZ_i W_i) (.) [H_{i-1} > 0] for i = n-1 .. 1.  dz[i] / hidden[i]: this step's blocks.
+static int mlp_chain_backward(const mpnhip_mlp& m0, const mpnhip_mlp* m1, float* const* dz, float* const* hidden,
+                              const RowRange* rr, int64_t rows, hipStream_t s) {
     const int ng = m1 ? 2 : 1;
     for (int i = m0.n_layers - 1; i >= 1; --i) {
         const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
-        const float* dzq[2] = {*dz, *dz};
+        const float* Wq[2] = {m0.weight[i], m1 ? m1->weight[i] : nullptr};
+        MPN_TRY(act_grad(ng, dz[i], n_out, nullptr, Wq, k_in, n_out, k_in, dz[i - 1], k_in, nullptr,
+                         k_in != 1 ? hidden[i - 1] : nullptr, k_in, 0, rr, rows, s));
+    }
+    return MPNHIP_OK;
+}
+
+// batched weight gradients of layers >= 1 of an MLP whose dZ / hidden blocks repeat every step
+static int mlp_weight_grads(const BwdPlan& p, const mpnhip_mlp& m0, const mpnhip_mlp* m1, float* const* dz_all,
+                            float* const* hidden0, int64_t hidden_bstride, const RowRange* rr, int64_t rows, int nbatch,
+                            hipStream_t s) {
+    for (int i = m0.n_layers - 1; i >= 1; --i) {
+        const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
         float* gw[2] = {m0.grad_weight[i], m1 ? m1->grad_weight[i] : nullptr};
         float* gb[2] = {m0.grad_bias[i], m1 ? m1->grad_bias[i] : nullptr};
-        MPN_TRY(weight_grad(p, ng, dzq, n_out, nullptr, hidden[i - 1], k_in, nullptr, 0, k_in, nullptr, n_out, k_in, gw,
-                            k_in, gb, rr, rows, s));
-        const float* Wq[2] = {m0.weight[i], m1 ? m1->weight[i] : nullptr};
+        MPN_TRY(weight_grad(p, m1 ? 2 : 1, {dz_all[i], n_out, rows * n_out}, nullptr, {hidden0[i - 1], k_in, hidden_bstride},
+                            {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, rr, rows, nbatch, s));
+    }
+    return MPNHIP_OK;
+}
+
+// encoder-style chain with ping-pong scratch (one batch): returns dZ of layer 0 in *dz
+static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, float* const* hidden, const float** dz, int* cur_buf,
+                             int64_t rows, hipStream_t s) {
+    for (int i = m0.n_layers - 1; i >= 1; --i) {
+        const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
+        float* gw[2] = {m0.grad_weight[i], nullptr};
+        float* gb[2] = {m0.grad_bias[i], nullptr};
+        MPN_TRY(weight_grad(p, 1, {*dz, n_out, 0}, nullptr, {hidden[i - 1], k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out,
+                            k_in, gw, k_in, gb, nullptr, rows, 1, s));
+        const float* Wq[2] = {m0.weight[i], nullptr};
         float* dst = p.T[*cur_buf ^ 1];
-        const bool relu_prev = k_in != 1;
-        MPN_TRY(act_grad(ng, dzq, n_out, nullptr, Wq, k_in, n_out, k_in, dst, k_in, nullptr,
-                         relu_prev ? hidden[i - 1] : nullptr, k_in, 0, rr, rows, s));
+        MPN_TRY(act_grad(1, *dz, n_out, nullptr, Wq, k_in, n_out, k_in, dst, k_in, nullptr,
+                         k_in != 1 ? hidden[i - 1] : nullptr, k_in, 0, nullptr, rows, s));
         *cur_buf ^= 1;
         *dz = dst;
     }
@@ -304,180 +354,203 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     }
     GraphView g;
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
-    const int he = d.he, hn = d.hn, dn = d.dn, de = d.de, kx = d.kx, ke = d.ke, pw = d.pw;
+    const int he = d.he, hn = d.hn, dn = d.dn, de = d.de, kx = d.kx, ke = d.ke, pw = d.pw, L = d.L;
     const size_t xs = (size_t)N * dn, es = (size_t)E * de;
     const RowRange dir_rr[2] = {{nullptr, g.header + 4}, {g.header + 4, g.header + 5}};
+    const mpnhip_mlp& cls = m.classifier;
+    const int ne = m.edge.n_layers, nfl = m.flow_in.n_layers, nc = cls.n_layers;
+    const int64_t sstride = (int64_t)(f.step_stride_bytes / sizeof(float));  // floats between two steps' saved activations
 
     // ---- seeds ----------------------------------------------------------------------------------
-    int cx = 0, ce = 0;  // which of dX[2] / dE[2] holds the gradient w.r.t. (x_s, e_s)
+    int cx = 0;
     if (grad_x_out) MPN_HIP(hipMemcpyAsync(p.dX[0], grad_x_out, xs * 4, hipMemcpyDeviceToDevice, s));
     else if (xs) MPN_HIP(hipMemsetAsync(p.dX[0], 0, xs * 4, s));
-    if (grad_e_out && es) {
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, grad_e_out, g.perm, p.dE[0], E, de);
-        MPN_LAUNCH_CHECK();
-    } else if (es) {
-        MPN_HIP(hipMemsetAsync(p.dE[0], 0, es * 4, s));
-    }
+    // the gradient w.r.t. e_s lives in the LAST edge-layer dZ block of step s (it becomes that dZ once masked)
+    float* dE_last = L > 0 ? p.dZed[ne - 1] + (size_t)(L - 1) * es : p.dE0;
     if (xs) MPN_HIP(hipMemsetAsync(p.dX0, 0, xs * 4, s));
     if (es) MPN_HIP(hipMemsetAsync(p.dE0, 0, es * 4, s));
+    if (grad_e_out && es) {
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, grad_e_out, g.perm, dE_last, E, de);
+        MPN_LAUNCH_CHECK();
+    } else if (es && L > 0) {
+        MPN_HIP(hipMemsetAsync(dE_last, 0, es * 4, s));
+    }
     MPN_HIP(hipMemsetAsync(p.gWnode, 0, (size_t)pw * kx * 4, s));
 
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
-    const mpnhip_mlp& cls = m.classifier;
 
-    // classifier backward on edge features `ef` (sorted order) for step-row `lrow` of grad_logits;
-    // accumulates into dEdst and finally applies `mask` (ReLU of the producing edge layer)
-    auto classifier_backward = [&](const float* ef, float* const* HC, const float* dlog, float* dEdst, const float* mask) -> int {
+    // activation-gradient chain of the classifier for one step: dz chain blocks in dzc[], final product
+    // accumulated into dEdst and masked by `mask` (ReLU of the edge layer that produced ef)
+    auto classifier_chain = [&](float* const* HC, float* const* dzc, const float* dlog, float* dEdst, const float* mask) -> int {
         if (E == 0) return MPNHIP_OK;
-        const float* dz = dlog;  // [E, 1] in ORIGINAL order -> gathered through perm
-        int64_t ldz = 1;
-        const int* zidx = g.perm;
-        int cur = 0;
-        for (int i = cls.n_layers - 1; i >= 0; --i) {
+        for (int i = nc - 1; i >= 0; --i) {
             const int n_out = cls.out_dims[i], k_in = i == 0 ? de : cls.out_dims[i - 1];
-            const float* Hin = i == 0 ? ef : HC[i - 1];
-            const float* dzq[2] = {dz, dz};
-            float* gw[2] = {cls.grad_weight[i], nullptr};
-            float* gb[2] = {cls.grad_bias[i], nullptr};
-            MPN_TRY(weight_grad(p, 1, dzq, ldz, zidx, Hin, k_in, nullptr, 0, k_in, nullptr, n_out, k_in, gw, k_in, gb,
-                                nullptr, E, s));
+            const bool top = i == nc - 1;  // dZ of the last layer is grad_logits, [E, 1] in ORIGINAL order
+            const float* A = top ? dlog : dzc[i];
             const float* Wq[2] = {cls.weight[i], nullptr};
-            if (i == 0) {
-                MPN_TRY(act_grad(1, dzq, ldz, zidx, Wq, k_in, n_out, k_in, dEdst, de, nullptr, mask, de, 1, nullptr, E, s));
-            } else {
-                float* dst = p.T[cur];
-                const bool relu_prev = k_in != 1;
-                MPN_TRY(act_grad(1, dzq, ldz, zidx, Wq, k_in, n_out, k_in, dst, k_in, nullptr,
-                                 relu_prev ? HC[i - 1] : nullptr, k_in, 0, nullptr, E, s));
-                dz = dst;
-                ldz = k_in;
-                zidx = nullptr;
-                cur ^= 1;
-            }
+            if (i == 0)
+                MPN_TRY(act_grad(1, A, top ? 1 : n_out, top ? g.perm : nullptr, Wq, k_in, n_out, k_in, dEdst, de, nullptr, mask, de,
+                                 1, nullptr, E, s));
+            else
+                MPN_TRY(act_grad(1, A, top ? 1 : n_out, top ? g.perm : nullptr, Wq, k_in, n_out, k_in, dzc[i - 1], k_in, nullptr,
+                                 k_in != 1 ? HC[i - 1] : nullptr, k_in, 0, nullptr, E, s));
         }
         return MPNHIP_OK;
     };
 
-    for (int step = d.L; step >= 1; --step) {
-        const StepBufs b = step_at(f, step - 1);
+    for (int step = L; step >= 1; --step) {
+        const int b_ = step - 1;  // batch (block) index of this step
+        const StepBufs b = step_at(f, b_);
         const float* x_s = f.x_hist + xs * step;
         const float* e_s = f.e_hist + es * step;
-        const float* x_p = f.x_hist + xs * (step - 1);
-        const float* e_p = f.e_hist + es * (step - 1);
         float* dXc = p.dX[cx];
-        float* dEc = p.dE[ce];
+        float* dZn = p.dZn + (size_t)b_ * xs;
+        float* dP = p.dP + (size_t)b_ * N * pw;
+        float* dzfl[MPNHIP_MAX_LAYERS];
+        float* dzed[MPNHIP_MAX_LAYERS];
+        float* dzcl[MPNHIP_MAX_LAYERS];
+        for (int i = 0; i < nfl; ++i) dzfl[i] = p.dZfl[i] + (size_t)b_ * E * m.flow_in.out_dims[i];
+        for (int i = 0; i < ne; ++i) dzed[i] = p.dZed[i] + (size_t)b_ * E * m.edge.out_dims[i];
+        for (int i = 0; i + 1 < nc; ++i) dzcl[i] = p.dZcl[i] + (size_t)b_ * E * cls.out_dims[i];
+        float* dEc = dzed[ne - 1];  // gradient w.r.t. e_s (seeded by the later step / the caller)
 
         // ---- A. node update  x_s = relu(AGG W^T + b)  (mpn.py:97-99) ---------------------------
-        MPN_TRY(relu_mask(dXc, x_s, p.dZn, (int64_t)xs, s));
+        MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s));
         {
-            const float* dzq[2] = {p.dZn, nullptr};
-            float* gw[2] = {m.node.grad_weight[0], nullptr};
-            float* gb[2] = {m.node.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, 1, dzq, dn, nullptr, b.AGG, 2 * dn, nullptr, 0, 2 * dn, nullptr, dn, 2 * dn, gw, 2 * dn,
-                                gb, nullptr, N, s));
             const float* Wq[2] = {m.node.weight[0], nullptr};
-            MPN_TRY(act_grad(1, dzq, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
+            MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
         }
         if (E > 0) {
             // ---- B. aggregation backward + ReLU of the last flow layer ---------------------------
-            float* dZM = p.T[0];
             {
-                int64_t tot = E * dn;
+                int64_t tot = E * (dn / 4 > 0 && dn % 4 == 0 ? dn / 4 : dn);
                 hipLaunchKernelGGL(k_agg_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.dAGG, b.M, b.ARG,
-                                   g.srow, g.seg_ptr, g.header, (int)N, E, dn, m.agg, dn != 1 ? 1 : 0, dZM);
+                                   g.srow, g.seg_ptr, g.header, (int)N, E, dn, m.agg, dn != 1 ? 1 : 0, dzfl[nfl - 1]);
                 MPN_LAUNCH_CHECK();
             }
             // ---- C. flow MLPs (both directions grouped) -------------------------------------------
-            const float* dz = dZM;
-            int cur = 0;
-            MPN_TRY(mlp_tail_backward(p, m.flow_out, &m.flow_in, b.HF, &dz, &cur, dir_rr, E, s));
+            MPN_TRY(mlp_chain_backward(m.flow_out, &m.flow_in, dzfl, b.HF, dir_rr, E, s));
             {
-                // layer 0:  Z = e_s Wfe^T + Pf[col]
-                const float* dzq[2] = {dz, dz};
-                float* gw[2] = {m.flow_out.grad_weight[0] + kx, m.flow_in.grad_weight[0] + kx};
-                float* gb[2] = {m.flow_out.grad_bias[0], m.flow_in.grad_bias[0]};
-                MPN_TRY(weight_grad(p, 2, dzq, hn, nullptr, e_s, de, nullptr, 0, de, nullptr, hn, de, gw, m.flow_out.in_dim,
-                                    gb, dir_rr, E, s));
-                // dPf[n] = sum over the direction's edges with col == n   (index_put_ of x[flow_col], mpn.py:87,93)
-                MPN_TRY(segment_reduce_csr2(dz, hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, p.dP, pw, (int)N, 2 * he, 2 * he + hn, s));
+                // layer 0:  Z = e_s Wfe^T + Pf[col];  dPf[n] = sum over the direction's edges with col == n
+                // (index_put_ of x[flow_col], mpn.py:87,93)
+                MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s));
                 const float* Wq[2] = {m.flow_out.weight[0] + kx, m.flow_in.weight[0] + kx};
-                MPN_TRY(act_grad(2, dzq, hn, nullptr, Wq, m.flow_out.in_dim, hn, de, dEc, de, nullptr, nullptr, 0, 1, dir_rr, E, s));
+                MPN_TRY(act_grad(2, dzfl[0], hn, nullptr, Wq, m.flow_out.in_dim, hn, de, dEc, de, nullptr, nullptr, 0, 1, dir_rr, E, s));
             }
             // ---- D. classifier (mpn.py:377 -> :114); also applies the ReLU mask of e_s -------------
-            MPN_TRY(classifier_backward(e_s, b.HC, grad_logits + (size_t)(step - 1) * E, dEc, de != 1 ? e_s : nullptr));
+            MPN_TRY(classifier_chain(b.HC, dzcl, grad_logits + (size_t)b_ * E, dEc, de != 1 ? e_s : nullptr));
             // ---- E. edge MLP (EdgeModel, mpn.py:67-69) ----------------------------------------------
-            dz = dEc;
-            cur = 0;  // T[0] (dZM) is dead by now; the chain ping-pongs T[1], T[0], ...
-            MPN_TRY(mlp_tail_backward(p, m.edge, nullptr, b.HE, &dz, &cur, nullptr, E, s));
+            MPN_TRY(mlp_chain_backward(m.edge, nullptr, dzed, b.HE, nullptr, E, s));
             {
-                const float* dzq[2] = {dz, nullptr};
-                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
-                float* gb[2] = {m.edge.grad_bias[0], nullptr};
-                const bool two = d.ef == 2;
-                MPN_TRY(weight_grad(p, 1, dzq, he, nullptr, two ? e0 : e_p, de, two ? e_p : nullptr, de, de, nullptr, he, ke,
-                                    gw, m.edge.in_dim, gb, nullptr, E, s));
                 // dPr / dPc: index_put_(accumulate) of x[row], x[col] (mpn.py:69)
-                MPN_TRY(segment_reduce_csr2(dz, he, g.rperm, g.rseg_ptr, (int)N, he, p.dP, pw, (int)N, 0, 0, s));
-                MPN_TRY(segment_reduce_csr2(dz, he, g.cperm_all, g.cseg_all, (int)N, he, p.dP, pw, (int)N, he, he, s));
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s));
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s));
                 // gradient w.r.t. [e0 | e_{s-1}]: one product, then split (e_0 IS e0 at step 1)
-                float* dEp = p.dE[ce ^ 1];
                 const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
-                MPN_TRY(act_grad(1, dzq, he, nullptr, Wa, m.edge.in_dim, he, ke, p.dCat, ke, nullptr, nullptr, 0, 0, nullptr, E, s));
-                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, p.dCat, E, de, two ? 1 : 0,
-                                   p.dE0, step == 1 ? p.dE0 : dEp, step == 1 ? 1 : 0);
+                MPN_TRY(act_grad(1, dzed[0], he, nullptr, Wa, m.edge.in_dim, he, ke, p.dCat, ke, nullptr, nullptr, 0, 0, nullptr, E, s));
+                float* dEp = step == 1 ? p.dE0 : p.dZed[ne - 1] + (size_t)(b_ - 1) * es;
+                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, p.dCat, E, de, d.ef == 2 ? 1 : 0,
+                                   p.dE0, dEp, step == 1 ? 1 : 0);
                 MPN_LAUNCH_CHECK();
             }
         } else {
-            MPN_HIP(hipMemsetAsync(p.dP, 0, (size_t)N * pw * 4, s));
+            MPN_HIP(hipMemsetAsync(dP, 0, (size_t)N * pw * 4, s));
         }
         // ---- F. per-node projections  P = [x0 | x_{s-1}] Wnode^T -----------------------------------
         {
-            const float* dzq[2] = {p.dP, nullptr};
-            float* gw[2] = {p.gWnode, nullptr};
-            const bool two = d.nf == 2;
-            MPN_TRY(weight_grad(p, 1, dzq, pw, nullptr, two ? x0 : x_p, dn, two ? x_p : nullptr, dn, dn, nullptr, pw, kx, gw,
-                                kx, nullptr, nullptr, N, s));
             float* dXp = p.dX[cx ^ 1];
             const float* Wa[2] = {f.Wnode, nullptr};
-            MPN_TRY(act_grad(1, dzq, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
+            MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
             if (xs) {
-                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dCat, N, dn, two ? 1 : 0,
+                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dCat, N, dn, d.nf == 2 ? 1 : 0,
                                    p.dX0, step == 1 ? p.dX0 : dXp, step == 1 ? 1 : 0);
                 MPN_LAUNCH_CHECK();
             }
         }
         cx ^= 1;
-        ce ^= 1;
     }
 
-    if (d.L == 0) {
+    if (L > 0) {
+        // ---- weight gradients of the message-passing modules: one batched product per weight ---------
+        {   // node update Linear
+            float* gw[2] = {m.node.grad_weight[0], nullptr};
+            float* gb[2] = {m.node.grad_bias[0], nullptr};
+            MPN_TRY(weight_grad(p, 1, {p.dZn, dn, (int64_t)xs}, nullptr, {f.step0.AGG, 2 * dn, sstride}, {nullptr, 0, 0}, 2 * dn,
+                                nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, L, s));
+        }
+        if (E > 0) {
+            MPN_TRY(mlp_weight_grads(p, m.flow_out, &m.flow_in, p.dZfl, f.step0.HF, sstride, dir_rr, E, L, s));
+            {   // flow layer 0: e-part columns [kx, kx + de) and the bias (folded into P in the forward)
+                float* gw[2] = {m.flow_out.grad_weight[0] + kx, m.flow_in.grad_weight[0] + kx};
+                float* gb[2] = {m.flow_out.grad_bias[0], m.flow_in.grad_bias[0]};
+                MPN_TRY(weight_grad(p, 2, {p.dZfl[0], hn, (int64_t)E * hn}, nullptr, {f.e_hist + es, de, (int64_t)es}, {nullptr, 0, 0},
+                                    de, nullptr, hn, de, gw, m.flow_out.in_dim, gb, dir_rr, E, L, s));
+            }
+            // classifier: dZ of the last layer is grad_logits ([L, E], original order -> perm)
+            for (int i = nc - 1; i >= 0; --i) {
+                const int n_out = cls.out_dims[i], k_in = i == 0 ? de : cls.out_dims[i - 1];
+                const bool top = i == nc - 1;
+                float* gw[2] = {cls.grad_weight[i], nullptr};
+                float* gb[2] = {cls.grad_bias[i], nullptr};
+                Operand dz = top ? Operand{grad_logits, 1, (int64_t)E} : Operand{p.dZcl[i], n_out, (int64_t)E * n_out};
+                Operand h = i == 0 ? Operand{f.e_hist + es, de, (int64_t)es} : Operand{f.step0.HC[i - 1], k_in, sstride};
+                MPN_TRY(weight_grad(p, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb,
+                                    nullptr, E, L, s));
+            }
+            MPN_TRY(mlp_weight_grads(p, m.edge, nullptr, p.dZed, f.step0.HE, sstride, nullptr, E, L, s));
+            {   // edge layer 0: e-part columns [2kx, 2kx + ke) = [e0 | e_{s-1}], and the bias
+                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
+                float* gb[2] = {m.edge.grad_bias[0], nullptr};
+                const bool two = d.ef == 2;
+                Operand h1 = two ? Operand{e0, de, 0} : Operand{f.e_hist, de, (int64_t)es};
+                Operand h2 = two ? Operand{f.e_hist, de, (int64_t)es} : Operand{nullptr, 0, 0};
+                MPN_TRY(weight_grad(p, 1, {p.dZed[0], he, (int64_t)E * he}, nullptr, h1, h2, de, nullptr, he, ke, gw, m.edge.in_dim,
+                                    gb, nullptr, E, L, s));
+            }
+        }
+        {   // per-node projections (packed [W1r; W1c; Wfo_x; Wfi_x]); their biases were handled above
+            float* gw[2] = {p.gWnode, nullptr};
+            const bool two = d.nf == 2;
+            Operand h1 = two ? Operand{x0, dn, 0} : Operand{f.x_hist, dn, (int64_t)xs};
+            Operand h2 = two ? Operand{f.x_hist, dn, (int64_t)xs} : Operand{nullptr, 0, 0};
+            MPN_TRY(weight_grad(p, 1, {p.dP, pw, (int64_t)N * pw}, nullptr, h1, h2, dn, nullptr, pw, kx, gw, kx, nullptr, nullptr, N,
+                                L, s));
+            struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
+                {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
+                {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
+                {m.flow_out.grad_weight[0], m.flow_out.in_dim, 0, 2 * he, hn},
+                {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
+            for (auto& q : parts) {
+                int64_t tot = (int64_t)q.rows * kx;
+                hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.gWnode + (size_t)q.r0 * kx,
+                                   kx, q.dst, q.ld, q.c0, q.rows, kx);
+                MPN_LAUNCH_CHECK();
+            }
+        }
+    } else {
         // mpn.py:387-389: only the classifier sits between the encoder output and the logits
         StepBufs b = f.step0;
-        MPN_TRY(classifier_backward(e0, b.HC, grad_logits, p.dE0, nullptr));
+        float* dzc[MPNHIP_MAX_LAYERS];
+        for (int i = 0; i + 1 < nc; ++i) dzc[i] = p.dZcl[i];
+        MPN_TRY(classifier_chain(b.HC, dzc, grad_logits, p.dE0, nullptr));
+        for (int i = nc - 1; i >= 0 && E > 0; --i) {
+            const int n_out = cls.out_dims[i], k_in = i == 0 ? de : cls.out_dims[i - 1];
+            const bool top = i == nc - 1;
+            float* gw[2] = {cls.grad_weight[i], nullptr};
+            float* gb[2] = {cls.grad_bias[i], nullptr};
+            Operand dz = top ? Operand{grad_logits, 1, 0} : Operand{p.dZcl[i], n_out, 0};
+            Operand h = i == 0 ? Operand{e0, de, 0} : Operand{b.HC[i - 1], k_in, 0};
+            MPN_TRY(weight_grad(p, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, nullptr,
+                                E, 1, s));
+        }
         // incoming gradients of the final latents ARE gradients of the encoder outputs
         if (xs) {
             hipLaunchKernelGGL(k_add_block, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dX[0], dn, p.dX0, dn, 0, (int)N, dn);
             MPN_LAUNCH_CHECK();
         }
-        if (es) {
-            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, p.dE[0], de, p.dE0, de, 0, (int)E, de);
-            MPN_LAUNCH_CHECK();
-        }
-    }
-
-    // ---- unpack the packed node-projection weight gradient into the four first-layer blocks --------
-    if (d.L > 0) {
-        struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
-            {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
-            {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
-            {m.flow_out.grad_weight[0], m.flow_out.in_dim, 0, 2 * he, hn},
-            {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
-        for (auto& q : parts) {
-            int64_t tot = (int64_t)q.rows * kx;
-            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.gWnode + (size_t)q.r0 * kx,
-                               kx, q.dst, q.ld, q.c0, q.rows, kx);
-            MPN_LAUNCH_CHECK();
+        if (grad_e_out && es) {
+            // dE0 was seeded with the gathered grad_e_out (dE_last aliases dE0 when L == 0): nothing to add
         }
     }
 
@@ -496,15 +569,14 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             } else {
                 cur = 1;  // keep T[0] free: the chain below writes T[cur ^ 1] first
             }
-            MPN_TRY(mlp_tail_backward(p, en, nullptr, hid, &dz, &cur, nullptr, N, s));
-            const float* dzq[2] = {dz, nullptr};
+            MPN_TRY(mlp_tail_backward(p, en, hid, &dz, &cur, N, s));
             float* gw[2] = {en.grad_weight[0], nullptr};
             float* gb[2] = {en.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, 1, dzq, en.out_dims[0], nullptr, x, en.in_dim, nullptr, 0, en.in_dim, nullptr, en.out_dims[0],
-                                en.in_dim, gw, en.in_dim, gb, nullptr, N, s));
+            MPN_TRY(weight_grad(p, 1, {dz, en.out_dims[0], 0}, nullptr, {x, en.in_dim, 0}, {nullptr, 0, 0}, en.in_dim, nullptr,
+                                en.out_dims[0], en.in_dim, gw, en.in_dim, gb, nullptr, N, 1, s));
             if (grad_x) {
                 const float* Wq[2] = {en.weight[0], nullptr};
-                MPN_TRY(act_grad(1, dzq, en.out_dims[0], nullptr, Wq, en.in_dim, en.out_dims[0], en.in_dim, grad_x, en.in_dim,
+                MPN_TRY(act_grad(1, dz, en.out_dims[0], nullptr, Wq, en.in_dim, en.out_dims[0], en.in_dim, grad_x, en.in_dim,
                                  nullptr, nullptr, 0, 0, nullptr, N, s));
             }
         }
@@ -523,20 +595,17 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             } else {
                 cur = 1;
             }
-            MPN_TRY(mlp_tail_backward(p, ee, nullptr, hid, &dz, &cur, nullptr, E, s));
-            const float* dzq[2] = {dz, nullptr};
+            MPN_TRY(mlp_tail_backward(p, ee, hid, &dz, &cur, E, s));
             float* gw[2] = {ee.grad_weight[0], nullptr};
             float* gb[2] = {ee.grad_bias[0], nullptr};
             // layer 0 read edge_attr through the sort permutation
-            MPN_TRY(weight_grad(p, 1, dzq, ee.out_dims[0], nullptr, edge_attr, ee.in_dim, nullptr, 0, ee.in_dim, g.perm,
-                                ee.out_dims[0], ee.in_dim, gw, ee.in_dim, gb, nullptr, E, s));
+            MPN_TRY(weight_grad(p, 1, {dz, ee.out_dims[0], 0}, nullptr, {edge_attr, ee.in_dim, 0}, {nullptr, 0, 0}, ee.in_dim,
+                                g.perm, ee.out_dims[0], ee.in_dim, gw, ee.in_dim, gb, nullptr, E, 1, s));
             if (grad_edge_attr) {
                 const float* Wq[2] = {ee.weight[0], nullptr};
-                MPN_TRY(act_grad(1, dzq, ee.out_dims[0], nullptr, Wq, ee.in_dim, ee.out_dims[0], ee.in_dim, grad_edge_attr,
+                MPN_TRY(act_grad(1, dz, ee.out_dims[0], nullptr, Wq, ee.in_dim, ee.out_dims[0], ee.in_dim, grad_edge_attr,
                                  ee.in_dim, g.perm, nullptr, 0, 0, nullptr, E, s));
             }
-        } else if (grad_edge_attr) {
-            // nothing to write
         }
     }
     return MPNHIP_OK;

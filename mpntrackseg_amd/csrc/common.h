@@ -100,16 +100,20 @@ struct TnGroup {
     float* grad_w;         // += ; leading dim ldw (may point into a wider matrix)
     float* grad_b;         // += ; may be nullptr
     int64_t ldz, ldh, ldh2, ldw, m_static;
+    // batched form (all L message-passing steps in one product): batch b reads dZ + b * z_bstride etc.
+    // (a stride of 0 = the same block every step, e.g. the re-attached initial features)
+    int64_t z_bstride, h_bstride, h2_bstride;
 };
 struct TnArgs {
     TnGroup g[2];
     int ngroups;
     int n_out, k_in, csplit;
-    int64_t m_upper;
-    int chunk, nsplit;     // filled by tn_plan
+    int64_t m_upper;       // upper bound of the rows of ONE batch
+    int nbatch;            // >= 1
+    int chunk, nsplit;     // filled by tn_plan: rows per chunk, chunks per batch
 };
 void tn_plan(TnArgs& a);
-size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper);
+size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);
 int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 
 // Convenience: y = act(x W^T + b)

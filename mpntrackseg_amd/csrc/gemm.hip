@@ -26,6 +26,8 @@
 // halves of the edge / flow MLP's first layer are computed once per NODE and added per edge here,
 // instead of gathering [E, 4dn] rows and multiplying them per edge as the reference does
 // (mpn.py:69,87,93).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mpnhip {
@@ -134,48 +136,49 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
     float4 a_reg[A_F4], b_reg[B_F4];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // Issue the global loads of K step kt; nothing here consumes the results (the zero-select for the K tail
+    // happens in store_tile), so the loads stay in flight across the MFMA phase of the previous step.
     auto load_tile = [&](int kt) {
         const int k = kt * BK + ld_k4;
-        const bool k_ok = k < K;                 // K % 4 == 0: a float4 is entirely in or out
-        const int kc = k_ok ? k : 0;
+        const int kc = k < K ? k : 0;
         const bool seg2 = kc >= ksplit;
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) {
-            a_reg[j] = keep4(k_ok, ld4((seg2 ? A2base : Abase) + (seg2 ? a_o2[j] : a_o1[j]) + kc));
-        }
+        for (int j = 0; j < A_F4; ++j) a_reg[j] = ld4((seg2 ? A2base : Abase) + (seg2 ? a_o2[j] : a_o1[j]) + kc);
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             if (BLAY == B_KCONTIG) {
-                b_reg[j] = keep4(k_ok, ld4(Bbase + b_o[j] + kc));
+                b_reg[j] = ld4(Bbase + b_o[j] + kc);
             } else {
-                int kk = kt * BK + b_k[j];
-                bool ok = kk < K;
-                b_reg[j] = keep4(ok, ld4(Bbase + b_o[j] + (ok ? kk : 0) * (int)G.ldb));
+                const int kk = kt * BK + b_k[j];
+                b_reg[j] = ld4(Bbase + b_o[j] + (kk < K ? kk : 0) * (int)G.ldb);
             }
         }
     };
 
-    auto store_tile = [&]() {
+    auto store_tile = [&](int kt) {
+        const bool k_ok = kt * BK + ld_k4 < K;   // K % 4 == 0: a float4 is entirely in or out
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
-            int r = ld_r + 32 * j;
-            As[(ld_k4 + 0) * PA + r] = a_reg[j].x;
-            As[(ld_k4 + 1) * PA + r] = a_reg[j].y;
-            As[(ld_k4 + 2) * PA + r] = a_reg[j].z;
-            As[(ld_k4 + 3) * PA + r] = a_reg[j].w;
+            const int r = ld_r + 32 * j;
+            const float4 v = keep4(k_ok, a_reg[j]);
+            As[(ld_k4 + 0) * PA + r] = v.x;
+            As[(ld_k4 + 1) * PA + r] = v.y;
+            As[(ld_k4 + 2) * PA + r] = v.z;
+            As[(ld_k4 + 3) * PA + r] = v.w;
         }
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             if (BLAY == B_KCONTIG) {
-                int r = ld_r + 32 * j;
-                Bs[(ld_k4 + 0) * PB + r] = b_reg[j].x;
-                Bs[(ld_k4 + 1) * PB + r] = b_reg[j].y;
-                Bs[(ld_k4 + 2) * PB + r] = b_reg[j].z;
-                Bs[(ld_k4 + 3) * PB + r] = b_reg[j].w;
+                const int r = ld_r + 32 * j;
+                const float4 v = keep4(k_ok, b_reg[j]);
+                Bs[(ld_k4 + 0) * PB + r] = v.x;
+                Bs[(ld_k4 + 1) * PB + r] = v.y;
+                Bs[(ld_k4 + 2) * PB + r] = v.z;
+                Bs[(ld_k4 + 3) * PB + r] = v.w;
             } else {
-                int f = tid + NTHREADS * j;
-                int kr = f / (BN / 4), n4 = f % (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[kr * PB + n4 * 4]) = b_reg[j];
+                const int f = tid + NTHREADS * j;
+                const int kr = f / (BN / 4), n4 = f % (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[kr * PB + n4 * 4]) = keep4(kt * BK + b_k[j] < K, b_reg[j]);
             }
         }
     };
@@ -188,20 +191,35 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
 
     const int nk = (K + BK - 1) / BK;
     load_tile(0);
-    const int a_base = wm * 32 + li;
-    const int b_base = wn * 32 * TN + li;
+    const float* a_ptr = As + lh * PA + wm * 32 + li;
+    const float* b_ptr = Bs + lh * PB + wn * 32 * TN + li;
     for (int kt = 0; kt < nk; ++kt) {
-        store_tile();
+        store_tile(kt);
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        // operand fetch one k pair ahead of the MFMAs that use it (explicit register double buffer)
+        float a_cur = a_ptr[0], b_cur[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_cur[j] = b_ptr[32 * j];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[(kk + lh) * PA + a_base];
-            float b[TN];
+            float a_nxt = 0.f, b_nxt[TN];
+            if (kk + 2 < BK) {
+                a_nxt = a_ptr[(kk + 2) * PA];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lh) * PB + b_base + 32 * j];
+                for (int j = 0; j < TN; ++j) b_nxt[j] = b_ptr[(kk + 2) * PB + 32 * j];
+            }
+            // keep the fetch of the NEXT pair above this pair's MFMAs (hipcc otherwise sinks every ds_read to
+            // just before its use and waits lgkmcnt(0) in front of each MFMA)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < BK) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+            }
         }
         __syncthreads();
     }
@@ -378,6 +396,10 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         for (int tn = 8; tn >= 1; --tn) {
             int cost = ((nt + tn - 1) / tn) * tn;
             if (cost < best_cost) { best_cost = cost; best = tn; }
+        }
+        if (const char* e = getenv("MPNHIP_TN")) {  // tuning override
+            int v = atoi(e);
+            if (v >= 1 && v <= 8) best = v;
         }
         switch (best) {
             case 8: return launch_cfg<4, 1, 8>(a, bl, s);

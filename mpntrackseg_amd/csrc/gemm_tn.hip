@@ -46,7 +46,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     const int* rep = TN_G(row_end);
     const int rb = rbp ? *rbp : 0;
     const int re = rep ? *rep : (int)TN_G(m_static);
-    const int r0 = rb + blockIdx.y * args.chunk;
+    const int batch = blockIdx.y / args.nsplit;
+    const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
     if (r0 >= r1) return;  // empty chunk: the reduce kernel skips it too
@@ -59,9 +60,10 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     int cc = c0 + bc;
     cc = cc + 3 < k_in ? cc : k_in - 4;
     const bool bseg2 = cc >= csplit;                     // csplit % 4 == 0: a float4 lies in one segment
-    const float* hbase = (bseg2 ? TN_G(H2) : TN_G(H)) + (bseg2 ? cc - csplit : cc);
+    const float* hbase = (bseg2 ? TN_G(H2) : TN_G(H)) + (bseg2 ? cc - csplit : cc) +
+                         (int64_t)batch * (bseg2 ? TN_G(h2_bstride) : TN_G(h_bstride));
     const int64_t ldh = bseg2 ? TN_G(ldh2) : TN_G(ldh);
-    const float* zbase = TN_G(dZ) + oc;
+    const float* zbase = TN_G(dZ) + oc + (int64_t)batch * TN_G(z_bstride);
     const int64_t ldz = TN_G(ldz);
 
     f32x16 acc[2];
@@ -134,13 +136,14 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     const int* rep = TN_G(row_end);
     const int rb = rbp ? *rbp : 0;
     const int re = rep ? *rep : (int)TN_G(m_static);
-    const int r0 = rb + blockIdx.y * args.chunk;
+    const int batch = blockIdx.y / args.nsplit;
+    const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
     if (r0 >= r1) return;
-    const float* dZ = TN_G(dZ);
-    const float* H = TN_G(H);
-    const float* H2 = TN_G(H2);
+    const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride);
+    const float* H = TN_G(H) + (int64_t)batch * TN_G(h_bstride);
+    const float* H2 = TN_G(H2) ? TN_G(H2) + (int64_t)batch * TN_G(h2_bstride) : nullptr;
     const int* zi = TN_G(dz_idx);
     const int* hi = TN_G(h_idx);
     const int64_t ldz = TN_G(ldz), ldh = TN_G(ldh), ldh2 = TN_G(ldh2);
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
         c = (int)(t % (args.k_in + 1));
         const float* p = TN_G(slab) + (size_t)o * kpad + c;
         const size_t stride = (size_t)args.n_out * kpad;
-        for (int i = l; i < nvalid; i += 8) s += p[i * stride];
+        for (int b = 0; b < args.nbatch; ++b)
+            for (int i = l; i < nvalid; i += 8) s += p[((size_t)b * args.nsplit + i) * stride];
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -203,20 +207,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
 
 static bool al16t(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper) {
+size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch) {
     TnArgs a = {};
     a.n_out = n_out;
     a.k_in = k_in;
     a.m_upper = m_upper;
+    a.nbatch = nbatch;
     tn_plan(a);
-    return (size_t)a.nsplit * n_out * (k_in + 4);
+    return (size_t)a.nbatch * a.nsplit * n_out * (k_in + 4);
 }
 
 void tn_plan(TnArgs& a) {
-    // enough row chunks that tiles x chunks fills the chip about three times over, but never chunks so
-    // short that the slab traffic (nsplit n_out k_in) rivals the operand traffic (rows (n_out + k_in))
-    int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
-    int target = 768 / (tiles > 0 ? tiles : 1);
+    // enough row chunks that tiles x batches x chunks fills the chip a few times over, but never chunks so
+    // short that the slab traffic (chunks n_out k_in) rivals the operand traffic (rows (n_out + k_in))
+    if (a.nbatch < 1) a.nbatch = 1;
+    int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN) * a.nbatch;
+    int target = 1536 / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
     if (target > 128) target = 128;
     int64_t chunk = (a.m_upper + target - 1) / target;
@@ -232,20 +238,22 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
     MPN_CHECK_ARG(a.ngroups == 1 || a.ngroups == 2, "gemm_tn: ngroups");
     MPN_CHECK_ARG(a.n_out >= 1 && a.k_in >= 1 && a.csplit >= 0 && a.csplit <= a.k_in, "gemm_tn: dims");
     if (a.m_upper <= 0) return MPNHIP_OK;
+    if (a.nbatch < 1) a.nbatch = 1;
     bool fast = (a.n_out % 4 == 0) && (a.k_in % 4 == 0) && (a.csplit % 4 == 0);
     for (int i = 0; i < a.ngroups; ++i) {
         const TnGroup& g = a.g[i];
         MPN_CHECK_ARG(g.dZ && g.H && (a.csplit == a.k_in || g.H2) && g.slab, "gemm_tn: null operand");
         fast = fast && !g.dz_idx && !g.h_idx && al16t(g.dZ) && g.ldz % 4 == 0 && al16t(g.H) && g.ldh % 4 == 0 &&
-               (!g.H2 || (al16t(g.H2) && g.ldh2 % 4 == 0));
+               (!g.H2 || (al16t(g.H2) && g.ldh2 % 4 == 0)) && g.z_bstride % 4 == 0 && g.h_bstride % 4 == 0 &&
+               g.h2_bstride % 4 == 0;
     }
     tn_plan(a);
     if (fast) {
         int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, a.nsplit, a.ngroups), dim3(TNT), 0, s, a);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
     } else {
-        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)(a.n_out * (a.k_in + 1)), a.nsplit, a.ngroups), dim3(256),
-                           0, s, a);
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)(a.n_out * (a.k_in + 1)), a.nsplit * a.nbatch, a.ngroups),
+                           dim3(256), 0, s, a);
     }
     MPN_LAUNCH_CHECK();
     int64_t total = (int64_t)a.n_out * (a.k_in + 1) * 8;
