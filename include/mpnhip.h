@@ -156,6 +156,9 @@ int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream)
  * the average duration (us) and launch count of each since the last read, and resets the counters.
  * The empty-pair cost applies to the default (NULL) stream the calibration pairs are recorded on. */
 int mpnhip_profile_enable(int on);
+/* 1 when mpnhip_forward evaluates the per-edge chain (edge MLP + classifier + flow MLPs) of this model with the
+ * fused edge_chain kernel (then THAT kernel is the one bracketed as "gemm" by the profile hooks), else 0. */
+int mpnhip_edge_chain_active(const mpnhip_model* model);
 int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches,
                         float* empty_pair_us /* cost of an event pair with nothing between, for calibration */);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mpnhip_mlp_forward": (_I, [C.POINTER(Mlp), _P, _P, _L, _P, _Z, _P]),
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
     "mpnhip_profile_enable": (_I, [_I]),
+    "mpnhip_edge_chain_active": (_I, [C.POINTER(Model)]),
     "mpnhip_profile_read": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),
                                  C.POINTER(C.c_float)]),
     "mpnhip_time_aggregate": (_I, [_P, _I, _L, _P, _I, _I, _P, _I, C.POINTER(C.c_float), _P]),

@@ -1,0 +1,46 @@
+// Fused per-edge chain kernel of one message-passing step (see edge_chain.hip).
+#pragma once
+#include "common.h"
+
+namespace mpnhip {
+
+struct EdgeChainArgs {
+    int E;                 // edges (sorted order)
+    const int* header;     // graph header: [1] = E_out, [2] = E_in
+    const int* srow;
+    const int* scol;
+    const int* perm;
+    const float* xa;       // first-layer input segments [e0 | e]: xa [E, k1a] (ld ldxa), xb [E, k1b] or nullptr
+    const float* xb;
+    int64_t ldxa, ldxb;
+    int k1a, k1b;
+    const float* P;        // [N, pw] per-node projections: [Pr (he) | Pc (he) | Pf_out (hn) | Pf_in (hn)]
+    int pw;
+    // pre-transposed weight images WT[k][n] and biases
+    const float* w1T;      // [k1a + k1b][he]   edge layer 0, e-part columns
+    const float* w2T;      // [he][de]          edge layer 1
+    const float* b2;       // [de]
+    const float* wc1T;     // [de][hc]          classifier layer 0
+    const float* bc1;      // [hc]
+    const float* wc2;      // [hc]              classifier layer 1 (out dim 1)
+    const float* bc2;      // [1]
+    const float* wf1T_out; // [de][hn]          flow_out layer 0, e'-part columns
+    const float* wf1T_in;
+    const float* wf2T_out; // [hn][dn]          flow_out layer 1
+    const float* wf2T_in;
+    const float* bf2_out;  // [dn]
+    const float* bf2_in;
+    // outputs (sorted edge order)
+    float* e_new;          // [E, de]
+    float* msg;            // [E, dn]
+    float* logits;         // [E] in ORIGINAL order (through perm) or nullptr
+    float* save_h1;        // [E, he] / nullptr  (training: activations kept for the backward pass)
+    float* save_hc;        // [E, hc] / nullptr
+    float* save_hf;        // [E, hn] / nullptr
+};
+
+bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
+int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
+int transpose_block(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, hipStream_t s);
+
+}  // namespace mpnhip

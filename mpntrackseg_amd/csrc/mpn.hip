@@ -11,9 +11,11 @@
 // the GEMM's A operand is read from two K segments.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
+#include "edge_chain.h"
 #include "plan.h"
 
 namespace mpnhip {
@@ -169,6 +171,26 @@ static int pack_node_weights(const mpnhip_model& m, const Dims& d, float* Wnode,
     return MPNHIP_OK;
 }
 
+static bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
+    if (getenv("MPNHIP_NO_CHAIN")) return false;  // tuning / A-B switch
+    return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
+           edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
+}
+
+static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights& cw, hipStream_t s) {
+    cw.ok = chain_shapes_ok(m, d);
+    if (!cw.ok) return MPNHIP_OK;
+    MPN_TRY(transpose_block(m.edge.weight[0], m.edge.in_dim, 2 * d.kx, d.he, d.ke, cw.w1T, s));
+    MPN_TRY(transpose_block(m.edge.weight[1], d.he, 0, d.de, d.he, cw.w2T, s));
+    MPN_TRY(transpose_block(m.classifier.weight[0], d.de, 0, m.classifier.out_dims[0], d.de, cw.wc1T, s));
+    const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
+    for (int q = 0; q < 2; ++q) {
+        MPN_TRY(transpose_block(fl[q]->weight[0], fl[q]->in_dim, d.kx, d.hn, d.de, cw.wf1T[q], s));
+        MPN_TRY(transpose_block(fl[q]->weight[1], d.hn, 0, d.dn, d.hn, cw.wf2T[q], s));
+    }
+    return MPNHIP_OK;
+}
+
 struct StepIO {
     // node features as one or two K segments (x0 | x) -- together kx columns
     const float* xa; int64_t ldxa; const float* xb; int64_t ldxb; int kxa;
@@ -182,7 +204,8 @@ struct StepIO {
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
 static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, const float* Wnode, const float* bnode,
-                    const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s) {
+                    const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s, const ChainWeights* cw = nullptr,
+                    bool save_acts = false) {
     const int64_t N = g.N, E = g.E;
     const int he = d.he, hn = d.hn;
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
@@ -195,7 +218,26 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         G.B = Wnode; G.ldb = d.kx; G.bias = bnode; G.C = b.P; G.ldc = d.pw; G.m_static = N;
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
-    if (E > 0) {
+    const bool chain = cw && cw->ok && E > 0 && io.logits && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
+    if (chain) {
+        // (2)-(4) fused: edge MLP, classifier and both flow MLPs in one kernel (edge_chain.hip)
+        EdgeChainArgs a = {};
+        a.E = (int)E; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm;
+        a.xa = io.ea; a.ldxa = io.ldea; a.k1a = io.eb ? io.kea : d.ke;
+        a.xb = io.eb; a.ldxb = io.ldeb; a.k1b = io.eb ? d.ke - io.kea : 0;
+        a.P = b.P; a.pw = d.pw;
+        a.w1T = cw->w1T; a.w2T = cw->w2T; a.b2 = m.edge.bias[1];
+        a.wc1T = cw->wc1T; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
+        a.wf1T_out = cw->wf1T[0]; a.wf1T_in = cw->wf1T[1]; a.wf2T_out = cw->wf2T[0]; a.wf2T_in = cw->wf2T[1];
+        a.bf2_out = m.flow_out.bias[1]; a.bf2_in = m.flow_in.bias[1];
+        a.e_new = io.e_new; a.msg = b.M; a.logits = io.logits;
+        a.save_h1 = save_acts ? b.HE[0] : nullptr;
+        a.save_hc = save_acts ? b.HC[0] : nullptr;
+        a.save_hf = save_acts ? b.HF[0] : nullptr;
+        prof_begin(PROF_GEMM, s);
+        MPN_TRY(launch_edge_chain(a, s));
+        prof_end(PROF_GEMM, s);
+    } else if (E > 0) {
         // (2) edge MLP layer 0: relu([ea | eb] W1e^T + P_r[row] + P_c[col])      (EdgeModel, mpn.py:67-69)
         {
             GemmArgs a = {};
@@ -319,6 +361,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
 
     MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
+    MPN_TRY(pack_chain_weights(m, d, p.cw, s));
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
     float* hid[MPNHIP_MAX_LAYERS];
@@ -344,7 +387,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.e_new = p.e_hist + es * cur;
         io.x_new = p.x_hist + xs * cur;
         io.logits = logits + (size_t)step * E;
-        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s));
+        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
         prev = cur;
     }
     if (d.L == 0 && E > 0) {
@@ -462,6 +505,12 @@ extern "C" int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, vo
                        x, rows, hw, y, sub);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_edge_chain_active(const mpnhip_model* model) {
+    Dims d;
+    if (!model || check_full(*model, &d, false) != MPNHIP_OK) return 0;
+    return chain_shapes_ok(*model, d) ? 1 : 0;
 }
 
 extern "C" int mpnhip_profile_enable(int on) {

@@ -103,9 +103,20 @@ struct StepBufs {
     int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
 };
 
+// pre-transposed weight images of the fused edge-chain kernel (edge_chain.hip)
+struct ChainWeights {
+    float* w1T;       // [ke][he]
+    float* w2T;       // [he][de]
+    float* wc1T;      // [de][hc]
+    float* wf1T[2];   // [de][hn]  (0: flow_out, 1: flow_in)
+    float* wf2T[2];   // [hn][dn]
+    bool ok;          // the model's shapes are covered by the fused kernel
+};
+
 struct FwdPlan {
     float* Wnode;  // [pw, kx]
     float* bnode;  // [pw]
+    ChainWeights cw;
     float* enc_n[2];
     float* enc_e[2];
     float* x_hist;  // [(L+1) or 3][N, dn]   x_hist[0] = encoder output
@@ -147,6 +158,17 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     FwdPlan p = {};
     p.Wnode = a.f((size_t)d.pw * d.kx);
     p.bnode = a.f((size_t)d.pw);
+    {
+        const int hc = m.classifier.out_dims[0];
+        p.cw.w1T = a.f((size_t)d.ke * d.he);
+        p.cw.w2T = a.f((size_t)d.he * d.de);
+        p.cw.wc1T = a.f((size_t)d.de * hc);
+        for (int q = 0; q < 2; ++q) {
+            p.cw.wf1T[q] = a.f((size_t)d.de * d.hn);
+            p.cw.wf2T[q] = a.f((size_t)d.hn * d.dn);
+        }
+        p.cw.ok = false;
+    }
     int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
     if (save) {
         // keep every encoder activation for the backward pass: one buffer per hidden layer
