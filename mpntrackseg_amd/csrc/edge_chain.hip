@@ -86,14 +86,24 @@ __device__ __forceinline__ float4 get4(const f32x16& a, int g) {
 template <int TOUT>
 __device__ __forceinline__ void chain_tile(const f32x16& src, f32x16* out, const float* ws, int nc, int krow0, int ncol0,
                                            int lane_off) {
+    // weight fetch runs two k pairs ahead of the MFMAs (pinned with sched_barrier: hipcc would otherwise sink
+    // every ds_read to just before its MFMA and wait lgkmcnt(0) there)
+    const float* base = ws + lane_off + ncol0;
+    float a[3][TOUT];
+    auto fetch = [&](int r, float* dst) {
+        const int krow = krow0 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) dst[t] = base[krow * nc + 32 * t];
+    };
+    fetch(0, a[0]);
+    fetch(1, a[1]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int krow = krow0 + (r & 3) + 8 * (r >> 2);
-        float a[TOUT];
+        if (r + 2 < 16) fetch(r + 2, a[(r + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < TOUT; ++t) a[t] = ws[krow * nc + lane_off + ncol0 + 32 * t];
-#pragma unroll
-        for (int t = 0; t < TOUT; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], src[r], out[t], 0, 0, 0);
+        for (int t = 0; t < TOUT; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r % 3][t], src[r], out[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -193,19 +203,24 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
         for (int i = 0; i < nch1; ++i) {
             prefetch();
             if (i + 1 < nch1) { xnxt[0] = xload((i + 1) * KC1); xnxt[1] = xload((i + 1) * KC1 + 8); }
-            const float* ws = wbuf[c & 1];
+            const float* ws = wbuf[c & 1] + 4 * lh * HE + lj;
+            // 8 steps (u, q) of T1 MFMAs each; the weights of step s+1 are fetched before the MFMAs of step s
+            float a[2][T1];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float xv[4] = {xcur[u].x, xcur[u].y, xcur[u].z, xcur[u].w};
+            for (int t = 0; t < T1; ++t) a[0][t] = ws[32 * t];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* wrow = ws + (8 * u + 4 * lh + q) * HE + lj;
-                    float a[T1];
+            for (int st = 0; st < 8; ++st) {
+                const int u = st >> 2, q = st & 3;
+                if (st + 1 < 8) {
+                    const int u1 = (st + 1) >> 2, q1 = (st + 1) & 3;
 #pragma unroll
-                    for (int t = 0; t < T1; ++t) a[t] = wrow[32 * t];
-#pragma unroll
-                    for (int t = 0; t < T1; ++t) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xv[q], h1[t], 0, 0, 0);
+                    for (int t = 0; t < T1; ++t) a[(st + 1) & 1][t] = ws[(8 * u1 + q1) * HE + 32 * t];
                 }
+                const float xv = q == 0 ? xcur[u].x : (q == 1 ? xcur[u].y : (q == 2 ? xcur[u].z : xcur[u].w));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < T1; ++t) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][t], xv, h1[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (i + 1 < nch1) { xcur[0] = xnxt[0]; xcur[1] = xnxt[1]; }
             commit();

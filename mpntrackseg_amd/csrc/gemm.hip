@@ -413,8 +413,19 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         }
     }
     // few rows (node-level products): spread the columns over the waves so that the grid fills the chip
-    if (nt >= 8) return launch_cfg<1, 4, 2>(a, bl, s);
-    if (nt >= 4) return launch_cfg<1, 4, 1>(a, bl, s);
+    if (const char* e = getenv("MPNHIP_SMALL_CFG")) {  // tuning override: 412 = <4,1,2>, 141 = <1,4,1>, ...
+        switch (atoi(e)) {
+            case 411: return launch_cfg<4, 1, 1>(a, bl, s);
+            case 412: return launch_cfg<4, 1, 2>(a, bl, s);
+            case 414: return launch_cfg<4, 1, 4>(a, bl, s);
+            case 141: return launch_cfg<1, 4, 1>(a, bl, s);
+            case 142: return launch_cfg<1, 4, 2>(a, bl, s);
+            case 221: return launch_cfg<2, 2, 1>(a, bl, s);
+            default: break;
+        }
+    }
+    // measured on MI355X at M = 5,000 (tools/gemm_bench.py): 64 x 64 tiles beat every wider strip for
+    // N = 128 ... 1088 and K = 128 ... 2048 (more, shorter blocks: the chip is latency- not MFMA-bound here)
     if (nt >= 2) return launch_cfg<2, 2, 1>(a, bl, s);
     return launch_cfg<4, 1, 1>(a, bl, s);
 }

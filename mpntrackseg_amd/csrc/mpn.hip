@@ -200,6 +200,8 @@ struct StepIO {
     const int* e_new_read_idx;            // how the flow MLPs must index e_new (nullptr = sorted order)
     float* x_new;                         // [N, dn]
     float* logits;                        // [E] original order, or nullptr (operator-level call)
+    const float* P0;                      // optional: xa's share of the projections (+ biases), precomputed [N, pw];
+                                          // then only xb is multiplied here (the weights are shared by all steps)
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -211,11 +213,21 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
     {
         GemmArgs a = {};
-        a.ngroups = 1; a.N = d.pw; a.K = d.kx; a.ksplit = io.xb ? io.kxa : d.kx; a.relu = 0; a.m_upper = N;
+        a.ngroups = 1; a.N = d.pw; a.relu = 0; a.m_upper = N;
         GemmGroup& G = a.g[0];
         init_group(G);
-        G.A = io.xa; G.lda = io.ldxa; G.A2 = io.xb; G.lda2 = io.ldxb;
-        G.B = Wnode; G.ldb = d.kx; G.bias = bnode; G.C = b.P; G.ldc = d.pw; G.m_static = N;
+        if (io.P0 && io.xb) {
+            // xa (the re-attached initial features) does not change from step to step: its product is P0
+            a.K = d.kx - io.kxa; a.ksplit = a.K;
+            G.A = io.xb; G.lda = io.ldxb;
+            G.B = Wnode + io.kxa; G.ldb = d.kx;
+            G.G1 = io.P0; G.ldg1 = d.pw;
+        } else {
+            a.K = d.kx; a.ksplit = io.xb ? io.kxa : d.kx;
+            G.A = io.xa; G.lda = io.ldxa; G.A2 = io.xb; G.lda2 = io.ldxb;
+            G.B = Wnode; G.ldb = d.kx; G.bias = bnode;
+        }
+        G.C = b.P; G.ldc = d.pw; G.m_static = N;
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
     const bool chain = cw && cw->ok && E > 0 && io.logits && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
@@ -373,6 +385,15 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     MPN_TRY(mlp_forward(m.enc_edge, edge_attr, m.enc_edge.in_dim, g.perm, hid, e0, E, s));
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
+    const bool hoist = d.nf == 2 && d.L > 1;
+    if (hoist) {  // P0 = x0 Wnode[:, :dn]^T + bnode, once per forward
+        GemmArgs a = {};
+        a.ngroups = 1; a.N = d.pw; a.K = d.dn; a.ksplit = d.dn; a.m_upper = N;
+        GemmGroup& G = a.g[0];
+        init_group(G);
+        G.A = x0; G.lda = d.dn; G.B = p.Wnode; G.ldb = d.kx; G.bias = p.bnode; G.C = p.P0; G.ldc = d.pw; G.m_static = N;
+        MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+    }
     int prev = 0;
     for (int step = 0; step < d.L; ++step) {
         int cur = save ? step + 1 : 1 + (step & 1);
@@ -387,6 +408,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.e_new = p.e_hist + es * cur;
         io.x_new = p.x_hist + xs * cur;
         io.logits = logits + (size_t)step * E;
+        io.P0 = hoist ? p.P0 : nullptr;
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
         prev = cur;
     }

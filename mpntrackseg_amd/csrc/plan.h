@@ -117,6 +117,7 @@ struct FwdPlan {
     float* Wnode;  // [pw, kx]
     float* bnode;  // [pw]
     ChainWeights cw;
+    float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
     float* enc_n[2];
     float* enc_e[2];
     float* x_hist;  // [(L+1) or 3][N, dn]   x_hist[0] = encoder output
@@ -158,6 +159,7 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     FwdPlan p = {};
     p.Wnode = a.f((size_t)d.pw * d.kx);
     p.bnode = a.f((size_t)d.pw);
+    p.P0 = a.f((size_t)N * d.pw);
     {
         const int hc = m.classifier.out_dims[0];
         p.cw.w1T = a.f((size_t)d.ke * d.he);
