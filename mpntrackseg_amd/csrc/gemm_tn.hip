@@ -18,8 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TBK = 32;
 constexpr int TBM = 64;    // n_out tile
-constexpr int TBN = 128;   // k_in tile
-constexpr int TNT = 256;
+constexpr int TNT = 256;   // k_in tile: template parameter TBN (128, or 64 for k_in <= 64)
 
 __device__ __forceinline__ float4 ld4t(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 keep4t(bool ok, float4 v) {
@@ -30,8 +29,11 @@ __device__ __forceinline__ float4 keep4t(bool ok, float4 v) {
 // the whole struct into scratch memory)
 #define TN_G(field) (blockIdx.z == 0 ? args.g[0].field : args.g[1].field)
 
+template <int TBN>
 __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     constexpr int PA = TBM + 4, PB = TBN + 4;
+    constexpr int NB = TBN / 32;          // float4 loads of the B' tile per thread; columns per row = TBN / 4
+    constexpr int TW = TBN / 64;          // 32-wide accumulator tiles per wave (waves 2 x 2)
     __shared__ __attribute__((aligned(16))) float As[TBK * PA];
     __shared__ __attribute__((aligned(16))) float Bs[TBK * PB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,9 +54,9 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     r1 = r1 < re ? r1 : re;
     if (r0 >= r1) return;  // empty chunk: the reduce kernel skips it too
 
-    // loader geometry: A' tile [32 rows][64 cols] = 512 float4 (2 / thread); B' tile [32][128] = 1024 (4 / thread)
+    // loader geometry: A' tile [32 rows][64 cols] = 512 float4 (2 / thread); B' tile [32][TBN] (NB / thread)
     const int ar = tid >> 4, ac = (tid & 15) * 4;        // + 16 rows for the second
-    const int br = tid >> 5, bc = (tid & 31) * 4;        // + 8 rows per j
+    const int br = tid / (TBN / 4), bc = (tid % (TBN / 4)) * 4;   // + 1024 / TBN rows per j
     int oc = o0 + ac;
     oc = oc + 3 < n_out ? oc : n_out - 4;                // clamped columns are never stored
     int cc = c0 + bc;
@@ -66,13 +68,13 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     const float* zbase = TN_G(dZ) + oc + (int64_t)batch * TN_G(z_bstride);
     const int64_t ldz = TN_G(ldz);
 
-    f32x16 acc[2];
+    f32x16 acc[TW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
-    float4 a_reg[2], b_reg[4];
+    float4 a_reg[2], b_reg[NB];
 
     auto load = [&](int m0) {
 #pragma unroll
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
             a_reg[j] = keep4t(ok, ld4t(zbase + (int64_t)(ok ? m : r1 - 1) * ldz));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int m = m0 + br + 8 * j;
+        for (int j = 0; j < NB; ++j) {
+            int m = m0 + br + (1024 / TBN) * j;
             bool ok = m < r1;
             b_reg[j] = keep4t(ok, ld4t(hbase + (int64_t)(ok ? m : r1 - 1) * ldh));
         }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(ar + 16 * j) * PA + ac]) = a_reg[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Bs[(br + 8 * j) * PB + bc]) = b_reg[j];
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4*>(&Bs[(br + (1024 / TBN) * j) * PB + bc]) = b_reg[j];
     };
 
     load(r0);
@@ -103,10 +105,11 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
 #pragma unroll
         for (int kk = 0; kk < TBK; kk += 2) {
             const float a = As[(kk + lh) * PA + wm * 32 + li];
-            const float b0 = Bs[(kk + lh) * PB + wn * 64 + li];
-            const float b1 = Bs[(kk + lh) * PB + wn * 64 + 32 + li];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            float b[TW];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) b[j] = Bs[(kk + lh) * PB + wn * 32 * TW + 32 * j + li];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
         }
         if (c0 == 0 && tid < TBM) {
 #pragma unroll
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     const int kpad = k_in + 4;
     float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * kpad;
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int c = c0 + wn * 64 + tj * 32 + li;
+    for (int tj = 0; tj < TW; ++tj) {
+        const int c = c0 + wn * 32 * TW + tj * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -129,9 +132,13 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     if (c0 == 0 && tid < TBM && o0 + tid < n_out) slab[(size_t)(o0 + tid) * kpad + k_in] = bsum;
 }
 
-// Any shape / alignment / row gathers: grid (output element (o, c), chunk); c == k_in is the bias column.
+// Any shape / alignment / row gathers (the K = 6 edge-encoder input read through the sort permutation, the
+// [1 x hc] classifier output layer whose dZ is grad_logits in original edge order): one thread per output
+// element (o, c) -- c == k_in is the bias column -- looping over the rows of its chunk; a block covers 256
+// outputs of one chunk, so the chunk's dZ / H rows are shared through L1.
 __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
-    const int o = blockIdx.x / (args.k_in + 1), c = blockIdx.x % (args.k_in + 1);
+    const int64_t nout_total = (int64_t)args.n_out * (args.k_in + 1);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int* rbp = TN_G(row_begin);
     const int* rep = TN_G(row_end);
     const int rb = rbp ? *rbp : 0;
@@ -140,32 +147,26 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
-    if (r0 >= r1) return;
-    const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride);
-    const float* H = TN_G(H) + (int64_t)batch * TN_G(h_bstride);
-    const float* H2 = TN_G(H2) ? TN_G(H2) + (int64_t)batch * TN_G(h2_bstride) : nullptr;
+    if (r0 >= r1 || t >= nout_total) return;
+    const int o = (int)(t / (args.k_in + 1)), c = (int)(t % (args.k_in + 1));
+    const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride) + o;
+    const bool seg2 = c >= args.csplit && c < args.k_in;
+    const float* H = seg2 ? TN_G(H2) + (int64_t)batch * TN_G(h2_bstride) + (c - args.csplit)
+                          : TN_G(H) + (int64_t)batch * TN_G(h_bstride) + (c < args.k_in ? c : 0);
+    const int64_t ldh = seg2 ? TN_G(ldh2) : TN_G(ldh);
     const int* zi = TN_G(dz_idx);
     const int* hi = TN_G(h_idx);
-    const int64_t ldz = TN_G(ldz), ldh = TN_G(ldh), ldh2 = TN_G(ldh2);
+    const int64_t ldz = TN_G(ldz);
+    const bool bias_col = c >= args.k_in;
     float s = 0.f;
-    for (int m = r0 + threadIdx.x; m < r1; m += blockDim.x) {
-        int64_t rz = zi ? zi[m] : m;
-        float z = dZ[rz * ldz + o];
-        float h = 1.f;
-        if (c < args.k_in) {
-            int64_t rh = hi ? hi[m] : m;
-            h = c >= args.csplit ? H2[rh * ldh2 + c - args.csplit] : H[rh * ldh + c];
-        }
+    for (int m = r0; m < r1; ++m) {
+        const int64_t rz = zi ? zi[m] : m;
+        const int64_t rh = hi ? hi[m] : m;
+        const float z = dZ[rz * ldz];
+        const float h = bias_col ? 1.f : H[rh * ldh];
         s = fmaf(z, h, s);
     }
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = red[0];
+    TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = s;
 }
 
 // grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]
@@ -221,7 +222,8 @@ void tn_plan(TnArgs& a) {
     // enough row chunks that tiles x batches x chunks fills the chip a few times over, but never chunks so
     // short that the slab traffic (chunks n_out k_in) rivals the operand traffic (rows (n_out + k_in))
     if (a.nbatch < 1) a.nbatch = 1;
-    int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN) * a.nbatch;
+    const int tbn = a.k_in <= 64 ? 64 : 128;
+    int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn) * a.nbatch;
     int target = 1536 / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
     if (target > 128) target = 128;
@@ -249,10 +251,15 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
     }
     tn_plan(a);
     if (fast) {
-        int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + TBN - 1) / TBN);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
+        const int tbn = a.k_in <= 64 ? 64 : 128;
+        int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn);
+        if (tbn == 64)
+            hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
+        else
+            hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
     } else {
-        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)(a.n_out * (a.k_in + 1)), a.nsplit * a.nbatch, a.ngroups),
+        const int64_t nout_total = (int64_t)a.n_out * (a.k_in + 1);
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)((nout_total + 255) / 256), a.nsplit * a.nbatch, a.ngroups),
                            dim3(256), 0, s, a);
     }
     MPN_LAUNCH_CHECK();
