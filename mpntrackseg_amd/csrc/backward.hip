@@ -9,7 +9,10 @@
 //   scatter_{add,mean,max} backward                                        -> one gather kernel (k_agg_bwd)
 //
 // Every per-step activation was saved by the forward (288 GB of HBM: nothing is recomputed).
+#include <cstdlib>
+
 #include "common.h"
+#include "edge_chain.h"
 #include "plan.h"
 
 namespace mpnhip {
@@ -379,6 +382,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
 
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
+    const bool use_chain = chain_shapes_ok(m, d);
 
     // activation-gradient chain of the classifier for one step: dz chain blocks in dzc[], final product
     // accumulated into dEdst and masked by `mask` (ReLU of the edge layer that produced ef)
@@ -421,7 +425,25 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             const float* Wq[2] = {m.node.weight[0], nullptr};
             MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
         }
-        if (E > 0) {
+        if (E > 0 && use_chain && !getenv("MPNHIP_NO_CHAIN_BWD")) {
+            // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
+            EdgeChainBwdArgs a = {};
+            a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0;
+            a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
+            a.dAGG = p.dAGG; a.M = b.M; a.ARG = b.ARG; a.HF = b.HF[0]; a.HC = b.HC[0]; a.H1 = b.HE[0]; a.e_s = e_s;
+            a.dlog = grad_logits + (size_t)b_ * E;
+            a.dE_io = dzed[1]; a.dZM = dzfl[1]; a.dZF = dzfl[0]; a.dZc = dzcl[0]; a.dZ1 = dzed[0];
+            a.dE0 = p.dE0; a.dEprev = step == 1 ? p.dE0 : p.dZed[ne - 1] + (size_t)(b_ - 1) * es;
+            a.wf2_out = m.flow_out.weight[1]; a.wf2_in = m.flow_in.weight[1];
+            a.wfe_out = m.flow_out.weight[0] + kx; a.wfe_in = m.flow_in.weight[0] + kx; a.ldwfe = m.flow_out.in_dim;
+            a.wc1 = cls.weight[0]; a.wc2 = cls.weight[1]; a.w2 = m.edge.weight[1];
+            a.w1e = m.edge.weight[0] + 2 * kx; a.ldw1e = m.edge.in_dim;
+            MPN_TRY(launch_edge_chain_bwd(a, s));
+            // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
+            MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s));
+            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s));
+            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s));
+        } else if (E > 0) {
             // ---- B. aggregation backward + ReLU of the last flow layer ---------------------------
             {
                 int64_t tot = E * (dn / 4 > 0 && dn % 4 == 0 ? dn / 4 : dn);

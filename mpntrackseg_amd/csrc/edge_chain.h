@@ -39,6 +39,41 @@ struct EdgeChainArgs {
     float* save_hf;        // [E, hn] / nullptr
 };
 
+// Backward of the same chain for one step (edge_chain.hip, edge_chain_bwd_kernel): all activation-gradient
+// products of the per-edge modules, with the saved activations as ReLU masks.
+struct EdgeChainBwdArgs {
+    int E, N, agg, first_step, cat_two;
+    const int* header;
+    const int* srow;
+    const int* perm;
+    const int* seg_ptr;
+    const float* dAGG;     // [N, 2dn] gradient of the aggregated messages [flow_in | flow_out]
+    const float* M;        // saved activations (sorted edge order)
+    const int* ARG;        // [N, 2dn] arg max (max aggregation) or nullptr
+    const float* HF;
+    const float* HC;
+    const float* H1;
+    const float* e_s;
+    const float* dlog;     // [E] gradient of this step's logits, ORIGINAL edge order
+    float* dE_io;          // [E, de] in: gradient w.r.t. e_s from the later step; out: dZ of the last edge layer
+    float* dZM;            // [E, dn] out
+    float* dZF;            // [E, hn] out
+    float* dZc;            // [E, hc] out
+    float* dZ1;            // [E, he] out
+    float* dE0;            // [E, de] accumulated gradient of the re-attached initial edge features
+    float* dEprev;         // [E, de] out: gradient w.r.t. e_{s-1} (unused at the first step)
+    // weights in their native nn.Linear layout W[n][k]
+    const float* wf2_out; const float* wf2_in;  // [dn][hn]
+    const float* wfe_out; const float* wfe_in;  // [hn][de] sub-blocks, leading dim ldwfe
+    int ldwfe;
+    const float* wc1;      // [hc][de]
+    const float* wc2;      // [hc]
+    const float* w2;       // [de][he]
+    const float* w1e;      // [he][ke] sub-block, leading dim ldw1e
+    int ldw1e;
+};
+int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s);
+
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
 int transpose_block(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, hipStream_t s);

@@ -107,6 +107,32 @@ __device__ __forceinline__ void chain_tile(const f32x16& src, f32x16* out, const
     }
 }
 
+// Half a source tile: registers r0 .. r0+7 of `src` (contraction indices 2 r0 .. 2 r0 + 15 of its 32) against a
+// chunk that holds exactly those 16 rows.
+template <int TOUT>
+__device__ __forceinline__ void chain_half(const f32x16& src, int r0, f32x16* out, const float* ws, int nc, int lane_off) {
+    // wide outputs: TOUT MFMAs per step already cover the LDS latency -> fetch one step ahead (fewer registers)
+    constexpr int DEPTH = TOUT >= 5 ? 1 : 2;
+    const float* base = ws + lane_off;
+    float a[DEPTH + 1][TOUT];
+    auto fetch = [&](int q, float* dst) {
+        const int krow = (q & 3) + 8 * (q >> 2);  // q = 0..7 -> chunk rows 0-3, 8-11 (+4h through lane_off)
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t) dst[t] = base[krow * nc + 32 * t];
+    };
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) fetch(q, a[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (q + DEPTH < 8) fetch(q + DEPTH, a[(q + DEPTH) % (DEPTH + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TOUT; ++t)
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % (DEPTH + 1)][t], r0 == 0 ? src[q] : src[q + 8], out[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 }  // namespace
 
 // T1 = he/32, T2 = de/32, TF = hn/32, TD = dn/32 (hc = 32)
@@ -361,6 +387,281 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
             for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = get4(mm[t], g);
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Backward chain of one step.  Same machinery, transposed weights: dH^T[k][edge] = sum_n W[n][k] dZ^T[n][edge],
+// so the LDS chunk image is W in its native [n][k] layout (rows = contraction index).
+//   B1  dZM = gather(dAGG)[row] (.) [M > 0]                      (node_agg_fn backward, mpn.py:89,96)
+//   B2  dZF = (Wf2^T dZM) (.) [HF > 0]
+//   B3  dE' = dE_in + Wfe^T dZF
+//   B4  dZc = (dlog wc2) (.) [HC > 0];  dE' += Wc1^T dZc;  dZ2 = dE' (.) [e_s > 0]
+//   B5  dZ1 = (W2^T dZ2) (.) [H1 > 0]
+//   B6  d[e0 | e_{s-1}] = W1e^T dZ1  ->  dE0 += ..., dEprev = ...
+template <int T1, int T2, int TF, int TD>
+__global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs A) {
+    constexpr int HE = 32 * T1, DE = 32 * T2, HN = 32 * TF, DN = 32 * TD, HC = 32;
+    constexpr int NR2 = 16;   // B2 chunk: [16 n][HN]
+    constexpr int NR3 = 64;   // B3 chunk: [64 n][DE]
+    constexpr int NR5 = 16;   // B5 chunk: [16 n][HE]
+    constexpr int NR6 = 64;   // B6 chunk: [64 n][64 k]
+    static_assert(NR2 * HN <= CH_FLOATS && NR3 * DE <= CH_FLOATS && NR5 * HE <= CH_FLOATS && NR6 * 64 <= CH_FLOATS, "chunk");
+    static_assert(DN % NR2 == 0 && DE % NR5 == 0 && HE % NR6 == 0, "dims");
+
+    __shared__ __attribute__((aligned(16))) float wbuf[2][CH_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 31, lh = lane >> 5;
+
+    const int e_out = A.header[1], e_in = A.header[2];
+    int grp, beg, end, blk = blockIdx.x;
+    {
+        const int nb0 = (e_out + 127) >> 7, nb1 = (e_in + 127) >> 7;
+        if (blk < nb0) { grp = 0; beg = 0; end = e_out; }
+        else if (blk < nb0 + nb1) { grp = 1; blk -= nb0; beg = e_out; end = e_out + e_in; }
+        else { grp = 2; blk -= nb0 + nb1; beg = e_out + e_in; end = A.E; }
+    }
+    const int tile0 = beg + blk * 128;
+    if (tile0 >= end) return;
+    const int edge_raw = tile0 + wave * 32 + lj;
+    const bool edge_ok = edge_raw < end;
+    const int edge = edge_ok ? edge_raw : end - 1;
+    const bool flow = grp < 2;
+    const int KE = A.cat_two ? 2 * DE : DE;   // columns of [e0 | e_{s-1}]
+    const int npass6 = KE / 64;               // B6 passes of 64 output columns
+
+    // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6 ------------------------------------------
+    constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = HE / NR6;
+    const int c3 = flow ? NCH2 : 0, c4 = c3 + (flow ? NCH3 : 0), c5 = c4 + 1, c6 = c5 + NCH5;
+    const int nchunks = c6 + npass6 * NCH6;
+    const float* wf2 = grp == 1 ? A.wf2_in : A.wf2_out;
+    const float* wfe = grp == 1 ? A.wfe_in : A.wfe_out;
+    auto desc = [&](int c) {
+        ChunkDesc d;
+        if (c < c3) { d.w = wf2; d.ldw = HN; d.k0 = c * NR2; d.kc = NR2; d.n0 = 0; d.nc = HN; }
+        else if (c < c4) { d.w = wfe; d.ldw = A.ldwfe; d.k0 = (c - c3) * NR3; d.kc = HN - d.k0 < NR3 ? HN - d.k0 : NR3; d.n0 = 0; d.nc = DE; }
+        else if (c < c5) { d.w = A.wc1; d.ldw = DE; d.k0 = 0; d.kc = HC; d.n0 = 0; d.nc = DE; }
+        else if (c < c6) { d.w = A.w2; d.ldw = HE; d.k0 = (c - c5) * NR5; d.kc = NR5; d.n0 = 0; d.nc = HE; }
+        else { const int q = c - c6; d.w = A.w1e; d.ldw = A.ldw1e; d.k0 = (q % NCH6) * NR6; d.kc = NR6; d.n0 = (q / NCH6) * 64; d.nc = 64; }
+        return d;
+    };
+    ChunkRegs creg;
+    int c = 0;
+    {
+        ChunkDesc d0 = desc(0);
+        chunk_load(d0, tid, creg);
+        chunk_store(d0, tid, creg, wbuf[0]);
+    }
+    auto prefetch = [&]() { if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_load(d, tid, creg); } };
+    auto commit = [&]() {
+        if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_store(d, tid, creg, wbuf[(c + 1) & 1]); }
+        __syncthreads();
+        ++c;
+    };
+
+    // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators (loaded after B2, when the
+    // dZM tiles are dead -- B2 is the register peak of this kernel)
+    f32x16 de[T2];
+    auto load_de = [&]() {
+        const float* p = A.dE_io + (int64_t)edge * DE + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) set4(de[t], g, ldg4(p + 32 * t + 8 * g));
+    };
+    __syncthreads();  // chunk 0 is in wbuf[0]
+
+    if (flow) {
+        // ---- B1: dZM ------------------------------------------------------------------------------------
+        f32x16 dzm[TD];
+        {
+            const int row = A.srow[edge];
+            const int64_t o = (int64_t)row * 2 * DN + (grp == 0 ? DN : 0) + 4 * lh;
+            float scale = 1.f;
+            if (A.agg == MPNHIP_AGG_MEAN) {
+                const int key = grp * A.N + row;
+                const int cnt = A.seg_ptr[key + 1] - A.seg_ptr[key];
+                scale = 1.f / 1.f;  // (placeholder keeps the division below exact: v / cnt, as the reference divides)
+                scale = (float)(cnt > 0 ? cnt : 1);
+            }
+            const float* mp = A.M + (int64_t)edge * DN + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < TD; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = ldg4(A.dAGG + o + 32 * t + 8 * g);
+                    const float4 m = ldg4(mp + 32 * t + 8 * g);
+                    if (A.agg == MPNHIP_AGG_MEAN) { v.x /= scale; v.y /= scale; v.z /= scale; v.w /= scale; }
+                    if (A.agg == MPNHIP_AGG_MAX) {
+                        const int4 a = *reinterpret_cast<const int4*>(A.ARG + o + 32 * t + 8 * g);
+                        v.x = a.x == edge_raw ? v.x : 0.f; v.y = a.y == edge_raw ? v.y : 0.f;
+                        v.z = a.z == edge_raw ? v.z : 0.f; v.w = a.w == edge_raw ? v.w : 0.f;
+                    }
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    set4(dzm[t], g, v);
+                }
+            if (edge_ok) {
+                float* o2 = A.dZM + (int64_t)edge * DN + 4 * lh;
+#pragma unroll
+                for (int t = 0; t < TD; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = get4(dzm[t], g);
+            }
+        }
+        // ---- B2: dZF = (Wf2^T dZM) (.) [HF > 0] -------------------------------------------------------------
+        f32x16 dzf[TF];
+#pragma unroll
+        for (int t = 0; t < TF; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dzf[t][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH2; ++i) {
+            prefetch();
+            // chunk rows = 16 contraction indices n = 16 i .. 16 i + 15 = registers 8 (i & 1) .. + 7 of source tile i / 2
+            chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf[c & 1], HN, 4 * lh * HN + lj);
+            commit();
+        }
+        {
+            const float* hp = A.HF + (int64_t)edge * HN + 4 * lh;
+            float* o2 = A.dZF + (int64_t)edge * HN + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < TF; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 m = ldg4(hp + 32 * t + 8 * g);
+                    float4 v = get4(dzf[t], g);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    set4(dzf[t], g, v);
+                    if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = v;
+                }
+            }
+        }
+        // ---- B3: dE' += Wfe^T dZF -------------------------------------------------------------------------------
+        load_de();
+#pragma unroll
+        for (int i = 0; i < NCH3; ++i) {
+            prefetch();
+            const float* ws = wbuf[c & 1];
+            chain_tile<T2>(dzf[2 * i], de, ws, DE, 0, 0, 4 * lh * DE + lj);
+            if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], de, ws, DE, 32, 0, 4 * lh * DE + lj);
+            commit();
+        }
+    }
+
+    if (!flow) load_de();
+    // ---- B4: classifier ---------------------------------------------------------------------------------------
+    {
+        f32x16 dzc;
+        const float dl = A.dlog[A.perm[edge]];
+        const float* hp = A.HC + (int64_t)edge * HC + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 w = ldg4(A.wc2 + 8 * g + 4 * lh);
+            const float4 m = ldg4(hp + 8 * g);
+            float4 v;
+            v.x = m.x > 0.f ? dl * w.x : 0.f; v.y = m.y > 0.f ? dl * w.y : 0.f;
+            v.z = m.z > 0.f ? dl * w.z : 0.f; v.w = m.w > 0.f ? dl * w.w : 0.f;
+            set4(dzc, g, v);
+            if (edge_ok) *reinterpret_cast<float4*>(A.dZc + (int64_t)edge * HC + 4 * lh + 8 * g) = v;
+        }
+        prefetch();
+        chain_tile<T2>(dzc, de, wbuf[c & 1], DE, 0, 0, 4 * lh * DE + lj);
+        commit();
+    }
+    // dZ2 = dE' (.) [e_s > 0]  (written over the incoming gradient)
+    {
+        const float* ep = A.e_s + (int64_t)edge * DE + 4 * lh;
+        float* o2 = A.dE_io + (int64_t)edge * DE + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 m = ldg4(ep + 32 * t + 8 * g);
+                float4 v = get4(de[t], g);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                set4(de[t], g, v);
+                if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = v;
+            }
+    }
+
+    // ---- B5: dZ1 = (W2^T dZ2) (.) [H1 > 0] -----------------------------------------------------------------------
+    f32x16 dz1[T1];
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz1[t][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH5; ++i) {
+        prefetch();
+        // two half-width sweeps over the same chunk keep the weight staging registers at T1 / 2 per step
+        chain_half<T1 / 2>(de[i >> 1], (i & 1) * 8, dz1, wbuf[c & 1], HE, 4 * lh * HE + lj);
+        chain_half<T1 / 2>(de[i >> 1], (i & 1) * 8, dz1 + T1 / 2, wbuf[c & 1], HE, 4 * lh * HE + lj + 16 * T1);
+        commit();
+    }
+    {
+        const float* hp = A.H1 + (int64_t)edge * HE + 4 * lh;
+        float* o2 = A.dZ1 + (int64_t)edge * HE + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < T1; t += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            float4 m[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) m[g] = ldg4(hp + 32 * (t + (g >> 2)) + 8 * (g & 3));
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                float4 v = get4(dz1[t + (g >> 2)], g & 3);
+                v.x = m[g].x > 0.f ? v.x : 0.f; v.y = m[g].y > 0.f ? v.y : 0.f;
+                v.z = m[g].z > 0.f ? v.z : 0.f; v.w = m[g].w > 0.f ? v.w : 0.f;
+                set4(dz1[t + (g >> 2)], g & 3, v);
+                if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * (t + (g >> 2)) + 8 * (g & 3)) = v;
+            }
+        }
+    }
+
+    // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, 64 output columns per pass ---------------------------------------------------
+    for (int pass = 0; pass < npass6; ++pass) {
+        f32x16 dc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dc[t][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH6; ++i) {
+            prefetch();
+            const float* ws = wbuf[c & 1];
+            chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
+            chain_tile<2>(dz1[2 * i + 1], dc, ws, 64, 32, 0, 4 * lh * 64 + lj);
+            commit();
+        }
+        // pass 0 of a two-segment input is the re-attached initial features (accumulated over all steps);
+        // the last pass is e_{s-1} -- which IS e0 at the first step
+        const bool to_e0 = (A.cat_two && pass == 0) || A.first_step;
+        float* dst = (to_e0 ? A.dE0 : A.dEprev) + (int64_t)edge * DE + 4 * lh;
+        if (edge_ok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = get4(dc[t], g);
+                    if (to_e0) {
+                        const float4 o = ldg4(dst + 32 * t + 8 * g);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + 32 * t + 8 * g) = v;
+                }
+        }
+    }
+}
+
+int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s) {
+    if (a.E <= 0) return MPNHIP_OK;
+    const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+    hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4>), dim3(blocks), dim3(256), 0, s, a);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
 }
 
 // WT[k][n] = W[n][k0 + k]   (n < n_rows, k < k_cols), W leading dim ldw

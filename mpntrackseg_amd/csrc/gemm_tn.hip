@@ -137,8 +137,11 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
 // element (o, c) -- c == k_in is the bias column -- looping over the rows of its chunk; a block covers 256
 // outputs of one chunk, so the chunk's dZ / H rows are shared through L1.
 __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
+    // 8 lanes share one output element (rows strided by 8, four independent partial sums each so that
+    // several gathers are in flight), 32 output elements per block
     const int64_t nout_total = (int64_t)args.n_out * (args.k_in + 1);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = threadIdx.x & 7;
+    const int64_t t = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const int* rbp = TN_G(row_begin);
     const int* rep = TN_G(row_end);
     const int rb = rbp ? *rbp : 0;
@@ -147,8 +150,10 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
-    if (r0 >= r1 || t >= nout_total) return;
-    const int o = (int)(t / (args.k_in + 1)), c = (int)(t % (args.k_in + 1));
+    if (r0 >= r1) return;
+    const bool live = t < nout_total;
+    const int64_t tt = live ? t : 0;
+    const int o = (int)(tt / (args.k_in + 1)), c = (int)(tt % (args.k_in + 1));
     const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride) + o;
     const bool seg2 = c >= args.csplit && c < args.k_in;
     const float* H = seg2 ? TN_G(H2) + (int64_t)batch * TN_G(h2_bstride) + (c - args.csplit)
@@ -158,15 +163,24 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     const int* hi = TN_G(h_idx);
     const int64_t ldz = TN_G(ldz);
     const bool bias_col = c >= args.k_in;
-    float s = 0.f;
-    for (int m = r0; m < r1; ++m) {
-        const int64_t rz = zi ? zi[m] : m;
-        const int64_t rh = hi ? hi[m] : m;
-        const float z = dZ[rz * ldz];
-        const float h = bias_col ? 1.f : H[rh * ldh];
-        s = fmaf(z, h, s);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m0 = r0 + l; m0 < r1; m0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + 8 * u;
+            const int mc = m < r1 ? m : r1 - 1;
+            const int64_t rz = zi ? zi[mc] : mc;
+            const int64_t rh = hi ? hi[mc] : mc;
+            const float z = dZ[rz * ldz];
+            const float h = bias_col ? 1.f : H[rh * ldh];
+            s[u] = fmaf(m < r1 ? z : 0.f, h, s[u]);
+        }
     }
-    TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = s;
+    float tot = (s[0] + s[1]) + (s[2] + s[3]);
+    tot += __shfl_xor(tot, 1, 64);
+    tot += __shfl_xor(tot, 2, 64);
+    tot += __shfl_xor(tot, 4, 64);
+    if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = tot;
 }
 
 // grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]
@@ -259,7 +273,7 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
             hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
     } else {
         const int64_t nout_total = (int64_t)a.n_out * (a.k_in + 1);
-        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)((nout_total + 255) / 256), a.nsplit * a.nbatch, a.ngroups),
+        hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)((nout_total + 31) / 32), a.nsplit * a.nbatch, a.ngroups),
                            dim3(256), 0, s, a);
     }
     MPN_LAUNCH_CHECK();

@@ -171,12 +171,6 @@ static int pack_node_weights(const mpnhip_model& m, const Dims& d, float* Wnode,
     return MPNHIP_OK;
 }
 
-static bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
-    if (getenv("MPNHIP_NO_CHAIN")) return false;  // tuning / A-B switch
-    return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
-           edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
-}
-
 static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights& cw, hipStream_t s) {
     cw.ok = chain_shapes_ok(m, d);
     if (!cw.ok) return MPNHIP_OK;

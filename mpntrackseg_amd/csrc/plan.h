@@ -1,9 +1,11 @@
 // Model checks and workspace planning shared by the forward (mpn.hip) and backward (backward.hip)
 // orchestration.  Everything here is host code; offsets are a pure function of (model dims, N, E, save).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
+#include "edge_chain.h"
 
 namespace mpnhip {
 
@@ -208,6 +210,13 @@ static inline void hidden_ptrs(const mpnhip_mlp& m, float* const two[2], int64_t
             out[i] = two[i & 1];
         }
     }
+}
+
+// the fused edge-chain kernels (edge_chain.hip) cover this model's per-edge modules
+static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
+    if (getenv("MPNHIP_NO_CHAIN")) return false;  // tuning / A-B switch
+    return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
+           edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
 }
 
 static inline void init_group(GemmGroup& g) { memset(&g, 0, sizeof(g)); }

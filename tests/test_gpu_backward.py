@@ -187,3 +187,23 @@ def test_train_step_runs_and_updates():
     assert torch.isfinite(step.bucket.flat).all()
     assert float(step.bucket.flat.abs().max()) > 0
     assert not torch.equal(before, model.classifier.edge_model.fc_layers[0].weight.detach())
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_fused_chain_kernels_d128(agg):
+    """d = 128 routes the per-edge modules through the fused edge-chain kernels (forward and backward).  Small graph
+    with self loops, interleaved direction halves (batched sub-graphs) and ragged 32-edge tiles, all three
+    aggregations, forward + gradients against the oracle."""
+    lib = capi.load()
+    gs = [synth.make_graph(n, e, T=6, seed=40 + i, node_in_dim=48) for i, (n, e) in enumerate([(70, 500), (45, 302), (33, 150)])]
+    g = synth.batch_graphs(gs)
+    ei = g["edge_index"].copy()
+    ei[:, 5] = [9, 9]
+    ei[:, 700] = [100, 100]   # two self loops
+    g["edge_index"] = ei
+    params = synth.model_params(128, 2, agg, node_in_dim=48)
+    W = synth.make_weights(params, seed=5)
+    model = make_model(params, W)
+    keep = []
+    assert lib.mpnhip_edge_chain_active(model.c_model(keep)) == 1
+    check_against_oracle(params, W, g, robust=(agg == "max"))
