@@ -201,7 +201,9 @@ def main():
     }
 
     if prof is not None:
-        out.update(rooflines(prof, c, args, N, E))
+        keep = []
+        chain = bool(lib.mpnhip_edge_chain_active(model.c_model(keep)))
+        out.update(rooflines(prof, c, args, N, E, chain))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, W, g, mode == "train")
     if mode == "train":
@@ -233,7 +235,7 @@ def pmc_traffic(kernel_key):
         return None
 
 
-def rooflines(prof, c, args, N, E):
+def rooflines(prof, c, args, N, E, chain):
     """Roofline fractions from the in-stream HIP-event timings taken over the timed region:
     dominant kernel = first-layer edge-MLP GEMM (fp32 MFMA); HBM-bound kernel = segmented aggregation."""
     gemm_us, gemm_n, agg_us, agg_n, empty_us = prof
@@ -244,7 +246,18 @@ def rooflines(prof, c, args, N, E):
     d = c["d"]
     dn, de, he = d, d // 2, 5 * d // 2
     res = {}
-    if gemm_n:
+    hn, hc = 7 * d // 4, d // 4
+    if gemm_n and chain:
+        # fused per-edge chain (edge MLP e-part + classifier + flow MLP e-part): MACs per edge, DESIGN.md section 4
+        macs = 2 * de * he + he * de + de * hc + hc + de * hn + hn * dn
+        flops = 2.0 * E * macs
+        ach = flops / (gemm_us * 1e-6) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "edge_chain_kernel<10,2,7,4>: fused edge MLP + classifier + flow MLPs of one MP step, "
+                                                      "fp32 v_mfma_f32_32x32x2_f32, %d edges x %d MACs" % (E, macs),
+                           "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                           "traffic": pmc_traffic("edge_chain"), "avg_us": gemm_us,
+                           "empty_event_pair_us": empty_us, "launches": gemm_n, "algorithmic_flops": flops}
+    elif gemm_n:
         K, Nn = 2 * de, he
         flops = 2.0 * E * K * Nn  # algorithmic: E rows x [e0|e] (2 de) x he outputs
         ach = flops / (gemm_us * 1e-6) / 1e12
