@@ -76,40 +76,57 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     float bsum = 0.f;
     float4 a_reg[2], b_reg[NB];
 
+    // raw loads only (rows clamped); the zero-select for rows past the chunk end happens at LDS-store time so
+    // that nothing consumes the loads before the MFMA phase of the previous step has been issued
     auto load = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int m = m0 + ar + 16 * j;
-            bool ok = m < r1;
-            a_reg[j] = keep4t(ok, ld4t(zbase + (int64_t)(ok ? m : r1 - 1) * ldz));
+            const int m = m0 + ar + 16 * j;
+            a_reg[j] = ld4t(zbase + (int64_t)(m < r1 ? m : r1 - 1) * ldz);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            int m = m0 + br + (1024 / TBN) * j;
-            bool ok = m < r1;
-            b_reg[j] = keep4t(ok, ld4t(hbase + (int64_t)(ok ? m : r1 - 1) * ldh));
+            const int m = m0 + br + (1024 / TBN) * j;
+            b_reg[j] = ld4t(hbase + (int64_t)(m < r1 ? m : r1 - 1) * ldh);
         }
     };
-    auto store = [&]() {
+    auto store = [&](int m0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[(ar + 16 * j) * PA + ac]) = a_reg[j];
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float4*>(&As[(ar + 16 * j) * PA + ac]) = keep4t(m0 + ar + 16 * j < r1, a_reg[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4*>(&Bs[(br + (1024 / TBN) * j) * PB + bc]) = b_reg[j];
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<float4*>(&Bs[(br + (1024 / TBN) * j) * PB + bc]) = keep4t(m0 + br + (1024 / TBN) * j < r1, b_reg[j]);
     };
 
     load(r0);
+    const float* a_ptr = As + lh * PA + wm * 32 + li;
+    const float* b_ptr = Bs + lh * PB + wn * 32 * TW + li;
     for (int m0 = r0; m0 < r1; m0 += TBK) {
-        store();
+        store(m0);
         __syncthreads();
         if (m0 + TBK < r1) load(m0 + TBK);
+        // operand fetch one k pair ahead of its MFMAs, pinned (see gemm.hip)
+        float a_cur = a_ptr[0], b_cur[TW];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) b_cur[j] = b_ptr[32 * j];
 #pragma unroll
         for (int kk = 0; kk < TBK; kk += 2) {
-            const float a = As[(kk + lh) * PA + wm * 32 + li];
-            float b[TW];
+            float a_nxt = 0.f, b_nxt[TW];
+            if (kk + 2 < TBK) {
+                a_nxt = a_ptr[(kk + 2) * PA];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b[j] = Bs[(kk + lh) * PB + wn * 32 * TW + 32 * j + li];
+                for (int j = 0; j < TW; ++j) b_nxt[j] = b_ptr[(kk + 2) * PB + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < TW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < TBK) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < TW; ++j) b_cur[j] = b_nxt[j];
+            }
         }
         if (c0 == 0 && tid < TBM) {
 #pragma unroll

@@ -78,18 +78,19 @@ __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
         V acc;
         vset(acc, is_max ? -INFINITY : 0.f);
         int arg_s[4] = {-1, -1, -1, -1};
-        for (int j = beg; j < end; j += 4) {
-            V v[4];
-            int id[4];
+        for (int j = beg; j < end; j += 8) {
+            // eight rows in flight: clamped (unconditional) index and row loads, predicated accumulation
+            V v[8];
+            int id[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j + u < end) {
-                    id[u] = a.list ? a.list[j + u] : j + u;
-                    v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u < end ? j + u : end - 1;
+                id[u] = a.list ? a.list[jj] : jj;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
                 if (j + u < end) {
                     if (is_max) vmax(acc, arg_s, v[u], id[u]);
                     else vadd(acc, v[u]);
