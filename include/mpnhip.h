@@ -143,6 +143,29 @@ size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m);
 int mpnhip_mlp_forward(const mpnhip_mlp* mlp, const float* x, float* y, int64_t m, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The callers' next step, device side, no host sync.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Tracking term of MOTNeuralSolver._compute_loss (pl_module/pl_module.py:88-107):
+ *   loss = weight * sum_{s >= first_step} BCEWithLogits(logits[s], labels, pos_weight = #neg / #pos), mean over edges.
+ * logits [n_steps, E] (every step, as mpnhip_forward returns them), labels [E] in {0,1} (edge_index order),
+ * first_step = num_enc_steps - num_class_steps (steps before it carry no loss).
+ * loss_out [1 + n_steps] (device): total, then per step.  grad_logits [n_steps, E]: d loss / d logits (zeros for
+ * the unclassified steps) -- exactly the grad_logits argument of mpnhip_backward. */
+size_t mpnhip_tracking_loss_workspace_bytes(int n_steps, int64_t n_edges);
+int mpnhip_tracking_loss(const float* logits, const float* labels, int n_steps, int64_t n_edges, int first_step,
+                         float weight, float* loss_out, float* grad_logits, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* compute_perform_metrics (utils/evaluation.py:416-437) on the last step's logits [E] (edge_index order):
+ * counts[0..3] = TP, FP, TN, FN of (logit > 0) vs labels (fast_compute_class_metric, :340-366);
+ * counts[4..5] = nodes whose outgoing / incoming flow exceeds 1, counts[6..7] = nodes that have an outgoing /
+ * incoming constraint (compute_constr_satisfaction_rate, :370-414, undirected_edges = True).
+ * counts: int32[8] on the device; the caller reads them back when it wants the ratios. */
+int mpnhip_step_metrics(const void* graph_buf, int n_nodes, int64_t n_edges, const float* logits, const float* labels,
+                        int32_t* counts, void* stream);
+
 /* nn.AdaptiveAvgPool2d((1,1)) + view (models/mpn.py:252,351-352): x [rows, hw] -> y [rows] = mean over
  * the hw contiguous spatial positions (rows = N * C). */
 int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream);

@@ -63,6 +63,9 @@ SIGNATURES = {
     "mpnhip_linear": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _P]),
     "mpnhip_mlp_workspace_bytes": (_Z, [C.POINTER(Mlp), _L]),
     "mpnhip_mlp_forward": (_I, [C.POINTER(Mlp), _P, _P, _L, _P, _Z, _P]),
+    "mpnhip_tracking_loss_workspace_bytes": (_Z, [_I, _L]),
+    "mpnhip_tracking_loss": (_I, [_P, _P, _I, _L, _I, C.c_float, _P, _P, _P, _Z, _P]),
+    "mpnhip_step_metrics": (_I, [_P, _I, _L, _P, _P, _P, _P]),
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
     "mpnhip_profile_enable": (_I, [_I]),
     "mpnhip_edge_chain_active": (_I, [C.POINTER(Model)]),

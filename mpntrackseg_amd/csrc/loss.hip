@@ -1,0 +1,169 @@
+// The two steps right after the hot path in the reference's training loop, on device
+// and without host synchronisation:
+//   * tracking loss of pl_module.py:88-107: sum over the classified steps of
+//     F.binary_cross_entropy_with_logits(logits_s, edge_labels, pos_weight = #neg / #pos) * loss_weight,
+//     together with d loss / d logits -- the seed of mpnhip_backward;
+//   * compute_perform_metrics (utils/evaluation.py:416-437): confusion counts of (logit > 0) vs labels
+//     (fast_compute_class_metric, :340-366) and the flow-conservation violation counts
+//     (compute_constr_satisfaction_rate, :370-414) as segmented sums over the prepared graph's CSR lists
+//     (the reference sorts every edge's endpoints and scatter-adds).
+#include "common.h"
+
+namespace mpnhip {
+
+__global__ __launch_bounds__(1024) void k_count_pos(const float* __restrict__ labels, int64_t E, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < E; i += 1024) s += labels[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// grid (ceil(E / 256), L)
+__global__ __launch_bounds__(256) void k_bce(const float* __restrict__ logits, const float* __restrict__ labels, int64_t E,
+                                             int first_step, float weight, const float* __restrict__ pos_count,
+                                             float* __restrict__ dlogits, float* __restrict__ partial) {
+    const int step = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float P = pos_count[0];
+    const float pw = P > 0.f ? ((float)E - P) / P : 0.f;  // pl_module.py:92-96
+    float term = 0.f;
+    if (i < E) {
+        float g = 0.f;
+        if (step >= first_step) {
+            const float z = logits[(int64_t)step * E + i], y = labels[i];
+            const float lw = 1.f + (pw - 1.f) * y;
+            // aten's stable form: (1 - y) z + lw (log1p(exp(-|z|)) + max(-z, 0))
+            term = (1.f - y) * z + lw * (log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f));
+            const float sg = z >= 0.f ? 1.f / (1.f + expf(-z)) : expf(z) / (1.f + expf(z));
+            g = (sg * lw - pw * y) * (weight / (float)E);
+        }
+        dlogits[(int64_t)step * E + i] = g;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)step * gridDim.x + blockIdx.x] = red[0];
+}
+
+// one block; loss_out[0] = total, loss_out[1 + s] = weighted mean BCE of step s
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ partial, int nblk, int L, int64_t E, float weight,
+                                                     float* __restrict__ loss_out) {
+    __shared__ double red[256];
+    double total = 0.0;
+    for (int s = 0; s < L; ++s) {
+        double acc = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) acc += (double)partial[(int64_t)s * nblk + b];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        const double ls = red[0] * (double)weight / (double)(E > 0 ? E : 1);
+        if (threadIdx.x == 0) loss_out[1 + s] = (float)ls;
+        total += ls;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = (float)total;
+}
+
+__global__ void k_confusion(const float* __restrict__ logits, const float* __restrict__ labels, int64_t E, int* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const int pred = logits[i] > 0.f, y = labels[i] == 1.f, y0 = labels[i] == 0.f;
+    if (y && pred) atomicAdd(out + 0, 1);        // TP
+    else if (y0 && pred) atomicAdd(out + 1, 1);  // FP
+    else if (y0 && !pred) atomicAdd(out + 2, 1); // TN
+    else if (y && !pred) atomicAdd(out + 3, 1);  // FN
+}
+
+// per node: flow_out = sum of predictions over edges whose SMALLER endpoint is n, flow_in: LARGER endpoint
+__global__ void k_flow_constraints(GraphView g, const float* __restrict__ logits, int* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= g.N) return;
+    const int N = g.N;
+    auto seg_sum = [&](const int* ptr, const int* list, int key, int& cnt) {
+        float s = 0.f;
+        const int b = ptr[key], e = ptr[key + 1];
+        for (int j = b; j < e; ++j) {
+            const int pos = list ? list[j] : j;
+            s += logits[g.perm[pos]] > 0.f ? 1.f : 0.f;
+        }
+        cnt += e - b;
+        return s;
+    };
+    int c_out = 0, c_in = 0;
+    float self_cnt;
+    int c_self = 0;
+    self_cnt = seg_sum(g.seg_ptr, nullptr, 2 * N + n, c_self);
+    const float f_out = (seg_sum(g.seg_ptr, nullptr, n, c_out) + seg_sum(g.cseg_ptr, g.cperm, N + n, c_out) + self_cnt) * 0.5f;
+    const float f_in = (seg_sum(g.seg_ptr, nullptr, N + n, c_in) + seg_sum(g.cseg_ptr, g.cperm, n, c_in) + self_cnt) * 0.5f;
+    c_out += c_self;
+    c_in += c_self;
+    if (f_out > 1.f) atomicAdd(out + 4, 1);
+    if (f_in > 1.f) atomicAdd(out + 5, 1);
+    if (c_out > 0) atomicAdd(out + 6, 1);
+    if (c_in > 0) atomicAdd(out + 7, 1);
+}
+
+}  // namespace mpnhip
+
+using namespace mpnhip;
+
+extern "C" size_t mpnhip_tracking_loss_workspace_bytes(int n_steps, int64_t n_edges) {
+    const size_t nblk = (size_t)((n_edges + 255) / 256);
+    return 256 + align_up((size_t)(n_steps > 0 ? n_steps : 1) * (nblk > 0 ? nblk : 1) * sizeof(float), 256);
+}
+
+extern "C" int mpnhip_tracking_loss(const float* logits, const float* labels, int n_steps, int64_t n_edges, int first_step,
+                                    float weight, float* loss_out, float* grad_logits, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(n_steps >= 1 && n_edges >= 0 && first_step >= 0, "tracking_loss: bad sizes");
+    MPN_CHECK_ARG(loss_out, "tracking_loss: null loss_out");
+    if (n_edges == 0) {
+        MPN_HIP(hipMemsetAsync(loss_out, 0, (size_t)(1 + n_steps) * sizeof(float), s));
+        return MPNHIP_OK;
+    }
+    MPN_CHECK_ARG(logits && labels && grad_logits, "tracking_loss: null tensor");
+    if (!workspace || workspace_bytes < mpnhip_tracking_loss_workspace_bytes(n_steps, n_edges)) {
+        set_error("tracking_loss: workspace %zu < %zu", workspace_bytes, mpnhip_tracking_loss_workspace_bytes(n_steps, n_edges));
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    float* pos = static_cast<float*>(workspace);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    const int nblk = (int)((n_edges + 255) / 256);
+    hipLaunchKernelGGL(k_count_pos, dim3(1), dim3(1024), 0, s, labels, n_edges, pos);
+    MPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bce, dim3(nblk, n_steps), dim3(256), 0, s, logits, labels, n_edges, first_step, weight, pos, grad_logits, partial);
+    MPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, s, partial, nblk, n_steps, n_edges, weight, loss_out);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_step_metrics(const void* graph_buf, int n_nodes, int64_t n_edges, const float* logits, const float* labels,
+                                   int32_t* counts, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(graph_buf && counts, "step_metrics: null pointer");
+    MPN_HIP(hipMemsetAsync(counts, 0, 8 * sizeof(int32_t), s));
+    if (n_edges == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(logits && labels, "step_metrics: null tensor");
+    GraphView g;
+    graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
+    hipLaunchKernelGGL(k_confusion, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, s, logits, labels, n_edges, counts);
+    MPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_flow_constraints, dim3((n_nodes + 255) / 256), dim3(256), 0, s, g, logits, counts);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}

@@ -89,8 +89,12 @@ class TrainStep:
         logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
         ws = native_forward_saved(model, g, x, ea, logits)
         if labels is None:
-            labels = (torch.arange(E, device=x.device) % 7 == 0).float()
-        glog, _ = bce_logits_grad(logits, labels, self.first_class_step)
+            if getattr(self, "_default_labels", None) is None or self._default_labels.numel() != E:
+                self._default_labels = (torch.arange(E, device=x.device) % 7 == 0).float()
+            labels = self._default_labels
+        # reference loss (pl_module.py:88-107) and its gradient w.r.t. every step's logits, natively
+        from .loss import tracking_loss_and_grad
+        self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0)
         self.bucket.zero_()
         native_backward(model, g, x, ea, glog, ws, self.bucket.views)
         allreduce_mean_(self.bucket.flat, self.world_size, self.pg)

@@ -1,0 +1,59 @@
+"""Native tracking loss / step metrics against the CPU restatement of
+pl_module.py:88-107 and utils/evaluation.py:340-437 (oracle/loss_oracle.py; parity unpinned -- see its header)."""
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import synth
+from mpntrackseg_amd.loss import compute_perform_metrics, tracking_loss, tracking_loss_and_grad
+from oracle import loss_oracle as LO
+
+pytestmark = pytest.mark.gpu
+dev = lambda: torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("E,L,frac", [(1, 1, 1.0), (1000, 3, 0.2), (50000, 12, 0.02), (777, 4, 0.0)])
+def test_tracking_loss_and_grad(E, L, frac):
+    logits = torch.from_numpy(synth.normal(3, (L, E), std=3.0))
+    labels = torch.from_numpy((synth.uniform01(4, E) < frac).astype(np.float32))
+    lg = logits.clone().requires_grad_(True)
+    ref = LO.tracking_loss([lg[s].view(E, 1) for s in range(L)], labels, weight=1.0)
+    ref.backward()
+    loss, grad = tracking_loss_and_grad(logits.to(dev()), labels.to(dev()), 0, 1.0)
+    assert abs(float(loss[0]) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert float((grad.cpu() - lg.grad).abs().max()) <= 1e-6 * max(1.0, float(lg.grad.abs().max()))
+    # autograd wrapper over the reference's list-of-[E,1] output
+    lgd = logits.to(dev()).requires_grad_(True)
+    out = tracking_loss([lgd[s].view(E, 1) for s in range(L)], labels.to(dev()))
+    out.backward()
+    assert float((lgd.grad.cpu() - lg.grad).abs().max()) <= 1e-6 * max(1.0, float(lg.grad.abs().max()))
+
+
+def test_unclassified_steps_get_zero_gradient():
+    E, L = 500, 6
+    logits = torch.from_numpy(synth.normal(5, (L, E)))
+    labels = torch.from_numpy((synth.uniform01(6, E) < 0.3).astype(np.float32))
+    loss, grad = tracking_loss_and_grad(logits.to(dev()), labels.to(dev()), 2, 1.0)
+    ref = LO.tracking_loss([logits[s].view(E, 1) for s in range(2, L)], labels)
+    assert abs(float(loss[0]) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert float(grad[:2].abs().max()) == 0.0 and float(grad[2:].abs().max()) > 0.0
+
+
+def test_step_metrics_match_reference_formulas():
+    g = synth.batch_graphs([synth.make_graph(60, 400, T=6, seed=s, node_in_dim=4) for s in (1, 2)])
+    ei = g["edge_index"].copy()
+    ei[:, 3] = [7, 7]  # a self loop
+    E, N = ei.shape[1], 120
+    logit = torch.from_numpy(synth.normal(8, (E, 1)))
+    labels = torch.from_numpy((synth.uniform01(9, E) < 0.25).astype(np.float32))
+
+    class G:
+        pass
+    go = G()
+    go.edge_index = torch.from_numpy(ei).to(dev())
+    go.edge_labels = labels.to(dev())
+    go.num_nodes = N
+    got = compute_perform_metrics({"classified_edges": [logit.to(dev())]}, go)
+    ref = LO.compute_perform_metrics([logit], torch.from_numpy(ei), labels, N)
+    for k in ("accuracy", "recall", "precision", "constr_sr"):
+        assert abs(got[k] - ref[k]) < 1e-6, k
