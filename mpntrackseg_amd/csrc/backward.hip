@@ -111,6 +111,27 @@ static int relu_mask(const float* g, const float* act, float* out, int64_t n, hi
     return MPNHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------ side stream
+// One internal stream + two events per process (one process per GPU), created on the first backward call:
+// the weight-gradient products of the later steps run there, concurrently with the earlier steps' chains.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    int device = -1;
+};
+static SideStream g_side;
+
+static int side_stream_ready() {
+    int dev = -1;
+    MPN_HIP(hipGetDevice(&dev));
+    if (g_side.stream && g_side.device == dev) return MPNHIP_OK;
+    MPN_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    MPN_HIP(hipEventCreateWithFlags(&g_side.ready, hipEventDisableTiming));
+    MPN_HIP(hipEventCreateWithFlags(&g_side.done, hipEventDisableTiming));
+    g_side.device = dev;
+    return MPNHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------ plan
 // Pre-activation gradients (dZ) of EVERY step are kept ([L][rows][width] blocks): the activation-gradient
 // chain of a step reads its predecessor's block, and after the step loop each weight's gradient is ONE
@@ -129,6 +150,7 @@ struct BwdPlan {
     float* T[2];                        // encoder chain scratch [max(E,N), max encoder width]
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
     float* slab;                        // split partials of the weight-gradient products (2 groups)
+    float* slab_side;                   // the same for the products issued on the side stream
     size_t slab_floats_per_group;
     size_t total;
 };
@@ -184,6 +206,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     upd(tn_slab_floats(d.pw, d.kx, N, (int)L));
     p.slab_floats_per_group = sl;
     p.slab = a.f(2 * sl);
+    p.slab_side = a.f(2 * sl);
     p.total = a.off;
     if (out) *out = p;
     return p.total;
@@ -202,7 +225,7 @@ struct Operand {        // one side of a (batched) weight-gradient product
 };
 
 // dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
-static int weight_grad(const BwdPlan& p, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
+static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
                        const int* h_idx, int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2],
                        const RowRange rr[2], int64_t rows, int nbatch, hipStream_t s) {
     TnArgs a = {};
@@ -228,7 +251,7 @@ static int weight_grad(const BwdPlan& p, int ngroups, Operand dZ, const int* dz_
         g.row_begin = rr ? rr[q].begin : nullptr;
         g.row_end = rr ? rr[q].end : nullptr;
         g.m_static = rows;
-        g.slab = p.slab + q * p.slab_floats_per_group;
+        g.slab = slab_base + q * p.slab_floats_per_group;
         g.grad_w = gw[q];
         g.ldw = ldw;
         g.grad_b = gb ? gb[q] : nullptr;
@@ -282,14 +305,14 @@ static int mlp_chain_backward(const mpnhip_mlp& m0, const mpnhip_mlp* m1, float*
 }
 
 // batched weight gradients of layers >= 1 of an MLP whose dZ / hidden blocks repeat every step
-static int mlp_weight_grads(const BwdPlan& p, const mpnhip_mlp& m0, const mpnhip_mlp* m1, float* const* dz_all,
+static int mlp_weight_grads(const BwdPlan& p, float* slab_base, const mpnhip_mlp& m0, const mpnhip_mlp* m1, float* const* dz_all,
                             float* const* hidden0, int64_t hidden_bstride, const RowRange* rr, int64_t rows, int nbatch,
                             hipStream_t s) {
     for (int i = m0.n_layers - 1; i >= 1; --i) {
         const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
         float* gw[2] = {m0.grad_weight[i], m1 ? m1->grad_weight[i] : nullptr};
         float* gb[2] = {m0.grad_bias[i], m1 ? m1->grad_bias[i] : nullptr};
-        MPN_TRY(weight_grad(p, m1 ? 2 : 1, {dz_all[i], n_out, rows * n_out}, nullptr, {hidden0[i - 1], k_in, hidden_bstride},
+        MPN_TRY(weight_grad(p, slab_base, m1 ? 2 : 1, {dz_all[i], n_out, rows * n_out}, nullptr, {hidden0[i - 1], k_in, hidden_bstride},
                             {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, rr, rows, nbatch, s));
     }
     return MPNHIP_OK;
@@ -302,7 +325,7 @@ static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, float* cons
         const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
         float* gw[2] = {m0.grad_weight[i], nullptr};
         float* gb[2] = {m0.grad_bias[i], nullptr};
-        MPN_TRY(weight_grad(p, 1, {*dz, n_out, 0}, nullptr, {hidden[i - 1], k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out,
+        MPN_TRY(weight_grad(p, p.slab, 1, {*dz, n_out, 0}, nullptr, {hidden[i - 1], k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out,
                             k_in, gw, k_in, gb, nullptr, rows, 1, s));
         const float* Wq[2] = {m0.weight[i], nullptr};
         float* dst = p.T[*cur_buf ^ 1];
@@ -403,6 +426,69 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         return MPNHIP_OK;
     };
 
+    // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per
+    // weight (batch index = step - 1).  Issued on `st` with the slab buffer `slab`.
+    auto mp_weight_grads = [&](int b0, int nb, hipStream_t st, float* slab) -> int {
+        if (nb <= 0) return MPNHIP_OK;
+        const int64_t zb = b0;  // first batch
+        {   // node update Linear
+            float* gw[2] = {m.node.grad_weight[0], nullptr};
+            float* gb[2] = {m.node.grad_bias[0], nullptr};
+            MPN_TRY(weight_grad(p, slab, 1, {p.dZn + zb * xs, dn, (int64_t)xs}, nullptr, {f.step0.AGG + zb * sstride, 2 * dn, sstride},
+                                {nullptr, 0, 0}, 2 * dn, nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, nb, st));
+        }
+        if (E > 0) {
+            float* dzfl_b[MPNHIP_MAX_LAYERS];
+            float* dzed_b[MPNHIP_MAX_LAYERS];
+            float* hf_b[MPNHIP_MAX_LAYERS];
+            float* he_b[MPNHIP_MAX_LAYERS];
+            for (int i = 0; i < nfl; ++i) { dzfl_b[i] = p.dZfl[i] + zb * E * m.flow_in.out_dims[i]; hf_b[i] = f.step0.HF[i] ? f.step0.HF[i] + zb * sstride : nullptr; }
+            for (int i = 0; i < ne; ++i) { dzed_b[i] = p.dZed[i] + zb * E * m.edge.out_dims[i]; he_b[i] = f.step0.HE[i] ? f.step0.HE[i] + zb * sstride : nullptr; }
+            MPN_TRY(mlp_weight_grads(p, slab, m.flow_out, &m.flow_in, dzfl_b, hf_b, sstride, dir_rr, E, nb, st));
+            {   // flow layer 0: e-part columns [kx, kx + de) and the bias (folded into P in the forward)
+                float* gw[2] = {m.flow_out.grad_weight[0] + kx, m.flow_in.grad_weight[0] + kx};
+                float* gb[2] = {m.flow_out.grad_bias[0], m.flow_in.grad_bias[0]};
+                MPN_TRY(weight_grad(p, slab, 2, {dzfl_b[0], hn, (int64_t)E * hn}, nullptr, {f.e_hist + es * (zb + 1), de, (int64_t)es},
+                                    {nullptr, 0, 0}, de, nullptr, hn, de, gw, m.flow_out.in_dim, gb, dir_rr, E, nb, st));
+            }
+            // classifier: dZ of the last layer is grad_logits ([L, E], original order -> perm)
+            for (int i = nc - 1; i >= 0; --i) {
+                const int n_out = cls.out_dims[i], k_in = i == 0 ? de : cls.out_dims[i - 1];
+                const bool top = i == nc - 1;
+                float* gw[2] = {cls.grad_weight[i], nullptr};
+                float* gb[2] = {cls.grad_bias[i], nullptr};
+                Operand dz = top ? Operand{grad_logits + zb * E, 1, (int64_t)E} : Operand{p.dZcl[i] + zb * E * n_out, n_out, (int64_t)E * n_out};
+                Operand h = i == 0 ? Operand{f.e_hist + es * (zb + 1), de, (int64_t)es} : Operand{f.step0.HC[i - 1] + zb * sstride, k_in, sstride};
+                MPN_TRY(weight_grad(p, slab, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb,
+                                    nullptr, E, nb, st));
+            }
+            MPN_TRY(mlp_weight_grads(p, slab, m.edge, nullptr, dzed_b, he_b, sstride, nullptr, E, nb, st));
+            {   // edge layer 0: e-part columns [2kx, 2kx + ke) = [e0 | e_{s-1}], and the bias
+                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
+                float* gb[2] = {m.edge.grad_bias[0], nullptr};
+                const bool two = d.ef == 2;
+                Operand h1 = two ? Operand{e0, de, 0} : Operand{f.e_hist + es * zb, de, (int64_t)es};
+                Operand h2 = two ? Operand{f.e_hist + es * zb, de, (int64_t)es} : Operand{nullptr, 0, 0};
+                MPN_TRY(weight_grad(p, slab, 1, {dzed_b[0], he, (int64_t)E * he}, nullptr, h1, h2, de, nullptr, he, ke, gw, m.edge.in_dim,
+                                    gb, nullptr, E, nb, st));
+            }
+        }
+        {   // per-node projections (packed), accumulated into gWnode
+            float* gw[2] = {p.gWnode, nullptr};
+            const bool two = d.nf == 2;
+            Operand h1 = two ? Operand{x0, dn, 0} : Operand{f.x_hist + xs * zb, dn, (int64_t)xs};
+            Operand h2 = two ? Operand{f.x_hist + xs * zb, dn, (int64_t)xs} : Operand{nullptr, 0, 0};
+            MPN_TRY(weight_grad(p, slab, 1, {p.dP + zb * N * pw, pw, (int64_t)N * pw}, nullptr, h1, h2, dn, nullptr, pw, kx, gw, kx, nullptr,
+                                nullptr, N, nb, st));
+        }
+        return MPNHIP_OK;
+    };
+    // Steps L .. fork_at are finished first; their weight gradients then run on a side stream UNDER the remaining
+    // steps' chain kernels (which leave about half of the MFMA pipe idle: 1.5 wave tiles per SIMD at cfg-B).
+    const int fork_at = L / 2 + 1;
+    bool forked = false;
+    const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready() == MPNHIP_OK;
+
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
         const StepBufs b = step_at(f, b_);
@@ -491,53 +577,24 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             }
         }
         cx ^= 1;
+        if (want_fork && step == fork_at) {
+            MPN_HIP(hipEventRecord(g_side.ready, s));
+            MPN_HIP(hipStreamWaitEvent(g_side.stream, g_side.ready, 0));
+            MPN_TRY(mp_weight_grads(fork_at - 1, L - fork_at + 1, g_side.stream, p.slab_side));
+            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
+            forked = true;
+        }
     }
 
     if (L > 0) {
-        // ---- weight gradients of the message-passing modules: one batched product per weight ---------
-        {   // node update Linear
-            float* gw[2] = {m.node.grad_weight[0], nullptr};
-            float* gb[2] = {m.node.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, 1, {p.dZn, dn, (int64_t)xs}, nullptr, {f.step0.AGG, 2 * dn, sstride}, {nullptr, 0, 0}, 2 * dn,
-                                nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, L, s));
+        // second half of the steps (if it was not forked to the side stream already), then join
+        if (forked) {
+            MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));  // the side stream's "+=" into the gradients come first
+            MPN_TRY(mp_weight_grads(0, fork_at - 1, s, p.slab));
+        } else {
+            MPN_TRY(mp_weight_grads(0, L, s, p.slab));
         }
-        if (E > 0) {
-            MPN_TRY(mlp_weight_grads(p, m.flow_out, &m.flow_in, p.dZfl, f.step0.HF, sstride, dir_rr, E, L, s));
-            {   // flow layer 0: e-part columns [kx, kx + de) and the bias (folded into P in the forward)
-                float* gw[2] = {m.flow_out.grad_weight[0] + kx, m.flow_in.grad_weight[0] + kx};
-                float* gb[2] = {m.flow_out.grad_bias[0], m.flow_in.grad_bias[0]};
-                MPN_TRY(weight_grad(p, 2, {p.dZfl[0], hn, (int64_t)E * hn}, nullptr, {f.e_hist + es, de, (int64_t)es}, {nullptr, 0, 0},
-                                    de, nullptr, hn, de, gw, m.flow_out.in_dim, gb, dir_rr, E, L, s));
-            }
-            // classifier: dZ of the last layer is grad_logits ([L, E], original order -> perm)
-            for (int i = nc - 1; i >= 0; --i) {
-                const int n_out = cls.out_dims[i], k_in = i == 0 ? de : cls.out_dims[i - 1];
-                const bool top = i == nc - 1;
-                float* gw[2] = {cls.grad_weight[i], nullptr};
-                float* gb[2] = {cls.grad_bias[i], nullptr};
-                Operand dz = top ? Operand{grad_logits, 1, (int64_t)E} : Operand{p.dZcl[i], n_out, (int64_t)E * n_out};
-                Operand h = i == 0 ? Operand{f.e_hist + es, de, (int64_t)es} : Operand{f.step0.HC[i - 1], k_in, sstride};
-                MPN_TRY(weight_grad(p, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb,
-                                    nullptr, E, L, s));
-            }
-            MPN_TRY(mlp_weight_grads(p, m.edge, nullptr, p.dZed, f.step0.HE, sstride, nullptr, E, L, s));
-            {   // edge layer 0: e-part columns [2kx, 2kx + ke) = [e0 | e_{s-1}], and the bias
-                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
-                float* gb[2] = {m.edge.grad_bias[0], nullptr};
-                const bool two = d.ef == 2;
-                Operand h1 = two ? Operand{e0, de, 0} : Operand{f.e_hist, de, (int64_t)es};
-                Operand h2 = two ? Operand{f.e_hist, de, (int64_t)es} : Operand{nullptr, 0, 0};
-                MPN_TRY(weight_grad(p, 1, {p.dZed[0], he, (int64_t)E * he}, nullptr, h1, h2, de, nullptr, he, ke, gw, m.edge.in_dim,
-                                    gb, nullptr, E, L, s));
-            }
-        }
-        {   // per-node projections (packed [W1r; W1c; Wfo_x; Wfi_x]); their biases were handled above
-            float* gw[2] = {p.gWnode, nullptr};
-            const bool two = d.nf == 2;
-            Operand h1 = two ? Operand{x0, dn, 0} : Operand{f.x_hist, dn, (int64_t)xs};
-            Operand h2 = two ? Operand{f.x_hist, dn, (int64_t)xs} : Operand{nullptr, 0, 0};
-            MPN_TRY(weight_grad(p, 1, {p.dP, pw, (int64_t)N * pw}, nullptr, h1, h2, dn, nullptr, pw, kx, gw, kx, nullptr, nullptr, N,
-                                L, s));
+        {   // unpack the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] (their biases were handled above)
             struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
                 {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
                 {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
@@ -563,7 +620,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             float* gb[2] = {cls.grad_bias[i], nullptr};
             Operand dz = top ? Operand{grad_logits, 1, 0} : Operand{p.dZcl[i], n_out, 0};
             Operand h = i == 0 ? Operand{e0, de, 0} : Operand{b.HC[i - 1], k_in, 0};
-            MPN_TRY(weight_grad(p, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, nullptr,
+            MPN_TRY(weight_grad(p, p.slab, 1, dz, top ? g.perm : nullptr, h, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, nullptr,
                                 E, 1, s));
         }
         // incoming gradients of the final latents ARE gradients of the encoder outputs
@@ -594,7 +651,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             MPN_TRY(mlp_tail_backward(p, en, hid, &dz, &cur, N, s));
             float* gw[2] = {en.grad_weight[0], nullptr};
             float* gb[2] = {en.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, 1, {dz, en.out_dims[0], 0}, nullptr, {x, en.in_dim, 0}, {nullptr, 0, 0}, en.in_dim, nullptr,
+            MPN_TRY(weight_grad(p, p.slab, 1, {dz, en.out_dims[0], 0}, nullptr, {x, en.in_dim, 0}, {nullptr, 0, 0}, en.in_dim, nullptr,
                                 en.out_dims[0], en.in_dim, gw, en.in_dim, gb, nullptr, N, 1, s));
             if (grad_x) {
                 const float* Wq[2] = {en.weight[0], nullptr};
@@ -621,7 +678,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             float* gw[2] = {ee.grad_weight[0], nullptr};
             float* gb[2] = {ee.grad_bias[0], nullptr};
             // layer 0 read edge_attr through the sort permutation
-            MPN_TRY(weight_grad(p, 1, {dz, ee.out_dims[0], 0}, nullptr, {edge_attr, ee.in_dim, 0}, {nullptr, 0, 0}, ee.in_dim,
+            MPN_TRY(weight_grad(p, p.slab, 1, {dz, ee.out_dims[0], 0}, nullptr, {edge_attr, ee.in_dim, 0}, {nullptr, 0, 0}, ee.in_dim,
                                 g.perm, ee.out_dims[0], ee.in_dim, gw, ee.in_dim, gb, nullptr, E, 1, s));
             if (grad_edge_attr) {
                 const float* Wq[2] = {ee.weight[0], nullptr};
