@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := mpntrackseg_amd/csrc
-SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_tn.hip $(CSRC)/edge_chain.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip
+SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_tn.hip $(CSRC)/edge_chain.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/attention.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := $(CSRC)/libmpnhip.so
 CXXFLAGS := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -Wall -Wno-unused-function

@@ -166,6 +166,19 @@ int mpnhip_tracking_loss(const float* logits, const float* labels, int n_steps, 
 int mpnhip_step_metrics(const void* graph_buf, int n_nodes, int64_t n_edges, const float* logits, const float* labels,
                         int32_t* counts, void* stream);
 
+/* Mask branch: the neighbour aggregation of TimeAwareAttentionModel.forward
+ * (models/mpn.py:117-134): per (node, direction) segment w = scatter_softmax(logits) and
+ * out_dir[n] = sum_j w_j x[col_j], x [N, feat] with feat = C*H*W (64*14*14).  logits [E] in edge_index order (the
+ * classifier output of this step); out_in / out_out [N, feat] (flow_in: row > col, flow_out: row < col);
+ * weights [E] (sorted edge order, optional) keeps w for the backward. */
+int mpnhip_attention_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, const float* x, int64_t feat,
+                               const float* logits, float* out_in, float* out_out, float* weights, void* stream);
+/* Its autograd: grad_x [N, feat] (overwritten, or += when accumulate_grad_x) and grad_logits [E] (+=, edge_index
+ * order) from grad_in / grad_out [N, feat]; workspace_dw: E floats. */
+int mpnhip_attention_aggregate_backward(const void* graph_buf, int n_nodes, int64_t n_edges, const float* x, int64_t feat,
+                                        const float* weights, const float* grad_in, const float* grad_out, float* grad_x,
+                                        int accumulate_grad_x, float* grad_logits, float* workspace_dw, void* stream);
+
 /* nn.AdaptiveAvgPool2d((1,1)) + view (models/mpn.py:252,351-352): x [rows, hw] -> y [rows] = mean over
  * the hw contiguous spatial positions (rows = N * C). */
 int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream);

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mpnhip_tracking_loss_workspace_bytes": (_Z, [_I, _L]),
     "mpnhip_tracking_loss": (_I, [_P, _P, _I, _L, _I, C.c_float, _P, _P, _P, _Z, _P]),
     "mpnhip_step_metrics": (_I, [_P, _I, _L, _P, _P, _P, _P]),
+    "mpnhip_attention_aggregate": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
+    "mpnhip_attention_aggregate_backward": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
     "mpnhip_profile_enable": (_I, [_I]),
     "mpnhip_edge_chain_active": (_I, [C.POINTER(Model)]),

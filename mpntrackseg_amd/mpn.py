@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from . import capi
+from .cnn import CNN, MaskRCNNPredictor
 from .mlp import MLP
 
 
@@ -179,13 +180,91 @@ class MLPGraphIndependent(nn.Module):
         return out_edge_feats, out_node_feats
 
 
+class _AttentionAggregate(torch.autograd.Function):
+    """flow_in, flow_out of TimeAwareAttentionModel.forward (mpn.py:117-134) through
+    ``mpnhip_attention_aggregate`` and its hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, g, x, logits):
+        lib = capi.load()
+        xc = capi.f32c(x.detach())
+        lg = capi.f32c(logits.detach()).view(-1)
+        n = xc.shape[0]
+        feat = int(xc[0].numel()) if n else 0
+        flow_in = torch.empty_like(xc)
+        flow_out = torch.empty_like(xc)
+        wts = torch.empty(max(g.E, 1), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device):
+            capi.check(lib.mpnhip_attention_aggregate(capi.ptr(g.buf), g.N, g.E, capi.ptr(xc), feat, capi.ptr(lg),
+                                                      capi.ptr(flow_in), capi.ptr(flow_out), capi.ptr(wts), capi.stream_ptr()),
+                       "mpnhip_attention_aggregate")
+        ctx.g, ctx.feat = g, feat
+        ctx.save_for_backward(xc, wts)
+        ctx.logit_shape = logits.shape
+        return flow_in, flow_out
+
+    @staticmethod
+    def backward(ctx, d_in, d_out):
+        lib = capi.load()
+        xc, wts = ctx.saved_tensors
+        g = ctx.g
+        d_in, d_out = capi.f32c(d_in), capi.f32c(d_out)
+        gx = torch.empty_like(xc) if ctx.needs_input_grad[1] else None
+        gl = torch.zeros(max(g.E, 1), dtype=torch.float32, device=xc.device) if ctx.needs_input_grad[2] else None
+        dw = torch.empty(max(g.E, 1), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device):
+            capi.check(lib.mpnhip_attention_aggregate_backward(capi.ptr(g.buf), g.N, g.E, capi.ptr(xc), ctx.feat, capi.ptr(wts),
+                                                               capi.ptr(d_in), capi.ptr(d_out), capi.ptr(gx), 0, capi.ptr(gl),
+                                                               capi.ptr(dw), capi.stream_ptr()),
+                       "mpnhip_attention_aggregate_backward")
+        return None, gx, (gl[:g.E].view(ctx.logit_shape) if gl is not None else None)
+
+
+class TimeAwareAttentionModel(nn.Module):
+    """mpn.py:102-137.  Like the reference, only ``node_model`` is kept (the two attention MLPs passed to the
+    constructor are never registered there either, mpn.py:106-109)."""
+
+    def __init__(self, node_model, flow_in_attention_model=None, flow_out_attention_model=None):
+        super(TimeAwareAttentionModel, self).__init__()
+        self.node_model = node_model
+
+    def aggregate(self, x, edge_index, dec_edge_feats, holder=None):
+        capi.require_device(x, edge_index, dec_edge_feats)
+        g = _prepared(edge_index, x.shape[0], holder)
+        flow_in, flow_out = _AttentionAggregate.apply(g, x, dec_edge_feats)
+        flow = torch.cat((x, flow_in, flow_out), dim=1)          # mpn.py:136
+        return self.node_model(flow)
+
+    def forward(self, x, edge_index, edge_attr, cls_net):
+        dec_edge_feats, _ = cls_net(edge_attr)                    # mpn.py:114
+        return self.aggregate(x, edge_index, dec_edge_feats), dec_edge_feats
+
+
+class MaskModel(nn.Module):
+    """mpn.py:180-206 (stock convolutions / LayerNorm)."""
+
+    def __init__(self, mask_model_params):
+        super(MaskModel, self).__init__()
+        self.feature_encoder = CNN(**mask_model_params['feature_encoder_feats_dict'])
+        self.layer_norm = nn.LayerNorm([64, 14, 14])
+        self.mask_head = CNN(**mask_model_params['mask_head_feats_dict'])
+        self.mask_predictor = MaskRCNNPredictor(**mask_model_params['mask_predictor_feats_dict'])
+
+    def forward(self, feature_embeds, node_embeds):
+        x = torch.cat((self.feature_encoder(feature_embeds), node_embeds), dim=1)
+        return self.mask_predictor(self.mask_head(self.layer_norm(x)))
+
+
 class MOTMPNet(nn.Module):
     """mpn.py:209-394.  ``MOTMPNet(model_params, bb_encoder=None)``; ``forward(data)`` returns
     ``{'classified_edges': [Tensor[E,1]] * num_class_steps, 'mask_predictions': [...]}``.
 
     The encoder -> message passing -> classifier loop (the hot path) is ONE native call.  The x_ext /
-    attention / mask branch of the reference (mpn.py:102-137,180-206) never feeds back into the edge
-    logits and is not part of this build yet: ``mask_predictions`` is an empty list.
+    attention / mask branch of the reference (mpn.py:102-137,180-206) never feeds back into the edge logits
+    (SURVEY.md section 3.3), so it runs AFTER the hot path, step by step, on the per-step logits: its neighbour
+    aggregation is native (``mpnhip_attention_aggregate``), its convolutions are stock PyTorch-ROCm modules.
+    It is built only when ``model_params`` carries the mask-branch dicts (as configs/tracking_cfg.yaml does) and
+    evaluated only when ``data.x_ext`` is present; otherwise ``mask_predictions`` is an empty list.
     """
 
     def __init__(self, model_params, bb_encoder=None):
@@ -196,7 +275,14 @@ class MOTMPNet(nn.Module):
         classifier_feats_dict = model_params['classifier_feats_dict']
         self.encoder = MLPGraphIndependent(**encoder_feats_dict)
         self.classifier = MLPGraphIndependent(**classifier_feats_dict)
+        self.has_mask_branch = all(k in model_params for k in ('node_ext_encoder_feats_dict', 'mask_model_feats_dict',
+                                                              'node_ext_model_feats_dict'))
+        if self.has_mask_branch:
+            self.node_ext_encoder = CNN(**model_params['node_ext_encoder_feats_dict'])
+            self.mask_predictor = MaskModel(model_params['mask_model_feats_dict'])
         self.MPNet = self._build_core_MPNet(model_params=model_params, encoder_feats_dict=encoder_feats_dict)
+        if self.has_mask_branch:
+            self.MPAttentionNet = self._build_attention_MPNet(model_params=model_params)
         self.num_enc_steps = model_params['num_enc_steps']
         self.num_class_steps = model_params['num_class_steps']
         self.last_logits = None  # [max(L,1), E]: classifier output of every step (the mask branch's input)
@@ -229,6 +315,13 @@ class MOTMPNet(nn.Module):
         return MetaLayer(edge_model=EdgeModel(edge_model=edge_model),
                          node_model=TimeAwareNodeModel(flow_in_model=flow_in_model, flow_out_model=flow_out_model,
                                                        node_model=node_model, node_agg_fn=node_agg_fn))
+
+    def _build_attention_MPNet(self, model_params):
+        """mpn.py:319-331 (the two attention MLPs the reference constructs there are never used nor registered)."""
+        node_ext_model_feats_dict = model_params['node_ext_model_feats_dict']
+        node_ext_model_in_dim = 3 * model_params['node_ext_encoder_feats_dict']['dims'][-1] * self.node_factor
+        node_ext_model = CNN(input_dim=node_ext_model_in_dim, **node_ext_model_feats_dict)
+        return TimeAwareAttentionModel(node_model=node_ext_model)
 
     # ------------------------------------------------------------------ native model description
     def hot_path_parameters(self):
@@ -297,13 +390,27 @@ class MOTMPNet(nn.Module):
         self.last_logits = logits
         E = logits.shape[1]
         L, k = int(self.num_enc_steps), int(self.num_class_steps)
+        x_ext = getattr(data, 'x_ext', None)
+        mask_branch = self.has_mask_branch and x_ext is not None
         outputs_dict = {'classified_edges': [], 'mask_predictions': []}
+        if mask_branch:
+            latent_node_ext_feats = self.node_ext_encoder(x_ext)                       # mpn.py:356
+            initial_node_ext_feats = latent_node_ext_feats
         first_class_step = L - k + 1
         for step in range(1, L + 1):
+            if mask_branch:
+                if self.reattach_initial_nodes:                                         # mpn.py:373
+                    latent_node_ext_feats = torch.cat((initial_node_ext_feats, latent_node_ext_feats), dim=1)
+                latent_node_ext_feats = self.MPAttentionNet.aggregate(latent_node_ext_feats, edge_index,
+                                                                      logits[step - 1], holder=data)   # mpn.py:377
             if step >= first_class_step:
                 outputs_dict['classified_edges'].append(logits[step - 1].view(E, 1))
+                if mask_branch:
+                    outputs_dict['mask_predictions'].append(self.mask_predictor(x_ext, latent_node_ext_feats))
         if L == 0:
             outputs_dict['classified_edges'].append(logits[0].view(E, 1))
+            if mask_branch:
+                outputs_dict['mask_predictions'].append(self.mask_predictor(x_ext, latent_node_ext_feats))
         return outputs_dict
 
 

@@ -115,6 +115,65 @@ def hot_path_param_shapes(p):
     return shapes
 
 
+# mask-branch dicts of the reference config (configs/tracking_cfg.yaml:168-218)
+MASK_PARAMS = {
+    "node_ext_encoder_feats_dict": dict(input_dim=256, dims=[128, 32], kernel_sizes=[1, 1], strides=[1, 1],
+                                        paddings=[0, 0], dropout_p=0, use_batchnorm=False),
+    "attention_model_feats_dict": dict(fc_dims=[16, 1], dropout_p=0, use_batchnorm=False),
+    "node_ext_model_feats_dict": dict(dims=[96, 32], kernel_sizes=[3, 3], strides=[1, 1], paddings=[1, 1],
+                                      dropout_p=0, use_batchnorm=False),
+    "mask_model_feats_dict": {
+        "feature_encoder_feats_dict": dict(input_dim=256, dims=[32], kernel_sizes=[1], strides=[1], paddings=[0],
+                                           dropout_p=0, use_batchnorm=False),
+        "mask_head_feats_dict": dict(input_dim=64, dims=[64, 64, 64], kernel_sizes=[3, 3, 3], strides=[1, 1, 1],
+                                     paddings=[1, 1, 1], dropout_p=0, use_batchnorm=False),
+        "mask_predictor_feats_dict": dict(input_dim=64, dims=[64, 64, 64, 1], kernel_sizes=[2, 3, 2, 1],
+                                          strides=[2, 1, 2, 1], paddings=[0, 1, 0, 0],
+                                          transposed=[True, False, True, False]),
+    },
+}
+
+
+def mask_param_shapes():
+    """{state_dict key: shape} of the mask branch for MASK_PARAMS with reattach_initial_nodes = True
+    (names and shapes as the reference's MOTMPNet.state_dict())."""
+    sh = {}
+
+    def conv(prefix, idx, cout, cin, k, transposed=False):
+        sh[f"{prefix}.layers.{idx}.weight"] = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        sh[f"{prefix}.layers.{idx}.bias"] = (cout,)
+
+    conv("node_ext_encoder", 0, 128, 256, 1)
+    conv("node_ext_encoder", 2, 32, 128, 1)
+    conv("mask_predictor.feature_encoder", 0, 32, 256, 1)
+    sh["mask_predictor.layer_norm.weight"] = (64, 14, 14)
+    sh["mask_predictor.layer_norm.bias"] = (64, 14, 14)
+    for i in (0, 2, 4):
+        conv("mask_predictor.mask_head", i, 64, 64, 3)
+    conv("mask_predictor.mask_predictor", 0, 64, 64, 2, transposed=True)
+    conv("mask_predictor.mask_predictor", 2, 64, 64, 3)
+    conv("mask_predictor.mask_predictor", 4, 64, 64, 2, transposed=True)
+    conv("mask_predictor.mask_predictor", 6, 1, 64, 1)
+    conv("MPAttentionNet.node_model", 0, 96, 192, 3)
+    conv("MPAttentionNet.node_model", 2, 32, 96, 3)
+    return sh
+
+
+def make_mask_weights(seed=17, bias_std=0.05):
+    """He-scale conv weights (std = sqrt(2 / (c_in k k))), LayerNorm weight 1 + N(0, 0.1^2), small biases."""
+    out = {}
+    for i, (k, shp) in enumerate(mask_param_shapes().items()):
+        if "layer_norm.weight" in k:
+            out[k] = (1.0 + normal(seed, shp, stream=i, std=0.1, dtype=np.float64)).astype(np.float32)
+        elif k.endswith(".weight"):
+            transposed = k in ("mask_predictor.mask_predictor.layers.0.weight", "mask_predictor.mask_predictor.layers.4.weight")
+            cin = shp[0] if transposed else shp[1]
+            out[k] = normal(seed, shp, stream=i, std=math.sqrt(2.0 / (cin * shp[2] * shp[3])))
+        else:
+            out[k] = normal(seed, shp, stream=i, std=bias_std)
+    return out
+
+
 def make_weights(p, seed=7, bias_std=0.1, gain=1.0):
     """He-normal weights (std = gain*sqrt(2/fan_in)), biases N(0, bias_std^2); one RNG stream per
     tensor in ``hot_path_param_shapes`` order. Returns {key: float32 ndarray}."""

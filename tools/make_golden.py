@@ -19,6 +19,8 @@ Fixtures:
   g3_cfgB_{agg}.npz            cfg-B (5000/50000/d128/L12): logits at 4096 fixed edges x 12 steps +
                                per-step sum / abs-sum / max checksums.
   g0_l0.npz                    num_enc_steps == 0 special case (mpn.py:387-389).
+  g6_mask_branch.npz           full forward WITH the attention / mask branch (deterministic weights for all 54
+                               tensors): mask predictions + reference-autograd gradients through both branches.
 
 Usage:  python tools/make_golden.py [--only g1,g2,...]
 """
@@ -108,23 +110,7 @@ def import_reference():
     return mpn
 
 
-# mask-branch dicts of configs/tracking_cfg.yaml:168-218 (needed to construct the full MOTMPNet)
-MASK_PARAMS = {
-    "node_ext_encoder_feats_dict": dict(input_dim=256, dims=[128, 32], kernel_sizes=[1, 1], strides=[1, 1],
-                                        paddings=[0, 0], dropout_p=0, use_batchnorm=False),
-    "attention_model_feats_dict": dict(fc_dims=[16, 1], dropout_p=0, use_batchnorm=False),
-    "node_ext_model_feats_dict": dict(dims=[96, 32], kernel_sizes=[3, 3], strides=[1, 1], paddings=[1, 1],
-                                      dropout_p=0, use_batchnorm=False),
-    "mask_model_feats_dict": {
-        "feature_encoder_feats_dict": dict(input_dim=256, dims=[32], kernel_sizes=[1], strides=[1], paddings=[0],
-                                           dropout_p=0, use_batchnorm=False),
-        "mask_head_feats_dict": dict(input_dim=64, dims=[64, 64, 64], kernel_sizes=[3, 3, 3], strides=[1, 1, 1],
-                                     paddings=[1, 1, 1], dropout_p=0, use_batchnorm=False),
-        "mask_predictor_feats_dict": dict(input_dim=64, dims=[64, 64, 64, 1], kernel_sizes=[2, 3, 2, 1],
-                                          strides=[2, 1, 2, 1], paddings=[0, 1, 0, 0],
-                                          transposed=[True, False, True, False]),
-    },
-}
+MASK_PARAMS = synth.MASK_PARAMS  # mask-branch dicts of configs/tracking_cfg.yaml:168-218
 
 
 def build_reference_model(mpn, params, weights):
@@ -203,6 +189,50 @@ def gen_g1(mpn):
             rec["G:" + k] = gr.numpy()
         np.savez_compressed(os.path.join(GOLD, f"g1_tiny_{agg}.npz"), **rec)
         print("g1", agg, "max|logit|", float(np.abs(rec["logits"]).max()))
+
+
+def gen_g6(mpn):
+    """Full MOTMPNet.forward INCLUDING the attention / mask branch with deterministic weights for every parameter:
+    mask_predictions of the classified steps (12 nodes + checksums of all), and reference-autograd gradients of
+    loss = sum logits*r + sum mask_preds*r2 (hot-path parameters, the first attention conv, x_ext)."""
+    N, E, L, nin = 40, 360, 3, 64
+    params = synth.model_params(32, L, "sum", num_class_steps=2, node_in_dim=nin)
+    W = synth.make_weights(params, seed=7)
+    W.update(synth.make_mask_weights(seed=17))
+    full = dict(params)
+    full.update(MASK_PARAMS)
+    model = mpn.MOTMPNet(full)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    g = synth.make_graph(N, E, T=8, seed=4, node_in_dim=nin)
+    d = Data()
+    d.x = torch.from_numpy(g["x"]).view(N, nin, 1, 1)
+    d.x_ext = torch.from_numpy(synth.normal(5, (N, 256, 14, 14), stream=1, std=0.5)).requires_grad_(True)
+    d.edge_index = torch.from_numpy(g["edge_index"])
+    d.edge_attr = torch.from_numpy(g["edge_attr"])
+    out = model(d)
+    masks = out["mask_predictions"]
+    assert len(masks) == 2 and masks[0].shape == (N, 1, 56, 56)
+    r = torch.from_numpy(synth.normal(11, (2, E), stream=0))
+    r2 = torch.from_numpy(synth.normal(12, (2, N, 1, 56, 56), stream=0, std=0.05))
+    loss = sum((out["classified_edges"][s].view(-1) * r[s]).sum() for s in range(2)) + \
+        sum((masks[s] * r2[s]).sum() for s in range(2))
+    names = [k for k in W if k.startswith(("encoder.", "MPNet.", "classifier."))] + ["MPAttentionNet.node_model.layers.0.weight",
+                                                                                    "mask_predictor.mask_head.layers.0.bias"]
+    pd = dict(model.named_parameters())
+    grads = torch.autograd.grad(loss, [pd[k] for k in names] + [d.x_ext])
+    rec = {"N": N, "E": E, "L": L, "node_in_dim": nin,
+           "logits": np.stack([t.detach().numpy().reshape(-1) for t in out["classified_edges"]]),
+           "mask_rows": np.stack([m.detach().numpy()[:12] for m in masks]),
+           "mask_sum": np.array([float(m.detach().double().sum()) for m in masks]),
+           "mask_abssum": np.array([float(m.detach().double().abs().sum()) for m in masks]),
+           "grad_x_ext_rows": grads[-1].numpy()[:4, :8],
+           "grad_x_ext_abssum": np.float64(grads[-1].double().abs().sum())}
+    for k, gr in zip(names, grads[:-1]):
+        a = gr.numpy()
+        rec["G:" + k] = a if a.size < 20000 else a.reshape(-1)[:20000]
+        rec["Gn:" + k] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    np.savez_compressed(os.path.join(GOLD, "g6_mask_branch.npz"), **rec)
+    print("g6 ok; |mask| per step", rec["mask_abssum"])
 
 
 def structure_graph():
@@ -314,7 +344,7 @@ def gen_cfg(mpn, name, tag, sample=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g4,g5,g2,g3")
+    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g2,g3")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     os.makedirs(GOLD, exist_ok=True)
@@ -324,6 +354,7 @@ def main():
     if "g1" in only: gen_g1(mpn)
     if "g4" in only: gen_g4(mpn)
     if "g5" in only: gen_g5(mpn)
+    if "g6" in only: gen_g6(mpn)
     if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
     if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
 
