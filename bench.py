@@ -109,7 +109,11 @@ def main():
     c = synth.CONFIGS[args.config]
     params = synth.model_params(c["d"], c["L"], args.agg)
     W = synth.make_weights(params, seed=7)
-    g = synth.make_graph(c["N"], c["E"], seed=1 + rank)  # one graph (sequence) per rank
+    if c.get("knn"):
+        g = synth.make_knn_graph(seed=1 + rank, **c["knn"])
+        c = dict(c, E=int(g["edge_index"].shape[1]))
+    else:
+        g = synth.make_graph(c["N"], c["E"], seed=1 + rank)  # one graph (sequence) per rank
     model = MOTMPNet(params)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
     model = model.to(dev)

@@ -274,4 +274,6 @@ CONFIGS = {
     "A": dict(N=500, E=4000, d=32, L=6),
     "B": dict(N=5000, E=50000, d=128, L=12),
     "E": dict(N=20000, E=400000, d=256, L=12),
+    # MOTS20-02-like stand-in (SURVEY.md section 8d cfg-C): 20 frames x 25 detections, reciprocal top-150 kNN, reference dims
+    "C": dict(N=500, E=None, d=32, L=12, knn=dict(frames=20, dets=25, top_k=150)),
 }
