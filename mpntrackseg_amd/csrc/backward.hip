@@ -148,6 +148,8 @@ struct BwdPlan {
     float* dZed[MPNHIP_MAX_LAYERS];     // edge MLP layer i:   [L][E, out_i]  (last layer: the masked dE_s)
     float* dZcl[MPNHIP_MAX_LAYERS];     // classifier layer i: [L][E, out_i]  (i < n-1; the last one is grad_logits)
     float* T[2];                        // encoder chain scratch [max(E,N), max encoder width]
+    // zero-padded copies of the per-edge weights for the fused backward chain (native [n][k] orientation)
+    float* wf2p[2]; float* wfep[2]; float* wc1p; float* w2p; float* w1ep;
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
     float* slab;                        // split partials of the weight-gradient products (2 groups)
     float* slab_side;                   // the same for the products issued on the side stream
@@ -193,6 +195,13 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     int64_t rows = E > N ? E : N;
     int mw = enc_maxw(m, d);
     for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
+    {
+        const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
+        for (int q = 0; q < 2; ++q) { p.wf2p[q] = a.f(DN * HN); p.wfep[q] = a.f(HN * DE); }
+        p.wc1p = a.f(32 * DE);
+        p.w2p = a.f(DE * HE);
+        p.w1ep = a.f(HE * 2 * DE);
+    }
     p.gWnode = a.f((size_t)d.pw * d.kx);
     size_t sl = 0;
     auto upd = [&](size_t f) { sl = f > sl ? f : sl; };
@@ -405,7 +414,20 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
 
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
-    const bool use_chain = chain_shapes_ok(m, d);
+    const bool use_chain = chain_shapes_ok(m, d) && E > 0 && L > 0 && !getenv("MPNHIP_NO_CHAIN_BWD");
+    if (use_chain) {
+        const int HE = pad32(he), DE = pad32(de), HN = pad32(hn), DN = pad32(dn);
+        const int KEp = d.ef * DE;
+        const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
+        for (int q = 0; q < 2; ++q) {
+            MPN_TRY(pack_padded(fl[q]->weight[1], hn, 0, dn, hn, p.wf2p[q], DN, HN, HN, 0, s));
+            MPN_TRY(pack_padded(fl[q]->weight[0], fl[q]->in_dim, kx, hn, de, p.wfep[q], HN, DE, DE, 0, s));
+        }
+        MPN_TRY(pack_padded(m.classifier.weight[0], de, 0, m.classifier.out_dims[0], de, p.wc1p, 32, DE, DE, 0, s));
+        MPN_TRY(pack_padded(m.edge.weight[1], he, 0, de, he, p.w2p, DE, HE, HE, 0, s));
+        for (int hlf = 0; hlf < d.ef; ++hlf)
+            MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de, p.w1ep, HE, DE, KEp, hlf * DE, s));
+    }
 
     // activation-gradient chain of the classifier for one step: dz chain blocks in dzc[], final product
     // accumulated into dEdst and masked by `mask` (ReLU of the edge layer that produced ef)
@@ -511,19 +533,18 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             const float* Wq[2] = {m.node.weight[0], nullptr};
             MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
         }
-        if (E > 0 && use_chain && !getenv("MPNHIP_NO_CHAIN_BWD")) {
+        if (use_chain) {
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
             EdgeChainBwdArgs a = {};
             a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0;
+            a.he = he; a.de = de; a.hn = hn; a.dn = dn; a.hc = cls.out_dims[0];
             a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
             a.dAGG = p.dAGG; a.M = b.M; a.ARG = b.ARG; a.HF = b.HF[0]; a.HC = b.HC[0]; a.H1 = b.HE[0]; a.e_s = e_s;
             a.dlog = grad_logits + (size_t)b_ * E;
             a.dE_io = dzed[1]; a.dZM = dzfl[1]; a.dZF = dzfl[0]; a.dZc = dzcl[0]; a.dZ1 = dzed[0];
             a.dE0 = p.dE0; a.dEprev = step == 1 ? p.dE0 : p.dZed[ne - 1] + (size_t)(b_ - 1) * es;
-            a.wf2_out = m.flow_out.weight[1]; a.wf2_in = m.flow_in.weight[1];
-            a.wfe_out = m.flow_out.weight[0] + kx; a.wfe_in = m.flow_in.weight[0] + kx; a.ldwfe = m.flow_out.in_dim;
-            a.wc1 = cls.weight[0]; a.wc2 = cls.weight[1]; a.w2 = m.edge.weight[1];
-            a.w1e = m.edge.weight[0] + 2 * kx; a.ldw1e = m.edge.in_dim;
+            a.wf2_out = p.wf2p[0]; a.wf2_in = p.wf2p[1]; a.wfe_out = p.wfep[0]; a.wfe_in = p.wfep[1];
+            a.wc1 = p.wc1p; a.wc2 = cls.weight[1]; a.w2 = p.w2p; a.w1e = p.w1ep;
             MPN_TRY(launch_edge_chain_bwd(a, s));
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
             MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s));

@@ -6,6 +6,7 @@ namespace mpnhip {
 
 struct EdgeChainArgs {
     int E;                 // edges (sorted order)
+    int he, de, hn, dn, hc;  // real widths; the kernel pads them to multiples of 32 (zero-padded weight images)
     const int* header;     // graph header: [1] = E_out, [2] = E_in
     const int* srow;
     const int* scol;
@@ -16,17 +17,17 @@ struct EdgeChainArgs {
     int k1a, k1b;
     const float* P;        // [N, pw] per-node projections: [Pr (he) | Pc (he) | Pf_out (hn) | Pf_in (hn)]
     int pw;
-    // pre-transposed weight images WT[k][n] and biases
-    const float* w1T;      // [k1a + k1b][he]   edge layer 0, e-part columns
-    const float* w2T;      // [he][de]          edge layer 1
+    // pre-transposed, zero-padded weight images WT[k][n] (capital = width rounded up to 32) and biases
+    const float* w1T;      // [k1a + k1b][HE]   edge layer 0, e-part columns
+    const float* w2T;      // [HE][DE]          edge layer 1
     const float* b2;       // [de]
-    const float* wc1T;     // [de][hc]          classifier layer 0
+    const float* wc1T;     // [DE][32]          classifier layer 0
     const float* bc1;      // [hc]
     const float* wc2;      // [hc]              classifier layer 1 (out dim 1)
     const float* bc2;      // [1]
-    const float* wf1T_out; // [de][hn]          flow_out layer 0, e'-part columns
+    const float* wf1T_out; // [DE][HN]          flow_out layer 0, e'-part columns
     const float* wf1T_in;
-    const float* wf2T_out; // [hn][dn]          flow_out layer 1
+    const float* wf2T_out; // [HN][DN]          flow_out layer 1
     const float* wf2T_in;
     const float* bf2_out;  // [dn]
     const float* bf2_in;
@@ -43,6 +44,7 @@ struct EdgeChainArgs {
 // products of the per-edge modules, with the saved activations as ReLU masks.
 struct EdgeChainBwdArgs {
     int E, N, agg, first_step, cat_two;
+    int he, de, hn, dn, hc;  // real widths
     const int* header;
     const int* srow;
     const int* perm;
@@ -62,20 +64,20 @@ struct EdgeChainBwdArgs {
     float* dZ1;            // [E, he] out
     float* dE0;            // [E, de] accumulated gradient of the re-attached initial edge features
     float* dEprev;         // [E, de] out: gradient w.r.t. e_{s-1} (unused at the first step)
-    // weights in their native nn.Linear layout W[n][k]
-    const float* wf2_out; const float* wf2_in;  // [dn][hn]
-    const float* wfe_out; const float* wfe_in;  // [hn][de] sub-blocks, leading dim ldwfe
-    int ldwfe;
-    const float* wc1;      // [hc][de]
-    const float* wc2;      // [hc]
-    const float* w2;       // [de][he]
-    const float* w1e;      // [he][ke] sub-block, leading dim ldw1e
-    int ldw1e;
+    // zero-padded copies of the weights in their native nn.Linear orientation W[n][k] (capital = padded to 32)
+    const float* wf2_out; const float* wf2_in;  // [DN][HN]
+    const float* wfe_out; const float* wfe_in;  // [HN][DE]   e'-part columns of flow layer 0
+    const float* wc1;      // [32][DE]
+    const float* wc2;      // [hc]   (the model's tensor)
+    const float* w2;       // [DE][HE]
+    const float* w1e;      // [HE][(1 or 2) DE]: e-part columns of edge layer 0, each half padded to DE
 };
 int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s);
 
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
-int transpose_block(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, hipStream_t s);
+int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s);
+int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
+                int dst_c0, hipStream_t s);
 
 }  // namespace mpnhip

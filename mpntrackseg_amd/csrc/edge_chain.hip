@@ -17,8 +17,10 @@
 // Only the WEIGHTS go through LDS: pre-transposed [k][n] images are streamed in <= 20 KB chunks, double
 // buffered, one barrier per chunk, shared by the block's four waves (128 edges of one direction).
 //
-// Instantiated for the BASELINE.json 128-d configuration (he 320, de 64, hn 224, dn 128, hc 32); other
-// widths use the unfused GEMM path.
+// Widths are padded to multiples of 32 inside the kernel (weight images are zero-padded when they are packed, row
+// pieces beyond the real width are masked on load / store), so one template serves the BASELINE.json 128-d
+// configuration (he 320, de 64, hn 224, dn 128, hc 32 -> tiles 10/2/7/4), the reference's shipped 32-d dims
+// (80/16/56/32/8 -> 3/1/2/1) and 64-d (5/1/4/2); anything else uses the unfused GEMM path.
 #include "common.h"
 #include "edge_chain.h"
 
@@ -62,6 +64,20 @@ __device__ __forceinline__ void chunk_store(const ChunkDesc& d, int tid, const C
         const int f = tid + 256 * q;
         if (f < total) *reinterpret_cast<float4*>(buf + 4 * f) = r.v[q];  // image [kc][nc], pitch nc
     }
+}
+
+// 16-byte piece of a feature row at column n (n % 4 == 0, dim % 4 == 0): zero beyond the real width
+template <bool EXACT>
+__device__ __forceinline__ float4 ldrow(const float* row, int n, int dim) {
+    if (EXACT) return ldg4(row + n);  // widths are multiples of 32: nothing to mask
+    const bool ok = n < dim;
+    float4 v = ldg4(row + (ok ? n : 0));
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+template <bool EXACT>
+__device__ __forceinline__ void strow(float* row, int n, int dim, float4 v, bool ok) {
+    if (ok && (EXACT || n < dim)) *reinterpret_cast<float4*>(row + n) = v;
 }
 
 __device__ __forceinline__ void relu16(f32x16& a) {
@@ -135,22 +151,25 @@ __device__ __forceinline__ void chain_half(const f32x16& src, int r0, f32x16* ou
 
 }  // namespace
 
-// T1 = he/32, T2 = de/32, TF = hn/32, TD = dn/32 (hc = 32)
-template <int T1, int T2, int TF, int TD>
-__global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
+// T1 = ceil(he/32), T2 = ceil(de/32), TF = ceil(hn/32), TD = ceil(dn/32); hc <= 32.  Capital names = padded widths
+// (weight-image pitches, loop bounds); A.he / A.de / ... = real widths (global row strides, load / store masks).
+constexpr int chain_waves(int t1) { return t1 <= 3 ? 4 : 2; }  // waves per SIMD the register budget allows
+
+template <int T1, int T2, int TF, int TD, bool EXACT>
+__global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeChainArgs A) {
     constexpr int HE = 32 * T1, DE = 32 * T2, HN = 32 * TF, DN = 32 * TD, HC = 32;
-    constexpr int KC1 = 16;                       // phase-1 chunk: [16 k][HE]   (HE * 16 <= 5120)
-    constexpr int KC2 = 64;                       // phase-2 chunk: [64 k][DE]
-    constexpr int NC4 = 64;                       // phase-4 chunk: [DE k][64 n]
+    constexpr int KC1 = 16;                       // phase-1 chunk: [16 k][HE]
+    constexpr int KC2 = 64;                       // phase-2 chunk: [<=64 k][DE]
+    constexpr int NC4 = 64;                       // phase-4 chunk: [DE k][<=64 n]
     constexpr int KC5 = 32;                       // phase-5 chunk: [32 k][DN]
     static_assert(HE * KC1 <= CH_FLOATS && KC2 * DE <= CH_FLOATS && DE * NC4 <= CH_FLOATS && KC5 * DN <= CH_FLOATS &&
                       DE * HC <= CH_FLOATS, "chunk too large");
-    static_assert(HE % KC2 == 0 && DE % 32 == 0 && T1 % 2 == 0, "dims");
 
     __shared__ __attribute__((aligned(16))) float wbuf[2][CH_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
+    const int he = A.he, de = A.de, hn = A.hn, dn = A.dn, hc = A.hc;
 
     // ---- which direction group / which 128 edges ---------------------------------------------------
     const int e_out = A.header[1], e_in = A.header[2];
@@ -167,12 +186,12 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
     const int edge_raw = tile0 + wave * 32 + lj;
     const bool edge_ok = edge_raw < end;
     const int edge = edge_ok ? edge_raw : end - 1;
-    const int K1 = A.k1a + A.k1b;                 // columns of [e0 | e]
+    const int K1 = A.k1a + A.k1b;                 // columns of [e0 | e] (multiples of 16)
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
 
     // ---- chunk schedule ----------------------------------------------------------------------------
-    constexpr int NCH2 = T2 * 0 + HE / KC2;       // phase 2: HE / 64 chunks, all DE columns each
+    constexpr int NCH2 = (HE + KC2 - 1) / KC2;
     constexpr int NCH4 = (HN + NC4 - 1) / NC4;
     constexpr int NCH5 = HN / KC5;
     const int c2 = nch1, c3 = c2 + NCH2, c4 = c3 + 1, c5 = c4 + NCH4, cend_flow = c5 + NCH5;
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
     auto desc = [&](int c) {
         ChunkDesc d;
         if (c < c2) { d.w = A.w1T; d.ldw = HE; d.k0 = c * KC1; d.kc = KC1; d.n0 = 0; d.nc = HE; }
-        else if (c < c3) { d.w = A.w2T; d.ldw = DE; d.k0 = (c - c2) * KC2; d.kc = KC2; d.n0 = 0; d.nc = DE; }
+        else if (c < c3) { d.w = A.w2T; d.ldw = DE; d.k0 = (c - c2) * KC2; d.kc = HE - d.k0 < KC2 ? HE - d.k0 : KC2; d.n0 = 0; d.nc = DE; }
         else if (c < c4) { d.w = A.wc1T; d.ldw = HC; d.k0 = 0; d.kc = DE; d.n0 = 0; d.nc = HC; }
         else if (c < c5) { d.w = wf1; d.ldw = HN; d.k0 = 0; d.kc = DE; d.n0 = (c - c4) * NC4;
                            d.nc = HN - d.n0 < NC4 ? HN - d.n0 : NC4; }
@@ -205,17 +224,15 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
         ++c;
     };
 
-    // ---- phase 1: H1^T = W1e [e0|e]^T, C-in = Pr[row] + Pc[col] --------------------------------------
+    // ---- phase 1: H1^T = W1e [e0|e]^T, C-in = Pr[row] (+ Pc[col] after the MFMAs) ---------------------------
     const int row = A.srow[edge], col = A.scol[edge];
     f32x16 h1[T1];
     {
-        // C-in = Pr[row]: loaded straight into the accumulators (Pc[col] is added after the MFMAs, when the
-        // weight / input staging registers are free again)
-        const float* pr = A.P + (int64_t)row * A.pw + 4 * lh;
+        const float* pr = A.P + (int64_t)row * A.pw;
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) set4(h1[t], g, ldg4(pr + 32 * t + 8 * g));
+            for (int g = 0; g < 4; ++g) set4(h1[t], g, ldrow<EXACT>(pr, 32 * t + 8 * g + 4 * lh, he));
     }
     {
         // lane (j, h) reads its edge's features 16 bytes at a time: k = 8u + 4h + (0..3)
@@ -253,25 +270,27 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
         }
     }
     {
-        const float* pc = A.P + (int64_t)col * A.pw + HE + 4 * lh;
+        const float* pc = A.P + (int64_t)col * A.pw + he;
+        float* sv = A.save_h1 ? A.save_h1 + (int64_t)edge * he : nullptr;
 #pragma unroll
         for (int t = 0; t < T1; t += 2) {
             __builtin_amdgcn_sched_barrier(0);  // two tiles (8 row pieces) of gathers in flight at a time
-            float4 v[8];
+            constexpr int NP = 8;
+            float4 v[NP];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) v[g] = ldg4(pc + 32 * (t + (g >> 2)) + 8 * (g & 3));
+            for (int g = 0; g < NP; ++g)
+                if (t + (g >> 2) < T1) v[g] = ldrow<EXACT>(pc, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
 #pragma unroll
-            for (int g = 0; g < 8; ++g) add4(h1[t + (g >> 2)], g & 3, v[g]);
+            for (int g = 0; g < NP; ++g)
+                if (t + (g >> 2) < T1) add4(h1[t + (g >> 2)], g & 3, v[g]);
             relu16(h1[t]);
-            relu16(h1[t + 1]);
+            if (t + 1 < T1) relu16(h1[t + 1]);
+            if (sv) {
+#pragma unroll
+                for (int g = 0; g < NP; ++g)
+                    if (t + (g >> 2) < T1) strow<EXACT>(sv, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[t + (g >> 2)], g & 3), edge_ok);
+            }
         }
-    }
-    if (A.save_h1 && edge_ok) {
-        float* o = A.save_h1 + (int64_t)edge * HE + 4 * lh;
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = get4(h1[t], g);
     }
 
     // ---- phase 2: e'^T = relu(W2 H1^T + b2) -----------------------------------------------------------
@@ -279,51 +298,51 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
 #pragma unroll
     for (int t = 0; t < T2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) set4(en[t], g, ldg4(A.b2 + 32 * t + 8 * g + 4 * lh));
+        for (int g = 0; g < 4; ++g) set4(en[t], g, ldrow<EXACT>(A.b2, 32 * t + 8 * g + 4 * lh, de));
 #pragma unroll
     for (int i = 0; i < NCH2; ++i) {
         prefetch();
         const float* ws = wbuf[c & 1];
         chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
-        chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
+        if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
         commit();
     }
+    {
+        float* o = A.e_new + (int64_t)edge * de;
 #pragma unroll
-    for (int t = 0; t < T2; ++t) relu16(en[t]);
-    if (edge_ok) {
-        float* o = A.e_new + (int64_t)edge * DE + 4 * lh;
+        for (int t = 0; t < T2; ++t) {
+            relu16(en[t]);
 #pragma unroll
-        for (int t = 0; t < T2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = get4(en[t], g);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, de, get4(en[t], g), edge_ok);
+        }
     }
 
     // ---- phase 3: classifier ----------------------------------------------------------------------------
     {
-        f32x16 hc;
+        f32x16 hcv;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) set4(hc, g, ldg4(A.bc1 + 8 * g + 4 * lh));
+        for (int g = 0; g < 4; ++g) set4(hcv, g, ldrow<EXACT>(A.bc1, 8 * g + 4 * lh, hc));
         prefetch();
         {
             const float* ws = wbuf[c & 1];
 #pragma unroll
-            for (int t = 0; t < T2; ++t) chain_tile<1>(en[t], &hc, ws, HC, 32 * t, 0, 4 * lh * HC + lj);
+            for (int t = 0; t < T2; ++t) chain_tile<1>(en[t], &hcv, ws, HC, 32 * t, 0, 4 * lh * HC + lj);
         }
         commit();
-        relu16(hc);
-        if (A.save_hc && edge_ok) {
-            float* o = A.save_hc + (int64_t)edge * HC + 4 * lh;
+        relu16(hcv);
+        if (A.save_hc) {
+            float* o = A.save_hc + (int64_t)edge * hc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 8 * g) = get4(hc, g);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o, 8 * g + 4 * lh, hc, get4(hcv, g), edge_ok);
         }
         float part = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 w = ldg4(A.wc2 + 8 * g + 4 * lh);
-            part = fmaf(w.x, hc[4 * g + 0], part);
-            part = fmaf(w.y, hc[4 * g + 1], part);
-            part = fmaf(w.z, hc[4 * g + 2], part);
-            part = fmaf(w.w, hc[4 * g + 3], part);
+            const float4 w = ldrow<EXACT>(A.wc2, 8 * g + 4 * lh, hc);
+            part = fmaf(w.x, hcv[4 * g + 0], part);
+            part = fmaf(w.y, hcv[4 * g + 1], part);
+            part = fmaf(w.z, hcv[4 * g + 2], part);
+            part = fmaf(w.w, hcv[4 * g + 3], part);
         }
         const float other = __shfl_xor(part, 32, 64);
         if (A.logits && edge_ok && lh == 0) A.logits[A.perm[edge]] = part + other + A.bc2[0];
@@ -333,11 +352,11 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
     // ---- phase 4: HF^T = relu(Wfe e'^T + Pf[col]) ---------------------------------------------------------
     f32x16 hf[TF];
     {
-        const float* pf = A.P + (int64_t)col * A.pw + 2 * HE + grp * HN + 4 * lh;
+        const float* pf = A.P + (int64_t)col * A.pw + 2 * he + grp * hn;
 #pragma unroll
         for (int t = 0; t < TF; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) set4(hf[t], g, ldg4(pf + 32 * t + 8 * g));
+            for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
     }
 #pragma unroll
     for (int i = 0; i < NCH4; ++i) {
@@ -352,24 +371,26 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
         }
         commit();
     }
+    {
+        float* o = A.save_hf ? A.save_hf + (int64_t)edge * hn : nullptr;
 #pragma unroll
-    for (int t = 0; t < TF; ++t) relu16(hf[t]);
-    if (A.save_hf && edge_ok) {
-        float* o = A.save_hf + (int64_t)edge * HN + 4 * lh;
+        for (int t = 0; t < TF; ++t) {
+            relu16(hf[t]);
+            if (o) {
 #pragma unroll
-        for (int t = 0; t < TF; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = get4(hf[t], g);
+                for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, hn, get4(hf[t], g), edge_ok);
+            }
+        }
     }
 
     // ---- phase 5: M^T = relu(Wf2 HF^T + bf2) -----------------------------------------------------------------
     f32x16 mm[TD];
     {
-        const float* bf2 = (grp == 1 ? A.bf2_in : A.bf2_out) + 4 * lh;
+        const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
 #pragma unroll
         for (int t = 0; t < TD; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) set4(mm[t], g, ldg4(bf2 + 32 * t + 8 * g));
+            for (int g = 0; g < 4; ++g) set4(mm[t], g, ldrow<EXACT>(bf2, 32 * t + 8 * g + 4 * lh, dn));
     }
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
@@ -378,40 +399,39 @@ __global__ __launch_bounds__(256, 2) void edge_chain_kernel(EdgeChainArgs A) {
         chain_tile<TD>(hf[i], mm, ws, DN, 0, 0, 4 * lh * DN + lj);
         commit();
     }
-    if (edge_ok) {
-        float* o = A.msg + (int64_t)edge * DN + 4 * lh;
+    {
+        float* o = A.msg + (int64_t)edge * dn;
 #pragma unroll
         for (int t = 0; t < TD; ++t) {
             relu16(mm[t]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = get4(mm[t], g);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, dn, get4(mm[t], g), edge_ok);
         }
     }
 }
 
-
 // ------------------------------------------------------------------------------------------------------
 // Backward chain of one step.  Same machinery, transposed weights: dH^T[k][edge] = sum_n W[n][k] dZ^T[n][edge],
-// so the LDS chunk image is W in its native [n][k] layout (rows = contraction index).
+// so the LDS chunk image is W in its native [n][k] layout (rows = contraction index), zero-padded to multiples of 32.
 //   B1  dZM = gather(dAGG)[row] (.) [M > 0]                      (node_agg_fn backward, mpn.py:89,96)
 //   B2  dZF = (Wf2^T dZM) (.) [HF > 0]
 //   B3  dE' = dE_in + Wfe^T dZF
 //   B4  dZc = (dlog wc2) (.) [HC > 0];  dE' += Wc1^T dZc;  dZ2 = dE' (.) [e_s > 0]
 //   B5  dZ1 = (W2^T dZ2) (.) [H1 > 0]
 //   B6  d[e0 | e_{s-1}] = W1e^T dZ1  ->  dE0 += ..., dEprev = ...
-template <int T1, int T2, int TF, int TD>
-__global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs A) {
+template <int T1, int T2, int TF, int TD, bool EXACT>
+__global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(EdgeChainBwdArgs A) {
     constexpr int HE = 32 * T1, DE = 32 * T2, HN = 32 * TF, DN = 32 * TD, HC = 32;
     constexpr int NR2 = 16;   // B2 chunk: [16 n][HN]
-    constexpr int NR3 = 64;   // B3 chunk: [64 n][DE]
+    constexpr int NR3 = 64;   // B3 chunk: [<=64 n][DE]
     constexpr int NR5 = 16;   // B5 chunk: [16 n][HE]
-    constexpr int NR6 = 64;   // B6 chunk: [64 n][64 k]
+    constexpr int NR6 = 64;   // B6 chunk: [<=64 n][64 k]
     static_assert(NR2 * HN <= CH_FLOATS && NR3 * DE <= CH_FLOATS && NR5 * HE <= CH_FLOATS && NR6 * 64 <= CH_FLOATS, "chunk");
-    static_assert(DN % NR2 == 0 && DE % NR5 == 0 && HE % NR6 == 0, "dims");
 
     __shared__ __attribute__((aligned(16))) float wbuf[2][CH_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
+    const int he = A.he, de = A.de, hn = A.hn, dn = A.dn, hc = A.hc;
 
     const int e_out = A.header[1], e_in = A.header[2];
     int grp, beg, end, blk = blockIdx.x;
@@ -427,11 +447,12 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
     const bool edge_ok = edge_raw < end;
     const int edge = edge_ok ? edge_raw : end - 1;
     const bool flow = grp < 2;
-    const int KE = A.cat_two ? 2 * DE : DE;   // columns of [e0 | e_{s-1}]
-    const int npass6 = KE / 64;               // B6 passes of 64 output columns
+    const int KEp = A.cat_two ? 2 * DE : DE;  // padded columns of [e0 | e_{s-1}] (each half padded to DE)
+    const int npass6 = KEp / 64 > 0 ? KEp / 64 : 1;
+    const int ncol6 = KEp < 64 ? KEp : 64;    // columns per B6 pass
 
     // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6 ------------------------------------------
-    constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = HE / NR6;
+    constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
     const int c3 = flow ? NCH2 : 0, c4 = c3 + (flow ? NCH3 : 0), c5 = c4 + 1, c6 = c5 + NCH5;
     const int nchunks = c6 + npass6 * NCH6;
     const float* wf2 = grp == 1 ? A.wf2_in : A.wf2_out;
@@ -439,10 +460,11 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
     auto desc = [&](int c) {
         ChunkDesc d;
         if (c < c3) { d.w = wf2; d.ldw = HN; d.k0 = c * NR2; d.kc = NR2; d.n0 = 0; d.nc = HN; }
-        else if (c < c4) { d.w = wfe; d.ldw = A.ldwfe; d.k0 = (c - c3) * NR3; d.kc = HN - d.k0 < NR3 ? HN - d.k0 : NR3; d.n0 = 0; d.nc = DE; }
+        else if (c < c4) { d.w = wfe; d.ldw = DE; d.k0 = (c - c3) * NR3; d.kc = HN - d.k0 < NR3 ? HN - d.k0 : NR3; d.n0 = 0; d.nc = DE; }
         else if (c < c5) { d.w = A.wc1; d.ldw = DE; d.k0 = 0; d.kc = HC; d.n0 = 0; d.nc = DE; }
         else if (c < c6) { d.w = A.w2; d.ldw = HE; d.k0 = (c - c5) * NR5; d.kc = NR5; d.n0 = 0; d.nc = HE; }
-        else { const int q = c - c6; d.w = A.w1e; d.ldw = A.ldw1e; d.k0 = (q % NCH6) * NR6; d.kc = NR6; d.n0 = (q / NCH6) * 64; d.nc = 64; }
+        else { const int q = c - c6; d.w = A.w1e; d.ldw = KEp; d.k0 = (q % NCH6) * NR6; d.kc = HE - d.k0 < NR6 ? HE - d.k0 : NR6;
+               d.n0 = (q / NCH6) * 64; d.nc = ncol6; }
         return d;
     };
     ChunkRegs creg;
@@ -461,13 +483,13 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
 
     // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators (loaded after B2, when the
     // dZM tiles are dead -- B2 is the register peak of this kernel)
-    f32x16 de[T2];
+    f32x16 dE[T2];
     auto load_de = [&]() {
-        const float* p = A.dE_io + (int64_t)edge * DE + 4 * lh;
+        const float* p = A.dE_io + (int64_t)edge * de;
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) set4(de[t], g, ldg4(p + 32 * t + 8 * g));
+            for (int g = 0; g < 4; ++g) set4(dE[t], g, ldrow<EXACT>(p, 32 * t + 8 * g + 4 * lh, de));
     };
     __syncthreads();  // chunk 0 is in wbuf[0]
 
@@ -476,38 +498,34 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
         f32x16 dzm[TD];
         {
             const int row = A.srow[edge];
-            const int64_t o = (int64_t)row * 2 * DN + (grp == 0 ? DN : 0) + 4 * lh;
+            const float* da = A.dAGG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0);
+            const int* ar = A.ARG ? A.ARG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0) : nullptr;
             float scale = 1.f;
             if (A.agg == MPNHIP_AGG_MEAN) {
                 const int key = grp * A.N + row;
                 const int cnt = A.seg_ptr[key + 1] - A.seg_ptr[key];
-                scale = 1.f / 1.f;  // (placeholder keeps the division below exact: v / cnt, as the reference divides)
                 scale = (float)(cnt > 0 ? cnt : 1);
             }
-            const float* mp = A.M + (int64_t)edge * DN + 4 * lh;
+            const float* mp = A.M + (int64_t)edge * dn;
+            float* o2 = A.dZM + (int64_t)edge * dn;
 #pragma unroll
             for (int t = 0; t < TD; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 v = ldg4(A.dAGG + o + 32 * t + 8 * g);
-                    const float4 m = ldg4(mp + 32 * t + 8 * g);
+                    const int n = 32 * t + 8 * g + 4 * lh;
+                    float4 v = ldrow<EXACT>(da, n, dn);
+                    const float4 m = ldrow<EXACT>(mp, n, dn);
                     if (A.agg == MPNHIP_AGG_MEAN) { v.x /= scale; v.y /= scale; v.z /= scale; v.w /= scale; }
                     if (A.agg == MPNHIP_AGG_MAX) {
-                        const int4 a = *reinterpret_cast<const int4*>(A.ARG + o + 32 * t + 8 * g);
+                        const int4 a = *reinterpret_cast<const int4*>(ar + (n < dn ? n : 0));
                         v.x = a.x == edge_raw ? v.x : 0.f; v.y = a.y == edge_raw ? v.y : 0.f;
                         v.z = a.z == edge_raw ? v.z : 0.f; v.w = a.w == edge_raw ? v.w : 0.f;
                     }
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
                     v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                     set4(dzm[t], g, v);
+                    strow<EXACT>(o2, n, dn, v, edge_ok);
                 }
-            if (edge_ok) {
-                float* o2 = A.dZM + (int64_t)edge * DN + 4 * lh;
-#pragma unroll
-                for (int t = 0; t < TD; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = get4(dzm[t], g);
-            }
         }
         // ---- B2: dZF = (Wf2^T dZM) (.) [HF > 0] -------------------------------------------------------------
         f32x16 dzf[TF];
@@ -523,18 +541,19 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
             commit();
         }
         {
-            const float* hp = A.HF + (int64_t)edge * HN + 4 * lh;
-            float* o2 = A.dZF + (int64_t)edge * HN + 4 * lh;
+            const float* hp = A.HF + (int64_t)edge * hn;
+            float* o2 = A.dZF + (int64_t)edge * hn;
 #pragma unroll
             for (int t = 0; t < TF; ++t) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 m = ldg4(hp + 32 * t + 8 * g);
+                    const int n = 32 * t + 8 * g + 4 * lh;
+                    const float4 m = ldrow<EXACT>(hp, n, hn);
                     float4 v = get4(dzf[t], g);
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
                     v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                     set4(dzf[t], g, v);
-                    if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = v;
+                    strow<EXACT>(o2, n, hn, v, edge_ok);
                 }
             }
         }
@@ -544,8 +563,8 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
         for (int i = 0; i < NCH3; ++i) {
             prefetch();
             const float* ws = wbuf[c & 1];
-            chain_tile<T2>(dzf[2 * i], de, ws, DE, 0, 0, 4 * lh * DE + lj);
-            if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], de, ws, DE, 32, 0, 4 * lh * DE + lj);
+            chain_tile<T2>(dzf[2 * i], dE, ws, DE, 0, 0, 4 * lh * DE + lj);
+            if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], dE, ws, DE, 32, 0, 4 * lh * DE + lj);
             commit();
         }
     }
@@ -555,35 +574,38 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
     {
         f32x16 dzc;
         const float dl = A.dlog[A.perm[edge]];
-        const float* hp = A.HC + (int64_t)edge * HC + 4 * lh;
+        const float* hp = A.HC + (int64_t)edge * hc;
+        float* o2 = A.dZc + (int64_t)edge * hc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 w = ldg4(A.wc2 + 8 * g + 4 * lh);
-            const float4 m = ldg4(hp + 8 * g);
+            const int n = 8 * g + 4 * lh;
+            const float4 w = ldrow<EXACT>(A.wc2, n, hc);
+            const float4 m = ldrow<EXACT>(hp, n, hc);
             float4 v;
             v.x = m.x > 0.f ? dl * w.x : 0.f; v.y = m.y > 0.f ? dl * w.y : 0.f;
             v.z = m.z > 0.f ? dl * w.z : 0.f; v.w = m.w > 0.f ? dl * w.w : 0.f;
             set4(dzc, g, v);
-            if (edge_ok) *reinterpret_cast<float4*>(A.dZc + (int64_t)edge * HC + 4 * lh + 8 * g) = v;
+            strow<EXACT>(o2, n, hc, v, edge_ok);
         }
         prefetch();
-        chain_tile<T2>(dzc, de, wbuf[c & 1], DE, 0, 0, 4 * lh * DE + lj);
+        chain_tile<T2>(dzc, dE, wbuf[c & 1], DE, 0, 0, 4 * lh * DE + lj);
         commit();
     }
     // dZ2 = dE' (.) [e_s > 0]  (written over the incoming gradient)
     {
-        const float* ep = A.e_s + (int64_t)edge * DE + 4 * lh;
-        float* o2 = A.dE_io + (int64_t)edge * DE + 4 * lh;
+        const float* ep = A.e_s + (int64_t)edge * de;
+        float* o2 = A.dE_io + (int64_t)edge * de;
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 m = ldg4(ep + 32 * t + 8 * g);
-                float4 v = get4(de[t], g);
+                const int n = 32 * t + 8 * g + 4 * lh;
+                const float4 m = ldrow<EXACT>(ep, n, de);
+                float4 v = get4(dE[t], g);
                 v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
                 v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                set4(de[t], g, v);
-                if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * t + 8 * g) = v;
+                set4(dE[t], g, v);
+                strow<EXACT>(o2, n, de, v, edge_ok);
             }
     }
 
@@ -596,32 +618,36 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
         prefetch();
-        // two half-width sweeps over the same chunk keep the weight staging registers at T1 / 2 per step
-        chain_half<T1 / 2>(de[i >> 1], (i & 1) * 8, dz1, wbuf[c & 1], HE, 4 * lh * HE + lj);
-        chain_half<T1 / 2>(de[i >> 1], (i & 1) * 8, dz1 + T1 / 2, wbuf[c & 1], HE, 4 * lh * HE + lj + 16 * T1);
+        // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
+        constexpr int TA = (T1 + 1) / 2, TB = T1 - TA;
+        chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf[c & 1], HE, 4 * lh * HE + lj);
+        if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf[c & 1], HE, 4 * lh * HE + lj + 32 * TA);
         commit();
     }
     {
-        const float* hp = A.H1 + (int64_t)edge * HE + 4 * lh;
-        float* o2 = A.dZ1 + (int64_t)edge * HE + 4 * lh;
+        const float* hp = A.H1 + (int64_t)edge * he;
+        float* o2 = A.dZ1 + (int64_t)edge * he;
 #pragma unroll
         for (int t = 0; t < T1; t += 2) {
             __builtin_amdgcn_sched_barrier(0);
             float4 m[8];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) m[g] = ldg4(hp + 32 * (t + (g >> 2)) + 8 * (g & 3));
+            for (int g = 0; g < 8; ++g)
+                if (t + (g >> 2) < T1) m[g] = ldrow<EXACT>(hp, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                float4 v = get4(dz1[t + (g >> 2)], g & 3);
-                v.x = m[g].x > 0.f ? v.x : 0.f; v.y = m[g].y > 0.f ? v.y : 0.f;
-                v.z = m[g].z > 0.f ? v.z : 0.f; v.w = m[g].w > 0.f ? v.w : 0.f;
-                set4(dz1[t + (g >> 2)], g & 3, v);
-                if (edge_ok) *reinterpret_cast<float4*>(o2 + 32 * (t + (g >> 2)) + 8 * (g & 3)) = v;
+                if (t + (g >> 2) < T1) {
+                    float4 v = get4(dz1[t + (g >> 2)], g & 3);
+                    v.x = m[g].x > 0.f ? v.x : 0.f; v.y = m[g].y > 0.f ? v.y : 0.f;
+                    v.z = m[g].z > 0.f ? v.z : 0.f; v.w = m[g].w > 0.f ? v.w : 0.f;
+                    set4(dz1[t + (g >> 2)], g & 3, v);
+                    strow<EXACT>(o2, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, v, edge_ok);
+                }
             }
         }
     }
 
-    // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, 64 output columns per pass ---------------------------------------------------
+    // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, up to 64 (padded) output columns per pass ---------------------------------
     for (int pass = 0; pass < npass6; ++pass) {
         f32x16 dc[2];
 #pragma unroll
@@ -632,64 +658,122 @@ __global__ __launch_bounds__(256, 2) void edge_chain_bwd_kernel(EdgeChainBwdArgs
         for (int i = 0; i < NCH6; ++i) {
             prefetch();
             const float* ws = wbuf[c & 1];
-            chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
-            chain_tile<2>(dz1[2 * i + 1], dc, ws, 64, 32, 0, 4 * lh * 64 + lj);
+            if (ncol6 == 64) {
+                chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
+                if (2 * i + 1 < T1) chain_tile<2>(dz1[2 * i + 1], dc, ws, 64, 32, 0, 4 * lh * 64 + lj);
+            } else {
+                chain_tile<1>(dz1[2 * i], dc, ws, 32, 0, 0, 4 * lh * 32 + lj);
+                if (2 * i + 1 < T1) chain_tile<1>(dz1[2 * i + 1], dc, ws, 32, 32, 0, 4 * lh * 32 + lj);
+            }
             commit();
         }
-        // pass 0 of a two-segment input is the re-attached initial features (accumulated over all steps);
-        // the last pass is e_{s-1} -- which IS e0 at the first step
-        const bool to_e0 = (A.cat_two && pass == 0) || A.first_step;
-        float* dst = (to_e0 ? A.dE0 : A.dEprev) + (int64_t)edge * DE + 4 * lh;
-        if (edge_ok) {
+        // output tile tt (32 padded columns) of the pass belongs to half tt / T2 of [e0 | e_{s-1}], tile tt % T2 in it;
+        // the first half is the re-attached initial features (accumulated over all steps), the second e_{s-1} --
+        // which IS e0 at the first step
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            const int tt = pass * 2 + t;
+            if (tt * 32 >= KEp) break;
+            const int half = tt / T2, tin = tt % T2;
+            const bool to_e0 = (A.cat_two && half == 0) || A.first_step;
+            float* dst = (to_e0 ? A.dE0 : A.dEprev) + (int64_t)edge * de;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 v = get4(dc[t], g);
-                    if (to_e0) {
-                        const float4 o = ldg4(dst + 32 * t + 8 * g);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *reinterpret_cast<float4*>(dst + 32 * t + 8 * g) = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * tin + 8 * g + 4 * lh;
+                float4 v = get4(dc[t], g);
+                if (to_e0) {
+                    const float4 o = ldrow<EXACT>(dst, n, de);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
+                strow<EXACT>(dst, n, de, v, edge_ok);
+            }
         }
     }
 }
 
-int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s) {
-    if (a.E <= 0) return MPNHIP_OK;
-    const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
-    hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4>), dim3(blocks), dim3(256), 0, s, a);
-    MPN_LAUNCH_CHECK();
-    return MPNHIP_OK;
-}
-
-// WT[k][n] = W[n][k0 + k]   (n < n_rows, k < k_cols), W leading dim ldw
-__global__ void k_transpose_block(const float* __restrict__ W, int64_t ldw, int k0, int n_rows, int k_cols,
-                                  float* __restrict__ WT) {
+// dst[r][c] = (r < rows && c < cols) ? src[r * lds + c0 + c] : 0   for r < rows_pad, c < cols_pad (ld = cols_pad)
+__global__ void k_pack_padded(const float* __restrict__ src, int64_t lds, int c0, int rows, int cols, float* __restrict__ dst,
+                              int rows_pad, int cols_pad, int ldd, int dst_c0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_rows * k_cols) return;
-    const int k = (int)(i / n_rows), n = (int)(i % n_rows);
-    WT[i] = W[(int64_t)n * ldw + k0 + k];
+    if (i >= (int64_t)rows_pad * cols_pad) return;
+    const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+    dst[(int64_t)r * ldd + dst_c0 + c] = (r < rows && c < cols) ? src[(int64_t)r * lds + c0 + c] : 0.f;
 }
 
-int transpose_block(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, hipStream_t s) {
-    const int64_t n = (int64_t)n_rows * k_cols;
+// dst[k][n] = (k < k_cols && n < n_rows) ? W[n * ldw + k0 + k] : 0   for k < k_pad, n < n_pad  (transposed, padded)
+__global__ void k_transpose_padded(const float* __restrict__ W, int64_t ldw, int k0, int n_rows, int k_cols,
+                                   float* __restrict__ WT, int n_pad, int k_pad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_pad * k_pad) return;
+    const int k = (int)(i / n_pad), n = (int)(i % n_pad);
+    WT[i] = (k < k_cols && n < n_rows) ? W[(int64_t)n * ldw + k0 + k] : 0.f;
+}
+
+int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s) {
+    const int64_t n = (int64_t)n_pad * k_pad;
     if (n <= 0) return MPNHIP_OK;
-    hipLaunchKernelGGL(k_transpose_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, k0, n_rows, k_cols, WT);
+    hipLaunchKernelGGL(k_transpose_padded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, k0, n_rows, k_cols, WT, n_pad, k_pad);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
+}
+
+int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
+                int dst_c0, hipStream_t s) {
+    const int64_t n = (int64_t)rows_pad * cols_pad;
+    if (n <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_pack_padded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, c0, rows, cols, dst, rows_pad,
+                       cols_pad, ldd, dst_c0);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+static int chain_variant(int he, int de, int hn, int dn) {
+    const int t1 = (he + 31) / 32, t2 = (de + 31) / 32, tf = (hn + 31) / 32, td = (dn + 31) / 32;
+    if (t1 == 10 && t2 == 2 && tf == 7 && td == 4) return 128;
+    if (t1 == 5 && t2 == 1 && tf == 4 && td == 2) return 64;
+    if (t1 == 3 && t2 == 1 && tf == 2 && td == 1) return 32;
+    return 0;
 }
 
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b) {
-    return he == 320 && de == 64 && hn == 224 && dn == 128 && hc == 32 && (k1a % 16 == 0) && (k1b % 16 == 0) &&
-           (k1a + k1b) >= 16;
+    return chain_variant(he, de, hn, dn) != 0 && hc >= 4 && hc <= 32 && he % 4 == 0 && de % 4 == 0 && hn % 4 == 0 && dn % 4 == 0 &&
+           hc % 4 == 0 && (k1a % 16 == 0) && (k1b % 16 == 0) && (k1a + k1b) >= 16;
 }
 
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s) {
     if (a.E <= 0) return MPNHIP_OK;
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
-    hipLaunchKernelGGL((edge_chain_kernel<10, 2, 7, 4>), dim3(blocks), dim3(256), 0, s, a);
+    const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
+    switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
+        case 128:
+            if (exact)
+                hipLaunchKernelGGL((edge_chain_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((edge_chain_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+            break;
+        case 64: hipLaunchKernelGGL((edge_chain_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((edge_chain_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        default: set_error("edge_chain: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
+    }
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s) {
+    if (a.E <= 0) return MPNHIP_OK;
+    const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+    const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
+    switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
+        case 128:
+            if (exact)
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+            break;
+        case 64: hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        default: set_error("edge_chain_bwd: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
+    }
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -174,13 +174,15 @@ static int pack_node_weights(const mpnhip_model& m, const Dims& d, float* Wnode,
 static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights& cw, hipStream_t s) {
     cw.ok = chain_shapes_ok(m, d);
     if (!cw.ok) return MPNHIP_OK;
-    MPN_TRY(transpose_block(m.edge.weight[0], m.edge.in_dim, 2 * d.kx, d.he, d.ke, cw.w1T, s));
-    MPN_TRY(transpose_block(m.edge.weight[1], d.he, 0, d.de, d.he, cw.w2T, s));
-    MPN_TRY(transpose_block(m.classifier.weight[0], d.de, 0, m.classifier.out_dims[0], d.de, cw.wc1T, s));
+    const int HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
+    const int hc = m.classifier.out_dims[0];
+    MPN_TRY(transpose_padded(m.edge.weight[0], m.edge.in_dim, 2 * d.kx, d.he, d.ke, cw.w1T, HE, d.ke, s));
+    MPN_TRY(transpose_padded(m.edge.weight[1], d.he, 0, d.de, d.he, cw.w2T, DE, HE, s));
+    MPN_TRY(transpose_padded(m.classifier.weight[0], d.de, 0, hc, d.de, cw.wc1T, 32, DE, s));
     const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
     for (int q = 0; q < 2; ++q) {
-        MPN_TRY(transpose_block(fl[q]->weight[0], fl[q]->in_dim, d.kx, d.hn, d.de, cw.wf1T[q], s));
-        MPN_TRY(transpose_block(fl[q]->weight[1], d.hn, 0, d.dn, d.hn, cw.wf2T[q], s));
+        MPN_TRY(transpose_padded(fl[q]->weight[0], fl[q]->in_dim, d.kx, d.hn, d.de, cw.wf1T[q], HN, DE, s));
+        MPN_TRY(transpose_padded(fl[q]->weight[1], d.hn, 0, d.dn, d.hn, cw.wf2T[q], DN, HN, s));
     }
     return MPNHIP_OK;
 }
@@ -229,6 +231,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         // (2)-(4) fused: edge MLP, classifier and both flow MLPs in one kernel (edge_chain.hip)
         EdgeChainArgs a = {};
         a.E = (int)E; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm;
+        a.he = d.he; a.de = d.de; a.hn = d.hn; a.dn = d.dn; a.hc = m.classifier.out_dims[0];
         a.xa = io.ea; a.ldxa = io.ldea; a.k1a = io.eb ? io.kea : d.ke;
         a.xb = io.eb; a.ldxb = io.ldeb; a.k1b = io.eb ? d.ke - io.kea : 0;
         a.P = b.P; a.pw = d.pw;

@@ -105,13 +105,15 @@ struct StepBufs {
     int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
 };
 
-// pre-transposed weight images of the fused edge-chain kernel (edge_chain.hip)
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+
+// pre-transposed, zero-padded weight images of the fused edge-chain kernel (edge_chain.hip); P(.) = pad32
 struct ChainWeights {
-    float* w1T;       // [ke][he]
-    float* w2T;       // [he][de]
-    float* wc1T;      // [de][hc]
-    float* wf1T[2];   // [de][hn]  (0: flow_out, 1: flow_in)
-    float* wf2T[2];   // [hn][dn]
+    float* w1T;       // [ke][P(he)]
+    float* w2T;       // [P(he)][P(de)]
+    float* wc1T;      // [P(de)][32]
+    float* wf1T[2];   // [P(de)][P(hn)]  (0: flow_out, 1: flow_in)
+    float* wf2T[2];   // [P(hn)][P(dn)]
     bool ok;          // the model's shapes are covered by the fused kernel
 };
 
@@ -163,13 +165,13 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.bnode = a.f((size_t)d.pw);
     p.P0 = a.f((size_t)N * d.pw);
     {
-        const int hc = m.classifier.out_dims[0];
-        p.cw.w1T = a.f((size_t)d.ke * d.he);
-        p.cw.w2T = a.f((size_t)d.he * d.de);
-        p.cw.wc1T = a.f((size_t)d.de * hc);
+        const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
+        p.cw.w1T = a.f((size_t)d.ke * HE);
+        p.cw.w2T = a.f(HE * DE);
+        p.cw.wc1T = a.f(DE * 32);
         for (int q = 0; q < 2; ++q) {
-            p.cw.wf1T[q] = a.f((size_t)d.de * d.hn);
-            p.cw.wf2T[q] = a.f((size_t)d.hn * d.dn);
+            p.cw.wf1T[q] = a.f(DE * HN);
+            p.cw.wf2T[q] = a.f(HN * DN);
         }
         p.cw.ok = false;
     }

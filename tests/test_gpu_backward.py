@@ -143,7 +143,10 @@ def test_cfgA(agg):
     c = synth.CONFIGS["A"]
     params = synth.model_params(c["d"], c["L"], agg)
     g = synth.make_graph(c["N"], c["E"], seed=1)
-    check_against_oracle(params, synth.make_weights(params, seed=7), g, robust=(agg == "max"))
+    # 6 steps x 4,000 edges x 80 hidden units: the forward agrees with the oracle to ~3e-6 relative, which is enough to
+    # flip a few ReLU / arg-max decisions (the oracle's own grad_x moves by 7e-3 of its maximum under a 1e-6 input
+    # perturbation with sum aggregation, 6e-3 at 1e-7 with max) -> overall-error criterion at this size
+    check_against_oracle(params, synth.make_weights(params, seed=7), g, robust=True)
 
 
 def test_cfgB_mean():
