@@ -229,10 +229,12 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic(kernel_key, cfg_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
-    tools/pmc_summary.py with the MI355X guide's corrections), or None."""
+    tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
     path = os.path.join(REPO, "profiles", "r01", "pmc_summary.json")
+    if cfg_name != "B":
+        return None
     try:
         return json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
     except Exception:
@@ -256,10 +258,11 @@ def rooflines(prof, c, args, N, E, chain):
         macs = 2 * de * he + he * de + de * hc + hc + de * hn + hn * dn
         flops = 2.0 * E * macs
         ach = flops / (gemm_us * 1e-6) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": "edge_chain_kernel<10,2,7,4>: fused edge MLP + classifier + flow MLPs of one MP step, "
-                                                      "fp32 v_mfma_f32_32x32x2_f32, %d edges x %d MACs" % (E, macs),
+        res["roofline"] = {"bound": "mfma", "kernel": "edge_chain_kernel<%s>: fused edge MLP + classifier + flow MLPs of one MP step, "
+                                                      "fp32 v_mfma_f32_32x32x2_f32, %d edges x %d MACs" % (
+                                                          {128: "10,2,7,4", 64: "5,1,4,2", 32: "3,1,2,1"}.get(d, "?"), E, macs),
                            "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                           "traffic": pmc_traffic("edge_chain"), "avg_us": gemm_us,
+                           "traffic": pmc_traffic("edge_chain", args.config), "avg_us": gemm_us,
                            "empty_event_pair_us": empty_us, "launches": gemm_n, "algorithmic_flops": flops}
     elif gemm_n:
         K, Nn = 2 * de, he
@@ -268,7 +271,7 @@ def rooflines(prof, c, args, N, E, chain):
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (B K-contiguous): edge-MLP layer 1 [%d,%d]x[%d,%d] fp32, "
                                                       "v_mfma_f32_32x32x2_f32, gather-add epilogue" % (E, K, K, Nn),
                            "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                           "traffic": pmc_traffic("gemm_edge_l1"), "avg_us": gemm_us,
+                           "traffic": pmc_traffic("gemm_edge_l1", args.config), "avg_us": gemm_us,
                            "empty_event_pair_us": empty_us, "launches": gemm_n,
                            "algorithmic_flops": flops}
     if agg_n:
@@ -277,7 +280,7 @@ def rooflines(prof, c, args, N, E, chain):
         ach = bytes_agg / (agg_us * 1e-6) / 1e9
         res["roofline_aggregation"] = {"bound": "hbm", "kernel": "k_aggregate (both directions, %d messages x %d-d, %s)" % (E, dn, args.agg),
                                        "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                                       "traffic": pmc_traffic("k_aggregate"), "avg_us": agg_us,
+                                       "traffic": pmc_traffic("k_aggregate", args.config), "avg_us": agg_us,
                                        "empty_event_pair_us": empty_us, "launches": agg_n,
                                        "algorithmic_bytes": bytes_agg}
     return res

@@ -547,9 +547,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             a.wc1 = p.wc1p; a.wc2 = cls.weight[1]; a.w2 = p.w2p; a.w1e = p.w1ep;
             MPN_TRY(launch_edge_chain_bwd(a, s));
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
-            MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s));
-            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s));
-            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s));
+            MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s, E));
+            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E));
+            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s, E));
         } else if (E > 0) {
             // ---- B. aggregation backward + ReLU of the last flow layer ---------------------------
             {
@@ -563,7 +563,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             {
                 // layer 0:  Z = e_s Wfe^T + Pf[col];  dPf[n] = sum over the direction's edges with col == n
                 // (index_put_ of x[flow_col], mpn.py:87,93)
-                MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s));
+                MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s, E));
                 const float* Wq[2] = {m.flow_out.weight[0] + kx, m.flow_in.weight[0] + kx};
                 MPN_TRY(act_grad(2, dzfl[0], hn, nullptr, Wq, m.flow_out.in_dim, hn, de, dEc, de, nullptr, nullptr, 0, 1, dir_rr, E, s));
             }
@@ -573,8 +573,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             MPN_TRY(mlp_chain_backward(m.edge, nullptr, dzed, b.HE, nullptr, E, s));
             {
                 // dPr / dPc: index_put_(accumulate) of x[row], x[col] (mpn.py:69)
-                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s));
-                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s));
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E));
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s, E));
                 // gradient w.r.t. [e0 | e_{s-1}]: one product, then split (e_0 IS e0 at step 1)
                 const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
                 MPN_TRY(act_grad(1, dzed[0], he, nullptr, Wa, m.edge.in_dim, he, ke, p.dCat, ke, nullptr, nullptr, 0, 0, nullptr, E, s));

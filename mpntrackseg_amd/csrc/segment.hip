@@ -165,6 +165,95 @@ __global__ __launch_bounds__(256) void k_aggregate(SegArgs a) {
     }
 }
 
+// Long segments (dense kNN graphs: E / N ~ 150, a few hundred nodes): one 256-thread block per segment.  `sub`
+// lanes cover the columns (16 bytes each), 256 / sub row lanes stride over the segment's rows, and the row lanes'
+// partial results are combined in a fixed tree through LDS -- deterministic, but not the sequential order of the
+// short-segment kernels.  dim % 4 == 0, dim <= 4 * 64.
+__global__ __launch_bounds__(256) void k_segment_reduce_block(SegArgs a) {
+    __shared__ float4 redv[256];
+    __shared__ int4 redi[256];
+    const int s = blockIdx.x;
+    const int sub = a.sub, rl_n = 256 / sub;
+    const int cl = threadIdx.x % sub, rl = threadIdx.x / sub;
+    const int beg = a.ptr[s], end = a.ptr[s + 1];
+    const int64_t orow = (int64_t)(s % a.nmod) * a.ldo + ((s / a.nmod) == 0 ? a.off0 : a.off1);
+    const bool is_max = a.agg == MPNHIP_AGG_MAX;
+    const int c = cl * 4;
+    const bool col_ok = c < a.dim;
+    float4 acc;
+    vset(acc, is_max ? -INFINITY : 0.f);
+    int arg_s[4] = {-1, -1, -1, -1};
+    if (col_ok) {
+        for (int j = beg + rl; j < end; j += 4 * rl_n) {
+            float4 v[4];
+            int id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + u * rl_n < end ? j + u * rl_n : end - 1;
+                id[u] = a.list ? a.list[jj] : jj;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(a.src + (int64_t)id[u] * a.lds + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u * rl_n < end) {
+                    if (is_max) vmax(acc, arg_s, v[u], id[u]);
+                    else vadd(acc, v[u]);
+                }
+            }
+        }
+    }
+    redv[threadIdx.x] = acc;
+    redi[threadIdx.x] = make_int4(arg_s[0], arg_s[1], arg_s[2], arg_s[3]);
+    __syncthreads();
+    for (int w = rl_n >> 1; w > 0; w >>= 1) {
+        if (rl < w) {
+            float4 o = redv[threadIdx.x + w * sub];
+            float4 m = redv[threadIdx.x];
+            if (is_max) {
+                int4 oi = redi[threadIdx.x + w * sub], mi = redi[threadIdx.x];
+                // larger value wins; equal values: the smaller (earlier) edge index, as the sequential scan would pick
+                auto pick = [](float& mv, int& mx, float ov, int ox) {
+                    if (ov > mv || (ov == mv && ox >= 0 && (mx < 0 || ox < mx))) { mv = ov; mx = ox; }
+                };
+                pick(m.x, mi.x, o.x, oi.x); pick(m.y, mi.y, o.y, oi.y); pick(m.z, mi.z, o.z, oi.z); pick(m.w, mi.w, o.w, oi.w);
+                redi[threadIdx.x] = mi;
+            } else {
+                m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            }
+            redv[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && col_ok) {
+        float4 r = redv[threadIdx.x];
+        if (a.agg == MPNHIP_AGG_MEAN) {
+            const int cnt = end - beg;
+            vdiv(r, (float)(cnt > 0 ? cnt : 1));
+        } else if (is_max && end == beg) {
+            vset(r, 0.f);
+        }
+        float* op = a.out + orow + c;
+        if (a.accumulate) vadd(r, *reinterpret_cast<const float4*>(op));
+        *reinterpret_cast<float4*>(op) = r;
+        if (a.argmax) *reinterpret_cast<int4*>(a.argmax + orow + c) = redi[threadIdx.x];
+    }
+}
+
+// average segment length above which the block-per-segment kernel is used
+constexpr int64_t LONG_SEGMENT = 48;
+
+static bool try_launch_block(SegArgs& a, int64_t total_rows, hipStream_t stream) {
+    const bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
+                     (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.out & 15) == 0) && (!a.argmax || ((uintptr_t)a.argmax & 15) == 0);
+    if (!vec || a.dim > 256 || a.nseg <= 0 || total_rows < LONG_SEGMENT * a.nseg) return false;
+    int sub = 1;
+    while (sub < a.dim / 4) sub <<= 1;
+    a.sub = sub;
+    hipLaunchKernelGGL(k_segment_reduce_block, dim3(a.nseg), dim3(256), 0, stream, a);
+    return true;
+}
+
 static int launch_seg(SegArgs a, hipStream_t stream) {
     if (a.nseg <= 0 || a.dim <= 0) return MPNHIP_OK;
     bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
@@ -196,6 +285,10 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
     a.nmod = g.N > 0 ? g.N : 1;
     a.off0 = dim;  // flow_out goes to the right half: torch.cat((flow_in, flow_out)) (mpn.py:97)
     a.off1 = 0;
+    if (try_launch_block(a, g.E, stream)) {
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
     if (dim % 4 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0 && a.nseg > 0) {
         int sub = 1;
         while (sub < dim / 4 && sub < 64) sub <<= 1;
@@ -228,7 +321,7 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 
 // segments [0, nmod) go to column offset off0, segments [nmod, 2 nmod) to off1 of out row (s % nmod)
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
-                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream) {
+                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows) {
     SegArgs a = {};
     a.src = src;
     a.lds = lds;
@@ -242,6 +335,10 @@ int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const in
     a.nmod = nmod > 0 ? nmod : 1;
     a.off0 = off0;
     a.off1 = off1;
+    if (try_launch_block(a, total_rows, stream)) {
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
     return launch_seg(a, stream);
 }
 
