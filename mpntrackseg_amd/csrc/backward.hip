@@ -425,8 +425,14 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         }
         MPN_TRY(pack_padded(m.classifier.weight[0], de, 0, m.classifier.out_dims[0], de, p.wc1p, 32, DE, DE, 0, s));
         MPN_TRY(pack_padded(m.edge.weight[1], he, 0, de, he, p.w2p, DE, HE, HE, 0, s));
-        for (int hlf = 0; hlf < d.ef; ++hlf)
-            MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de, p.w1ep, HE, DE, KEp, hlf * DE, s));
+        // e-part columns of edge layer 0 as one image [HE][ncol6] per pass of <= 64 (padded) columns of [e0 | e_{s-1}]
+        // (the kernel streams whole rows of one pass image)
+        const int ncol6 = KEp < 64 ? KEp : 64;
+        for (int hlf = 0; hlf < d.ef; ++hlf) {
+            const int col0 = hlf * DE;
+            MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de,
+                                p.w1ep + (int64_t)(col0 / 64) * HE * ncol6, HE, DE, ncol6, col0 % 64, s));
+        }
     }
 
     // activation-gradient chain of the classifier for one step: dz chain blocks in dzc[], final product

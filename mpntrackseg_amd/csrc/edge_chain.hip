@@ -34,37 +34,29 @@ constexpr int CH_FLOATS = 5120;  // floats per weight chunk buffer (20 KB)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-struct ChunkDesc {
-    const float* w;  // pre-transposed weight image WT[k][n], leading dim ldw
-    int ldw, k0, kc, n0, nc;
-};
-
-// register-staged copy of one chunk: up to 5 float4 per thread
-struct ChunkRegs {
-    float4 v[5];
-};
-
-__device__ __forceinline__ void chunk_load(const ChunkDesc& d, int tid, ChunkRegs& r) {
-    const int nc4 = d.nc >> 2;
-    const int total = d.kc * nc4;
+// Weight chunks are CONTIGUOUS runs of floats in the packed images (the images are laid out so that every chunk is:
+// whole rows of a [k][n] image, or one column block stored as its own image).  They are copied with the gfx950
+// LDS-DMA load (global_load_lds_dwordx4: 1 KiB per wave instruction, lane-linear destination, no staging registers,
+// no ds_write pass), issued at the start of the chunk BEFORE the one that uses them and drained by the vmcnt(0) that
+// __syncthreads() carries.  Every load is unconditional (source index clamped into the chunk; surplus lanes land in
+// the unused tail of the 20 KB buffer) and sizes are compile-time constants wherever the schedule is static: a load
+// behind a branch makes the compiler's s_waitcnt bookkeeping conservative.
+template <int Q>
+__device__ __forceinline__ void chunk_fetch(const float* src, int n4, int tid, float* buf) {
+    static_assert(Q >= 1 && Q * 1024 <= CH_FLOATS, "chunk larger than its buffer");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < Q; ++q) {
         int f = tid + 256 * q;
-        f = f < total ? f : total - 1;  // clamped (unconditional loads); surplus copies are not written
-        const int kr = f / nc4, c4 = f - kr * nc4;
-        r.v[q] = ldg4(d.w + (int64_t)(d.k0 + kr) * d.ldw + d.n0 + 4 * c4);
+        f = f < n4 ? f : n4 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * f),
+                                         (__attribute__((address_space(3))) void*)(buf + 4 * (256 * q + 64 * wave)), 16, 0, 0);
     }
 }
 
-__device__ __forceinline__ void chunk_store(const ChunkDesc& d, int tid, const ChunkRegs& r, float* buf) {
-    const int nc4 = d.nc >> 2;
-    const int total = d.kc * nc4;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int f = tid + 256 * q;
-        if (f < total) *reinterpret_cast<float4*>(buf + 4 * f) = r.v[q];  // image [kc][nc], pitch nc
-    }
-}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int chunk_q(int n4) { return (n4 + 255) / 256; }
 
 // 16-byte piece of a feature row at column n (n % 4 == 0, dim % 4 == 0): zero beyond the real width
 template <bool EXACT>
@@ -165,7 +157,14 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     static_assert(HE * KC1 <= CH_FLOATS && KC2 * DE <= CH_FLOATS && DE * NC4 <= CH_FLOATS && KC5 * DN <= CH_FLOATS &&
                       DE * HC <= CH_FLOATS, "chunk too large");
 
-    __shared__ __attribute__((aligned(16))) float wbuf[2][CH_FLOATS];
+    // ONE LDS object (a second one beside the LDS-DMA target makes hipcc drain vmcnt before unrelated ds_reads):
+    // two weight-chunk buffers, two phase-1 input staging buffers, then the biases [b2 (DE) | bc1 (32) | wc2 (32) | bf2 (DN)], zero-padded
+    constexpr int XS_FLOATS = 4 * 2 * 64 * 4;  // phase-1 input staging per buffer: 4 waves x 2 pieces x 64 lanes x 16 B
+    __shared__ __attribute__((aligned(16))) float smem[2 * CH_FLOATS + 2 * XS_FLOATS + DE + 64 + DN];
+    float* const wbuf0 = smem;
+    float* const xs0 = smem + 2 * CH_FLOATS;
+    float* const sbias = xs0 + 2 * XS_FLOATS;
+#define wbuf_at(i) (wbuf0 + ((i) & 1) * CH_FLOATS)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
@@ -190,39 +189,30 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
 
-    // ---- chunk schedule ----------------------------------------------------------------------------
+    // ---- chunk schedule (float4 counts; every chunk is a contiguous run of its image) -----------------------
     constexpr int NCH2 = (HE + KC2 - 1) / KC2;
     constexpr int NCH4 = (HN + NC4 - 1) / NC4;
     constexpr int NCH5 = HN / KC5;
-    const int c2 = nch1, c3 = c2 + NCH2, c4 = c3 + 1, c5 = c4 + NCH4, cend_flow = c5 + NCH5;
-    const int nchunks = flow ? cend_flow : c4;
-    const float* wf1 = grp == 1 ? A.wf1T_in : A.wf1T_out;
+    constexpr int N4_1 = KC1 * HE / 4;                       // phase 1: 16 rows of W1T
+    constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4;           // phase 2, first chunk
+    constexpr int N4_3 = DE * HC / 4;                        // classifier layer 0, whole
+    constexpr int N4_4_0 = DE * cmin(NC4, HN) / 4;           // phase 4, first column block
+    constexpr int N4_5 = KC5 * DN / 4;                       // phase 5: 32 rows of Wf2T
+    const float* wf1 = grp == 1 ? A.wf1T_in : A.wf1T_out;   // NCH4 column-block images [DE][<=64], block i at DE * 64 * i
     const float* wf2 = grp == 1 ? A.wf2T_in : A.wf2T_out;
-    auto desc = [&](int c) {
-        ChunkDesc d;
-        if (c < c2) { d.w = A.w1T; d.ldw = HE; d.k0 = c * KC1; d.kc = KC1; d.n0 = 0; d.nc = HE; }
-        else if (c < c3) { d.w = A.w2T; d.ldw = DE; d.k0 = (c - c2) * KC2; d.kc = HE - d.k0 < KC2 ? HE - d.k0 : KC2; d.n0 = 0; d.nc = DE; }
-        else if (c < c4) { d.w = A.wc1T; d.ldw = HC; d.k0 = 0; d.kc = DE; d.n0 = 0; d.nc = HC; }
-        else if (c < c5) { d.w = wf1; d.ldw = HN; d.k0 = 0; d.kc = DE; d.n0 = (c - c4) * NC4;
-                           d.nc = HN - d.n0 < NC4 ? HN - d.n0 : NC4; }
-        else { d.w = wf2; d.ldw = DN; d.k0 = (c - c5) * KC5; d.kc = KC5; d.n0 = 0; d.nc = DN; }
-        return d;
-    };
 
-    ChunkRegs creg;
-    int c = 0;  // chunk being computed
+    int c = 0;  // chunk being computed (buffer parity)
+    chunk_fetch<chunk_q(N4_1)>(A.w1T, N4_1, tid, wbuf_at(0));
     {
-        ChunkDesc d0 = desc(0);
-        chunk_load(d0, tid, creg);
-        chunk_store(d0, tid, creg, wbuf[0]);
+        // biases -> LDS (ordinary loads; drained with chunk 0 by the first barrier)
+        const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
+        float v = 0.f;
+        if (tid < DE) v = tid < de ? A.b2[tid] : 0.f;
+        else if (tid < DE + 32) v = tid - DE < hc ? A.bc1[tid - DE] : 0.f;
+        else if (tid < DE + 64) v = tid - DE - 32 < hc ? A.wc2[tid - DE - 32] : 0.f;
+        else if (tid < DE + 64 + DN) v = tid - DE - 64 < dn ? bf2[tid - DE - 64] : 0.f;
+        if (tid < DE + 64 + DN) sbias[tid] = v;
     }
-    // prefetch / commit of the NEXT chunk around the compute of chunk c
-    auto prefetch = [&]() { if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_load(d, tid, creg); } };
-    auto commit = [&]() {
-        if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_store(d, tid, creg, wbuf[(c + 1) & 1]); }
-        __syncthreads();
-        ++c;
-    };
 
     // ---- phase 1: H1^T = W1e [e0|e]^T, C-in = Pr[row] (+ Pc[col] after the MFMAs) ---------------------------
     const int row = A.srow[edge], col = A.scol[edge];
@@ -238,15 +228,33 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         // lane (j, h) reads its edge's features 16 bytes at a time: k = 8u + 4h + (0..3)
         const float* xa = A.xa + (int64_t)edge * A.ldxa + 4 * lh;
         const float* xb = A.xb ? A.xb + (int64_t)edge * A.ldxb + 4 * lh - A.k1a : xa;
-        auto xload = [&](int k) { return ldg4((k < A.k1a ? xa : xb) + k); };
-        float4 xcur[2], xnxt[2];
-        xcur[0] = xload(0);
-        xcur[1] = xload(8);
+        // ... through LDS by LDS-DMA as well (each lane's 16 bytes land at its own lane-linear slot and are read back by
+        // the same lane): with only DMA loads in the loop the compiler's vmcnt waits stay where the barriers are
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        auto xfetch = [&](int k, int buf) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)((k + 8 * u < A.k1a ? xa : xb) + k + 8 * u),
+                    (__attribute__((address_space(3))) void*)(xs0 + (buf & 1) * XS_FLOATS + (wave_u * 2 + u) * 256), 16, 0, 0);
+        };
+        xfetch(0, 0);
         __syncthreads();  // chunk 0 is in wbuf[0]
         for (int i = 0; i < nch1; ++i) {
-            prefetch();
-            if (i + 1 < nch1) { xnxt[0] = xload((i + 1) * KC1); xnxt[1] = xload((i + 1) * KC1 + 8); }
-            const float* ws = wbuf[c & 1] + 4 * lh * HE + lj;
+            // next chunk: the following 16 rows of W1T, or the first chunk of phase 2 (scalar selects, no branch)
+            const bool last1 = i + 1 >= nch1;
+            const float* nsrc = last1 ? A.w2T : A.w1T + (int64_t)(i + 1) * KC1 * HE;
+            const int nn4 = last1 ? N4_2_0 : N4_1;
+            // (read this chunk's inputs BEFORE the DMAs go out: hipcc drains vmcnt in front of a plain ds_read_b128 that
+            // follows an LDS-DMA into the same object)
+            float4 xcur[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                xcur[u] = *reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_FLOATS + (wave * 2 + u) * 256 + lane * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_fetch<chunk_q(cmax(N4_1, N4_2_0))>(nsrc, nn4, tid, wbuf_at(c + 1));
+            xfetch(last1 ? i * KC1 : (i + 1) * KC1, c + 1);  // the last iteration re-reads its own columns (unused)
+            const float* ws = wbuf_at(c) + 4 * lh * HE + lj;
             // 8 steps (u, q) of T1 MFMAs each; the weights of step s+1 are fetched before the MFMAs of step s
             float a[2][T1];
 #pragma unroll
@@ -265,8 +273,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
                 for (int t = 0; t < T1; ++t) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][t], xv, h1[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (i + 1 < nch1) { xcur[0] = xnxt[0]; xcur[1] = xnxt[1]; }
-            commit();
+            __syncthreads();
+            ++c;
         }
     }
     {
@@ -298,14 +306,20 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
     for (int t = 0; t < T2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) set4(en[t], g, ldrow<EXACT>(A.b2, 32 * t + 8 * g + 4 * lh, de));
+        for (int g = 0; g < 4; ++g) set4(en[t], g, *reinterpret_cast<const float4*>(sbias + 32 * t + 8 * g + 4 * lh));
 #pragma unroll
     for (int i = 0; i < NCH2; ++i) {
-        prefetch();
-        const float* ws = wbuf[c & 1];
+        // next: rows 64 (i + 1) .. of W2T, or the classifier image
+        const bool more = i + 1 < NCH2;
+        const int rows_n = more ? (HE - (i + 1) * KC2 < KC2 ? HE - (i + 1) * KC2 : KC2) : 0;  // folds: i is unrolled
+        const float* nsrc = more ? A.w2T + (i + 1) * KC2 * DE : A.wc1T;
+        const int nn4 = more ? rows_n * DE / 4 : N4_3;
+        chunk_fetch<chunk_q(cmax(N4_2_0, N4_3))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        const float* ws = wbuf_at(c);
         chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
         if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
-        commit();
+        __syncthreads();
+        ++c;
     }
     {
         float* o = A.e_new + (int64_t)edge * de;
@@ -317,18 +331,30 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         }
     }
 
+    // C-in of phase 4 (gathered per-node flow projections), issued here so that the gather's latency hides behind the
+    // classifier; it is drained, with the chunk prefetch, by the barrier that ends phase 3 (self-loop blocks gather
+    // the flow_out columns and drop them)
+    f32x16 hf[TF];
+    {
+        const float* pf = A.P + (int64_t)col * A.pw + 2 * he + (grp == 1 ? hn : 0);
+#pragma unroll
+        for (int t = 0; t < TF; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
+    }
     // ---- phase 3: classifier ----------------------------------------------------------------------------
     {
         f32x16 hcv;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) set4(hcv, g, ldrow<EXACT>(A.bc1, 8 * g + 4 * lh, hc));
-        prefetch();
+        for (int g = 0; g < 4; ++g) set4(hcv, g, *reinterpret_cast<const float4*>(sbias + DE + 8 * g + 4 * lh));
+        chunk_fetch<chunk_q(N4_4_0)>(wf1, N4_4_0, tid, wbuf_at(c + 1));  // (self-loop blocks fetch it too and never use it)
         {
-            const float* ws = wbuf[c & 1];
+            const float* ws = wbuf_at(c);
 #pragma unroll
             for (int t = 0; t < T2; ++t) chain_tile<1>(en[t], &hcv, ws, HC, 32 * t, 0, 4 * lh * HC + lj);
         }
-        commit();
+        __syncthreads();
+        ++c;
         relu16(hcv);
         if (A.save_hc) {
             float* o = A.save_hc + (int64_t)edge * hc;
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         float part = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 w = ldrow<EXACT>(A.wc2, 8 * g + 4 * lh, hc);
+            const float4 w = *reinterpret_cast<const float4*>(sbias + DE + 32 + 8 * g + 4 * lh);
             part = fmaf(w.x, hcv[4 * g + 0], part);
             part = fmaf(w.y, hcv[4 * g + 1], part);
             part = fmaf(w.z, hcv[4 * g + 2], part);
@@ -347,21 +373,19 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         const float other = __shfl_xor(part, 32, 64);
         if (A.logits && edge_ok && lh == 0) A.logits[A.perm[edge]] = part + other + A.bc2[0];
     }
+#undef wbuf_at
+#define wbuf_at(i) (wbuf0 + ((i) & 1) * CH_FLOATS)
     if (!flow) return;  // self loops take part in the edge update only (mpn.py:85,91)
 
     // ---- phase 4: HF^T = relu(Wfe e'^T + Pf[col]) ---------------------------------------------------------
-    f32x16 hf[TF];
-    {
-        const float* pf = A.P + (int64_t)col * A.pw + 2 * he + grp * hn;
-#pragma unroll
-        for (int t = 0; t < TF; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
-    }
 #pragma unroll
     for (int i = 0; i < NCH4; ++i) {
-        prefetch();
-        const float* ws = wbuf[c & 1];
+        const bool more = i + 1 < NCH4;
+        const int ncw_n = more ? ((HN - (i + 1) * NC4) < NC4 ? (HN - (i + 1) * NC4) : NC4) : 0;
+        const float* nsrc = more ? wf1 + DE * NC4 * (i + 1) : wf2;
+        const int nn4 = more ? DE * ncw_n / 4 : N4_5;
+        chunk_fetch<chunk_q(cmax(N4_4_0, N4_5))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        const float* ws = wbuf_at(c);
         constexpr int full = NC4 / 32;
         const int ncw = (HN - i * NC4) < NC4 ? (HN - i * NC4) : NC4;  // compile-time per unrolled i
 #pragma unroll
@@ -369,7 +393,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             if (ncw == NC4) chain_tile<full>(en[t], &hf[i * full], ws, NC4, 32 * t, 0, 4 * lh * NC4 + lj);
             else chain_tile<1>(en[t], &hf[i * full], ws, 32, 32 * t, 0, 4 * lh * 32 + lj);
         }
-        commit();
+        __syncthreads();
+        ++c;
     }
     {
         float* o = A.save_hf ? A.save_hf + (int64_t)edge * hn : nullptr;
@@ -385,19 +410,19 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 
     // ---- phase 5: M^T = relu(Wf2 HF^T + bf2) -----------------------------------------------------------------
     f32x16 mm[TD];
-    {
-        const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
 #pragma unroll
-        for (int t = 0; t < TD; ++t)
+    for (int t = 0; t < TD; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) set4(mm[t], g, ldrow<EXACT>(bf2, 32 * t + 8 * g + 4 * lh, dn));
-    }
+        for (int g = 0; g < 4; ++g) set4(mm[t], g, *reinterpret_cast<const float4*>(sbias + DE + 64 + 32 * t + 8 * g + 4 * lh));
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
-        prefetch();
-        const float* ws = wbuf[c & 1];
+        if (i + 1 < NCH5) chunk_fetch<chunk_q(N4_5)>(wf2 + (i + 1) * KC5 * DN, N4_5, tid, wbuf_at(c + 1));  // static: i is unrolled
+        const float* ws = wbuf_at(c);
         chain_tile<TD>(hf[i], mm, ws, DN, 0, 0, 4 * lh * DN + lj);
-        commit();
+        if (i + 1 < NCH5) {
+            __syncthreads();
+            ++c;
+        }
     }
     {
         float* o = A.msg + (int64_t)edge * dn;
@@ -409,6 +434,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         }
     }
 }
+
+#undef wbuf_at
 
 // ------------------------------------------------------------------------------------------------------
 // Backward chain of one step.  Same machinery, transposed weights: dH^T[k][edge] = sum_n W[n][k] dZ^T[n][edge],
@@ -451,35 +478,21 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     const int npass6 = KEp / 64 > 0 ? KEp / 64 : 1;
     const int ncol6 = KEp < 64 ? KEp : 64;    // columns per B6 pass
 
-    // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6 ------------------------------------------
+    // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6; float4 counts of the contiguous chunks ------------
     constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
-    const int c3 = flow ? NCH2 : 0, c4 = c3 + (flow ? NCH3 : 0), c5 = c4 + 1, c6 = c5 + NCH5;
-    const int nchunks = c6 + npass6 * NCH6;
+    constexpr int N4_2 = NR2 * HN / 4;                  // 16 rows of Wf2
+    constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4;      // first 64 rows of Wfe
+    constexpr int N4_4 = HC * DE / 4;                   // Wc1, whole
+    constexpr int N4_5 = NR5 * HE / 4;                  // 16 rows of W2
+    constexpr int N4_6MAX = cmin(NR6, HE) * 64 / 4;     // <= 64 rows of one W1e column-pass image [HE][ncol6]
     const float* wf2 = grp == 1 ? A.wf2_in : A.wf2_out;
     const float* wfe = grp == 1 ? A.wfe_in : A.wfe_out;
-    auto desc = [&](int c) {
-        ChunkDesc d;
-        if (c < c3) { d.w = wf2; d.ldw = HN; d.k0 = c * NR2; d.kc = NR2; d.n0 = 0; d.nc = HN; }
-        else if (c < c4) { d.w = wfe; d.ldw = DE; d.k0 = (c - c3) * NR3; d.kc = HN - d.k0 < NR3 ? HN - d.k0 : NR3; d.n0 = 0; d.nc = DE; }
-        else if (c < c5) { d.w = A.wc1; d.ldw = DE; d.k0 = 0; d.kc = HC; d.n0 = 0; d.nc = DE; }
-        else if (c < c6) { d.w = A.w2; d.ldw = HE; d.k0 = (c - c5) * NR5; d.kc = NR5; d.n0 = 0; d.nc = HE; }
-        else { const int q = c - c6; d.w = A.w1e; d.ldw = KEp; d.k0 = (q % NCH6) * NR6; d.kc = HE - d.k0 < NR6 ? HE - d.k0 : NR6;
-               d.n0 = (q / NCH6) * 64; d.nc = ncol6; }
-        return d;
-    };
-    ChunkRegs creg;
     int c = 0;
-    {
-        ChunkDesc d0 = desc(0);
-        chunk_load(d0, tid, creg);
-        chunk_store(d0, tid, creg, wbuf[0]);
+    if (flow) {
+        chunk_fetch<chunk_q(N4_2)>(wf2, N4_2, tid, wbuf[0]);
+    } else {
+        chunk_fetch<chunk_q(N4_4)>(A.wc1, N4_4, tid, wbuf[0]);
     }
-    auto prefetch = [&]() { if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_load(d, tid, creg); } };
-    auto commit = [&]() {
-        if (c + 1 < nchunks) { ChunkDesc d = desc(c + 1); chunk_store(d, tid, creg, wbuf[(c + 1) & 1]); }
-        __syncthreads();
-        ++c;
-    };
 
     // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators (loaded after B2, when the
     // dZM tiles are dead -- B2 is the register peak of this kernel)
@@ -535,10 +548,14 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             for (int r = 0; r < 16; ++r) dzf[t][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH2; ++i) {
-            prefetch();
+            const bool more = i + 1 < NCH2;  // folds: i is unrolled
+            const float* nsrc = more ? wf2 + (i + 1) * NR2 * HN : wfe;
+            const int nn4 = more ? N4_2 : N4_3_0;
+            chunk_fetch<chunk_q(cmax(N4_2, N4_3_0))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
             // chunk rows = 16 contraction indices n = 16 i .. 16 i + 15 = registers 8 (i & 1) .. + 7 of source tile i / 2
             chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf[c & 1], HN, 4 * lh * HN + lj);
-            commit();
+            __syncthreads();
+            ++c;
         }
         {
             const float* hp = A.HF + (int64_t)edge * hn;
@@ -561,11 +578,16 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         load_de();
 #pragma unroll
         for (int i = 0; i < NCH3; ++i) {
-            prefetch();
+            const bool more = i + 1 < NCH3;
+            const int rows_n = more ? (HN - (i + 1) * NR3 < NR3 ? HN - (i + 1) * NR3 : NR3) : 0;
+            const float* nsrc = more ? wfe + (i + 1) * NR3 * DE : A.wc1;
+            const int nn4 = more ? rows_n * DE / 4 : N4_4;
+            chunk_fetch<chunk_q(cmax(N4_3_0, N4_4))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
             const float* ws = wbuf[c & 1];
             chain_tile<T2>(dzf[2 * i], dE, ws, DE, 0, 0, 4 * lh * DE + lj);
             if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], dE, ws, DE, 32, 0, 4 * lh * DE + lj);
-            commit();
+            __syncthreads();
+            ++c;
         }
     }
 
@@ -587,9 +609,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             set4(dzc, g, v);
             strow<EXACT>(o2, n, hc, v, edge_ok);
         }
-        prefetch();
+        chunk_fetch<chunk_q(N4_5)>(A.w2, N4_5, tid, wbuf[(c + 1) & 1]);
         chain_tile<T2>(dzc, dE, wbuf[c & 1], DE, 0, 0, 4 * lh * DE + lj);
-        commit();
+        __syncthreads();
+        ++c;
     }
     // dZ2 = dE' (.) [e_s > 0]  (written over the incoming gradient)
     {
@@ -615,14 +638,19 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     for (int t = 0; t < T1; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz1[t][r] = 0.f;
+    const int rows6_0 = HE < NR6 ? HE : NR6;
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
-        prefetch();
+        const bool more = i + 1 < NCH5;
+        const float* nsrc = more ? A.w2 + (i + 1) * NR5 * HE : A.w1e;
+        const int nn4 = more ? N4_5 : rows6_0 * ncol6 / 4;
+        chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
         // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
         constexpr int TA = (T1 + 1) / 2, TB = T1 - TA;
         chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf[c & 1], HE, 4 * lh * HE + lj);
         if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf[c & 1], HE, 4 * lh * HE + lj + 32 * TA);
-        commit();
+        __syncthreads();
+        ++c;
     }
     {
         const float* hp = A.H1 + (int64_t)edge * he;
@@ -656,7 +684,16 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             for (int r = 0; r < 16; ++r) dc[t][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH6; ++i) {
-            prefetch();
+            // next: the following <= 64 rows of this pass's image [HE][ncol6], or the first rows of the next pass's
+            // image; after the very last chunk the same rows are fetched again and dropped (keeps the load unconditional)
+            const bool more = i + 1 < NCH6;
+            const bool more_pass = pass + 1 < npass6;
+            const int in = more ? i + 1 : (more_pass ? 0 : i);
+            const int pn = more ? pass : (more_pass ? pass + 1 : pass);
+            const int rows_n = HE - in * NR6 < NR6 ? HE - in * NR6 : NR6;
+            const float* nsrc = A.w1e + ((int64_t)pn * HE + in * NR6) * ncol6;
+            const int nn4 = rows_n * ncol6 / 4;
+            chunk_fetch<chunk_q(N4_6MAX)>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
             const float* ws = wbuf[c & 1];
             if (ncol6 == 64) {
                 chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
@@ -665,7 +702,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
                 chain_tile<1>(dz1[2 * i], dc, ws, 32, 0, 0, 4 * lh * 32 + lj);
                 if (2 * i + 1 < T1) chain_tile<1>(dz1[2 * i + 1], dc, ws, 32, 32, 0, 4 * lh * 32 + lj);
             }
-            commit();
+            __syncthreads();
+            ++c;
         }
         // output tile tt (32 padded columns) of the pass belongs to half tt / T2 of [e0 | e_{s-1}], tile tt % T2 in it;
         // the first half is the re-attached initial features (accumulated over all steps), the second e_{s-1} --

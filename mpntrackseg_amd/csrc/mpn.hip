@@ -181,7 +181,13 @@ static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights
     MPN_TRY(transpose_padded(m.classifier.weight[0], d.de, 0, hc, d.de, cw.wc1T, 32, DE, s));
     const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
     for (int q = 0; q < 2; ++q) {
-        MPN_TRY(transpose_padded(fl[q]->weight[0], fl[q]->in_dim, d.kx, d.hn, d.de, cw.wf1T[q], HN, DE, s));
+        // flow layer 0, e'-part: one image [DE][<= 64] per block of 64 output features (the kernel streams whole blocks)
+        for (int n0 = 0; n0 < HN; n0 += 64) {
+            const int ncw = HN - n0 < 64 ? HN - n0 : 64;
+            const int rows = d.hn - n0 < 0 ? 0 : (d.hn - n0 < ncw ? d.hn - n0 : ncw);
+            MPN_TRY(transpose_padded(fl[q]->weight[0] + (int64_t)n0 * fl[q]->in_dim, fl[q]->in_dim, d.kx, rows, d.de,
+                                     cw.wf1T[q] + (int64_t)DE * n0, ncw, DE, s));
+        }
         MPN_TRY(transpose_padded(fl[q]->weight[1], d.hn, 0, d.dn, d.hn, cw.wf2T[q], DN, HN, s));
     }
     return MPNHIP_OK;
