@@ -5,7 +5,8 @@ CSRC := mpntrackseg_amd/csrc
 SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_tn.hip $(CSRC)/edge_chain.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/attention.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := $(CSRC)/libmpnhip.so
-CXXFLAGS := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -Wall -Wno-unused-function
+# EXTRA=-DMPNHIP_CHAIN_TS builds the fused chain kernels with per-phase cycle stamps (tools/chain_stamps.py)
+CXXFLAGS := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -Wall -Wno-unused-function $(EXTRA)
 
 all: $(LIB)
 

@@ -38,6 +38,9 @@ struct EdgeChainArgs {
     float* save_h1;        // [E, he] / nullptr  (training: activations kept for the backward pass)
     float* save_hc;        // [E, hc] / nullptr
     float* save_hf;        // [E, hn] / nullptr
+#ifdef MPNHIP_CHAIN_TS
+    long long* ts;         // debug build: 16 cycle stamps per wave
+#endif
 };
 
 // Backward of the same chain for one step (edge_chain.hip, edge_chain_bwd_kernel): all activation-gradient
@@ -70,7 +73,10 @@ struct EdgeChainBwdArgs {
     const float* wc1;      // [32][DE]
     const float* wc2;      // [hc]   (the model's tensor)
     const float* w2;       // [DE][HE]
-    const float* w1e;      // [HE][(1 or 2) DE]: e-part columns of edge layer 0, each half padded to DE
+    const float* w1e;      // one image [HE][ncol] per pass of <= 64 padded columns of [e0 | e_{s-1}]
+#ifdef MPNHIP_CHAIN_TS
+    long long* ts;
+#endif
 };
 int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s);
 

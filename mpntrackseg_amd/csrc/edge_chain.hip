@@ -23,12 +23,27 @@
 // (80/16/56/32/8 -> 3/1/2/1) and 64-d (5/1/4/2); anything else uses the unfused GEMM path.
 #include "common.h"
 #include "edge_chain.h"
+#ifdef MPNHIP_CHAIN_TS
+#include <cstdio>
+#include <string>
+#include <vector>
+#endif
 
 namespace mpnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
+
+// Debug build (make EXTRA=-DMPNHIP_CHAIN_TS): lane 0 of every wave stamps s_memtime at the phase boundaries; with
+// MPNHIP_CHAIN_TS=<file prefix> in the environment the 40th launch of each kernel dumps its stamps as text.
+#ifdef MPNHIP_CHAIN_TS
+#define TS_INIT() long long* tsp = A.ts ? A.ts + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 : nullptr
+#define TS(i) do { if (tsp && (threadIdx.x & 63) == 0) tsp[i] = clock64(); } while (0)
+#else
+#define TS_INIT() do {} while (0)
+#define TS(i) do {} while (0)
+#endif
 
 constexpr int CH_FLOATS = 5120;  // floats per weight chunk buffer (20 KB)
 
@@ -202,6 +217,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const float* wf2 = grp == 1 ? A.wf2T_in : A.wf2T_out;
 
     int c = 0;  // chunk being computed (buffer parity)
+    TS_INIT();
+    TS(0);
     chunk_fetch<chunk_q(N4_1)>(A.w1T, N4_1, tid, wbuf_at(0));
     {
         // biases -> LDS (ordinary loads; drained with chunk 0 by the first barrier)
@@ -240,6 +257,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         };
         xfetch(0, 0);
         __syncthreads();  // chunk 0 is in wbuf[0]
+        TS(1);
         for (int i = 0; i < nch1; ++i) {
             // next chunk: the following 16 rows of W1T, or the first chunk of phase 2 (scalar selects, no branch)
             const bool last1 = i + 1 >= nch1;
@@ -277,6 +295,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             ++c;
         }
     }
+    TS(2);
     {
         const float* pc = A.P + (int64_t)col * A.pw + he;
         float* sv = A.save_h1 ? A.save_h1 + (int64_t)edge * he : nullptr;
@@ -301,6 +320,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         }
     }
 
+    TS(3);
     // ---- phase 2: e'^T = relu(W2 H1^T + b2) -----------------------------------------------------------
     f32x16 en[T2];
 #pragma unroll
@@ -331,6 +351,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         }
     }
 
+    TS(4);
     // C-in of phase 4 (gathered per-node flow projections), issued here so that the gather's latency hides behind the
     // classifier; it is drained, with the chunk prefetch, by the barrier that ends phase 3 (self-loop blocks gather
     // the flow_out columns and drop them)
@@ -375,6 +396,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     }
 #undef wbuf_at
 #define wbuf_at(i) (wbuf0 + ((i) & 1) * CH_FLOATS)
+    TS(5);
     if (!flow) return;  // self loops take part in the edge update only (mpn.py:85,91)
 
     // ---- phase 4: HF^T = relu(Wfe e'^T + Pf[col]) ---------------------------------------------------------
@@ -408,6 +430,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         }
     }
 
+    TS(6);
     // ---- phase 5: M^T = relu(Wf2 HF^T + bf2) -----------------------------------------------------------------
     f32x16 mm[TD];
 #pragma unroll
@@ -424,6 +447,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             ++c;
         }
     }
+    TS(7);
     {
         float* o = A.msg + (int64_t)edge * dn;
 #pragma unroll
@@ -433,8 +457,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, dn, get4(mm[t], g), edge_ok);
         }
     }
+    TS(8);
 }
-
 #undef wbuf_at
 
 // ------------------------------------------------------------------------------------------------------
@@ -488,6 +512,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     const float* wf2 = grp == 1 ? A.wf2_in : A.wf2_out;
     const float* wfe = grp == 1 ? A.wfe_in : A.wfe_out;
     int c = 0;
+    TS_INIT();
+    TS(0);
     if (flow) {
         chunk_fetch<chunk_q(N4_2)>(wf2, N4_2, tid, wbuf[0]);
     } else {
@@ -505,6 +531,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             for (int g = 0; g < 4; ++g) set4(dE[t], g, ldrow<EXACT>(p, 32 * t + 8 * g + 4 * lh, de));
     };
     __syncthreads();  // chunk 0 is in wbuf[0]
+    TS(1);
 
     if (flow) {
         // ---- B1: dZM ------------------------------------------------------------------------------------
@@ -540,6 +567,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
                     strow<EXACT>(o2, n, dn, v, edge_ok);
                 }
         }
+        TS(2);
         // ---- B2: dZF = (Wf2^T dZM) (.) [HF > 0] -------------------------------------------------------------
         f32x16 dzf[TF];
 #pragma unroll
@@ -557,6 +585,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             __syncthreads();
             ++c;
         }
+        TS(3);
         {
             const float* hp = A.HF + (int64_t)edge * hn;
             float* o2 = A.dZF + (int64_t)edge * hn;
@@ -574,6 +603,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
                 }
             }
         }
+        TS(4);
         // ---- B3: dE' += Wfe^T dZF -------------------------------------------------------------------------------
         load_de();
 #pragma unroll
@@ -591,6 +621,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         }
     }
 
+    TS(5);
     if (!flow) load_de();
     // ---- B4: classifier ---------------------------------------------------------------------------------------
     {
@@ -632,6 +663,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             }
     }
 
+    TS(6);
     // ---- B5: dZ1 = (W2^T dZ2) (.) [H1 > 0] -----------------------------------------------------------------------
     f32x16 dz1[T1];
 #pragma unroll
@@ -652,6 +684,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         __syncthreads();
         ++c;
     }
+    TS(7);
     {
         const float* hp = A.H1 + (int64_t)edge * he;
         float* o2 = A.dZ1 + (int64_t)edge * he;
@@ -675,6 +708,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         }
     }
 
+    TS(8);
     // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, up to 64 (padded) output columns per pass ---------------------------------
     for (int pass = 0; pass < npass6; ++pass) {
         f32x16 dc[2];
@@ -727,6 +761,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             }
         }
     }
+    TS(9);
 }
 
 // dst[r][c] = (r < rows && c < cols) ? src[r * lds + c0 + c] : 0   for r < rows_pad, c < cols_pad (ld = cols_pad)
@@ -765,6 +800,37 @@ int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float
     return MPNHIP_OK;
 }
 
+#ifdef MPNHIP_CHAIN_TS
+// stamp buffer of one kernel kind; the 40th launch is synchronised and dumped to "<MPNHIP_CHAIN_TS>_<name>.txt"
+struct StampDump {
+    long long* buf = nullptr;
+    size_t cap = 0;
+    int launches = 0;
+    long long* prepare(unsigned blocks, hipStream_t s) {
+        if (!getenv("MPNHIP_CHAIN_TS")) return nullptr;
+        const size_t need = (size_t)blocks * 4 * 16 * sizeof(long long);
+        if (need > cap) { if (buf) (void)hipFree(buf); if (hipMalloc(&buf, need) != hipSuccess) return nullptr; cap = need; }
+        (void)hipMemsetAsync(buf, 0, need, s);
+        return buf;
+    }
+    void finish(const char* name, unsigned blocks, hipStream_t s) {
+        if (!buf || !getenv("MPNHIP_CHAIN_TS") || ++launches != 40) return;
+        (void)hipStreamSynchronize(s);
+        std::vector<long long> h((size_t)blocks * 64);
+        (void)hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        std::string path = std::string(getenv("MPNHIP_CHAIN_TS")) + "_" + name + ".txt";
+        if (FILE* f = fopen(path.c_str(), "w")) {
+            for (unsigned w = 0; w < blocks * 4; ++w) {
+                for (int i = 0; i < 16; ++i) fprintf(f, "%lld ", h[(size_t)w * 16 + i]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+};
+static StampDump g_stamp_fwd, g_stamp_bwd;
+#endif
+
 static int chain_variant(int he, int de, int hn, int dn) {
     const int t1 = (he + 31) / 32, t2 = (de + 31) / 32, tf = (hn + 31) / 32, td = (dn + 31) / 32;
     if (t1 == 10 && t2 == 2 && tf == 7 && td == 4) return 128;
@@ -778,9 +844,13 @@ bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k
            hc % 4 == 0 && (k1a % 16 == 0) && (k1b % 16 == 0) && (k1a + k1b) >= 16;
 }
 
-int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s) {
-    if (a.E <= 0) return MPNHIP_OK;
+int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
+    if (a_in.E <= 0) return MPNHIP_OK;
+    EdgeChainArgs a = a_in;
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+#ifdef MPNHIP_CHAIN_TS
+    a.ts = g_stamp_fwd.prepare(blocks, s);
+#endif
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
@@ -793,13 +863,20 @@ int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s) {
         case 32: hipLaunchKernelGGL((edge_chain_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
         default: set_error("edge_chain: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
+#ifdef MPNHIP_CHAIN_TS
+    g_stamp_fwd.finish("fwd", blocks, s);
+#endif
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
 
-int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s) {
-    if (a.E <= 0) return MPNHIP_OK;
+int launch_edge_chain_bwd(const EdgeChainBwdArgs& a_in, hipStream_t s) {
+    if (a_in.E <= 0) return MPNHIP_OK;
+    EdgeChainBwdArgs a = a_in;
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+#ifdef MPNHIP_CHAIN_TS
+    a.ts = g_stamp_bwd.prepare(blocks, s);
+#endif
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
@@ -812,6 +889,9 @@ int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s) {
         case 32: hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
         default: set_error("edge_chain_bwd: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
+#ifdef MPNHIP_CHAIN_TS
+    g_stamp_bwd.finish("bwd", blocks, s);
+#endif
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
