@@ -58,7 +58,7 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // behind a branch makes the compiler's s_waitcnt bookkeeping conservative.
 template <int Q>
 __device__ __forceinline__ void chunk_fetch(const float* src, int n4, int tid, float* buf) {
-    static_assert(Q >= 1 && Q * 1024 <= CH_FLOATS, "chunk larger than its buffer");
+    static_assert(Q >= 1 && Q <= 5, "chunk larger than the largest buffer");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void chain_half(const f32x16& src, int r0, f32x16* ou
 
 // T1 = ceil(he/32), T2 = ceil(de/32), TF = ceil(hn/32), TD = ceil(dn/32); hc <= 32.  Capital names = padded widths
 // (weight-image pitches, loop bounds); A.he / A.de / ... = real widths (global row strides, load / store masks).
-constexpr int chain_waves(int t1) { return t1 <= 3 ? 4 : 2; }  // waves per SIMD the register budget allows
+constexpr int chain_waves(int t1) { return t1 <= 3 ? 3 : 2; }  // waves per SIMD the register budget allows
 
 template <int T1, int T2, int TF, int TD, bool EXACT>
 __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeChainArgs A) {
@@ -169,17 +169,27 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     constexpr int KC2 = 64;                       // phase-2 chunk: [<=64 k][DE]
     constexpr int NC4 = 64;                       // phase-4 chunk: [DE k][<=64 n]
     constexpr int KC5 = 32;                       // phase-5 chunk: [32 k][DN]
-    static_assert(HE * KC1 <= CH_FLOATS && KC2 * DE <= CH_FLOATS && DE * NC4 <= CH_FLOATS && KC5 * DN <= CH_FLOATS &&
-                      DE * HC <= CH_FLOATS, "chunk too large");
 
+    // ---- chunk schedule (float4 counts; every chunk is a contiguous run of its image) -----------------------
+    constexpr int NCH2 = (HE + KC2 - 1) / KC2;
+    constexpr int NCH4 = (HN + NC4 - 1) / NC4;
+    constexpr int NCH5 = HN / KC5;
+    constexpr int N4_1 = KC1 * HE / 4;                       // phase 1: 16 rows of W1T
+    constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4;           // phase 2, first chunk
+    constexpr int N4_3 = DE * HC / 4;                        // classifier layer 0, whole
+    constexpr int N4_4_0 = DE * cmin(NC4, HN) / 4;           // phase 4, first column block
+    constexpr int N4_5 = KC5 * DN / 4;                       // phase 5: 32 rows of Wf2T
+    // chunk buffer: whole 1 KiB DMA pieces of the largest chunk
+    constexpr int CHF = 1024 * chunk_q(cmax(cmax(N4_1, N4_2_0), cmax(cmax(N4_3, N4_4_0), N4_5)));
+    static_assert(CHF <= CH_FLOATS, "chunk too large");
     // ONE LDS object (a second one beside the LDS-DMA target makes hipcc drain vmcnt before unrelated ds_reads):
     // two weight-chunk buffers, two phase-1 input staging buffers, then the biases [b2 (DE) | bc1 (32) | wc2 (32) | bf2 (DN)], zero-padded
     constexpr int XS_FLOATS = 4 * 2 * 64 * 4;  // phase-1 input staging per buffer: 4 waves x 2 pieces x 64 lanes x 16 B
-    __shared__ __attribute__((aligned(16))) float smem[2 * CH_FLOATS + 2 * XS_FLOATS + DE + 64 + DN];
+    __shared__ __attribute__((aligned(16))) float smem[2 * CHF + 2 * XS_FLOATS + DE + 64 + DN];
     float* const wbuf0 = smem;
-    float* const xs0 = smem + 2 * CH_FLOATS;
+    float* const xs0 = smem + 2 * CHF;
     float* const sbias = xs0 + 2 * XS_FLOATS;
-#define wbuf_at(i) (wbuf0 + ((i) & 1) * CH_FLOATS)
+#define wbuf_at(i) (wbuf0 + ((i) & 1) * CHF)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
@@ -204,15 +214,6 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
 
-    // ---- chunk schedule (float4 counts; every chunk is a contiguous run of its image) -----------------------
-    constexpr int NCH2 = (HE + KC2 - 1) / KC2;
-    constexpr int NCH4 = (HN + NC4 - 1) / NC4;
-    constexpr int NCH5 = HN / KC5;
-    constexpr int N4_1 = KC1 * HE / 4;                       // phase 1: 16 rows of W1T
-    constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4;           // phase 2, first chunk
-    constexpr int N4_3 = DE * HC / 4;                        // classifier layer 0, whole
-    constexpr int N4_4_0 = DE * cmin(NC4, HN) / 4;           // phase 4, first column block
-    constexpr int N4_5 = KC5 * DN / 4;                       // phase 5: 32 rows of Wf2T
     const float* wf1 = grp == 1 ? A.wf1T_in : A.wf1T_out;   // NCH4 column-block images [DE][<=64], block i at DE * 64 * i
     const float* wf2 = grp == 1 ? A.wf2T_in : A.wf2T_out;
 
@@ -241,6 +242,29 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(h1[t], g, ldrow<EXACT>(pr, 32 * t + 8 * g + 4 * lh, he));
     }
+    // Pc[col] joins H1 after the MFMAs, two tiles (8 row pieces) per gather round; round r is issued one chunk before
+    // the phase-2 chunk that consumes tiles 2r, 2r+1 (round 0: in the last phase-1 chunk)
+    float4 pcv[8];
+    const float* pc = A.P + (int64_t)col * A.pw + he;
+    float* sv = A.save_h1 ? A.save_h1 + (int64_t)edge * he : nullptr;
+    auto pc_issue = [&](int r) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (2 * r + (g >> 2) < T1) pcv[g] = ldrow<EXACT>(pc, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
+    };
+    auto pc_finish = [&](int r) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (2 * r + (g >> 2) < T1) add4(h1[2 * r + (g >> 2)], g & 3, pcv[g]);
+        relu16(h1[2 * r]);
+        if (2 * r + 1 < T1) relu16(h1[2 * r + 1]);
+        if (sv) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (2 * r + (g >> 2) < T1)
+                    strow<EXACT>(sv, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[2 * r + (g >> 2)], g & 3), edge_ok);
+        }
+    };
     {
         // lane (j, h) reads its edge's features 16 bytes at a time: k = 8u + 4h + (0..3)
         const float* xa = A.xa + (int64_t)edge * A.ldxa + 4 * lh;
@@ -258,9 +282,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         xfetch(0, 0);
         __syncthreads();  // chunk 0 is in wbuf[0]
         TS(1);
-        for (int i = 0; i < nch1; ++i) {
-            // next chunk: the following 16 rows of W1T, or the first chunk of phase 2 (scalar selects, no branch)
-            const bool last1 = i + 1 >= nch1;
+        // One phase-1 chunk (16 contraction rows).  `last`: the chunk also carries the first Pc gather round.
+        auto p1_chunk = [&](int i, bool last1) {
+            // next chunk: the following 16 rows of W1T, or the first chunk of phase 2
             const float* nsrc = last1 ? A.w2T : A.w1T + (int64_t)(i + 1) * KC1 * HE;
             const int nn4 = last1 ? N4_2_0 : N4_1;
             // (read this chunk's inputs BEFORE the DMAs go out: hipcc drains vmcnt in front of a plain ds_read_b128 that
@@ -271,7 +295,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
                 xcur[u] = *reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_FLOATS + (wave * 2 + u) * 256 + lane * 4);
             __builtin_amdgcn_sched_barrier(0);
             chunk_fetch<chunk_q(cmax(N4_1, N4_2_0))>(nsrc, nn4, tid, wbuf_at(c + 1));
-            xfetch(last1 ? i * KC1 : (i + 1) * KC1, c + 1);  // the last iteration re-reads its own columns (unused)
+            if (last1) pc_issue(0);
+            else xfetch((i + 1) * KC1, c + 1);
             const float* ws = wbuf_at(c) + 4 * lh * HE + lj;
             // 8 steps (u, q) of T1 MFMAs each; the weights of step s+1 are fetched before the MFMAs of step s
             float a[2][T1];
@@ -293,48 +318,44 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             }
             __syncthreads();
             ++c;
-        }
-    }
-    TS(2);
-    {
-        const float* pc = A.P + (int64_t)col * A.pw + he;
-        float* sv = A.save_h1 ? A.save_h1 + (int64_t)edge * he : nullptr;
-#pragma unroll
-        for (int t = 0; t < T1; t += 2) {
-            __builtin_amdgcn_sched_barrier(0);  // two tiles (8 row pieces) of gathers in flight at a time
-            constexpr int NP = 8;
-            float4 v[NP];
-#pragma unroll
-            for (int g = 0; g < NP; ++g)
-                if (t + (g >> 2) < T1) v[g] = ldrow<EXACT>(pc, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
-#pragma unroll
-            for (int g = 0; g < NP; ++g)
-                if (t + (g >> 2) < T1) add4(h1[t + (g >> 2)], g & 3, v[g]);
-            relu16(h1[t]);
-            if (t + 1 < T1) relu16(h1[t + 1]);
-            if (sv) {
-#pragma unroll
-                for (int g = 0; g < NP; ++g)
-                    if (t + (g >> 2) < T1) strow<EXACT>(sv, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[t + (g >> 2)], g & 3), edge_ok);
-            }
-        }
+        };
+        for (int i = 0; i + 1 < nch1; ++i) p1_chunk(i, false);
+        p1_chunk(nch1 - 1, true);
     }
 
     TS(3);
     // ---- phase 2: e'^T = relu(W2 H1^T + b2) -----------------------------------------------------------
+    // Chunk i contracts H1 tiles 2i and 2i+1.  Their finishing touches -- + Pc[col] (gather round i, issued one chunk
+    // earlier), ReLU, the training-mode save -- come first; then the prefetches for the NEXT chunk go out (weights by
+    // LDS-DMA, gather round i+1, and two tiles of phase 4's C-in into the registers the consumed H1 tiles free), so that
+    // every gather has a whole chunk of MFMAs to land and is drained by the barrier that ends the chunk.
     f32x16 en[T2];
+    f32x16 hf[TF];
+    const float* pf = A.P + (int64_t)col * A.pw + 2 * he + (grp == 1 ? hn : 0);  // (self-loop blocks gather flow_out's and drop it)
+    auto pf_issue = [&](int t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
+    };
 #pragma unroll
     for (int t = 0; t < T2; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) set4(en[t], g, *reinterpret_cast<const float4*>(sbias + 32 * t + 8 * g + 4 * lh));
+    static_assert(NCH2 == (T1 + 1) / 2, "one Pc gather round per phase-2 chunk");
 #pragma unroll
     for (int i = 0; i < NCH2; ++i) {
+        pc_finish(i);
         // next: rows 64 (i + 1) .. of W2T, or the classifier image
         const bool more = i + 1 < NCH2;
         const int rows_n = more ? (HE - (i + 1) * KC2 < KC2 ? HE - (i + 1) * KC2 : KC2) : 0;  // folds: i is unrolled
         const float* nsrc = more ? A.w2T + (i + 1) * KC2 * DE : A.wc1T;
         const int nn4 = more ? rows_n * DE / 4 : N4_3;
+        __builtin_amdgcn_sched_barrier(0);
         chunk_fetch<chunk_q(cmax(N4_2_0, N4_3))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        if (more) pc_issue(i + 1);
+        if (i >= 1) {
+            if (2 * (i - 1) < TF) pf_issue(2 * (i - 1));
+            if (2 * (i - 1) + 1 < TF) pf_issue(2 * (i - 1) + 1);
+        }
         const float* ws = wbuf_at(c);
         chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
         if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
@@ -352,17 +373,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     }
 
     TS(4);
-    // C-in of phase 4 (gathered per-node flow projections), issued here so that the gather's latency hides behind the
-    // classifier; it is drained, with the chunk prefetch, by the barrier that ends phase 3 (self-loop blocks gather
-    // the flow_out columns and drop them)
-    f32x16 hf[TF];
-    {
-        const float* pf = A.P + (int64_t)col * A.pw + 2 * he + (grp == 1 ? hn : 0);
+    // phase-4 C-in tiles the phase-2 chunks did not cover (none for the shipped width sets)
 #pragma unroll
-        for (int t = 0; t < TF; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
-    }
+    for (int t = 2 * (NCH2 - 1); t < TF; ++t) pf_issue(t);
     // ---- phase 3: classifier ----------------------------------------------------------------------------
     {
         f32x16 hcv;
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         if (A.logits && edge_ok && lh == 0) A.logits[A.perm[edge]] = part + other + A.bc2[0];
     }
 #undef wbuf_at
-#define wbuf_at(i) (wbuf0 + ((i) & 1) * CH_FLOATS)
+#define wbuf_at(i) (wbuf0 + ((i) & 1) * CHF)
     TS(5);
     if (!flow) return;  // self loops take part in the edge update only (mpn.py:85,91)
 

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 PH = {
-    "fwd": [("start->chunk0", 0, 1, 0), ("phase1 loop", 1, 2, 640), ("Pc add/save", 2, 3, 0), ("phase2", 3, 4, 320),
+    "fwd": [("start->chunk0", 0, 1, 0), ("phase1 loop", 1, 3, 640), ("phase2 (+Pc, Pf gathers)", 3, 4, 320),
             ("phase3", 4, 5, 32), ("phase4", 5, 6, 224), ("phase5 mfma", 6, 7, 448), ("epilogue", 7, 8, 0)],
     "bwd": [("start->chunk0", 0, 1, 0), ("B1 dZM", 1, 2, 0), ("B2 mfma", 2, 3, 448), ("HF mask/save", 3, 4, 0),
             ("B3", 4, 5, 224), ("B4+dZ2", 5, 6, 32), ("B5 mfma", 6, 7, 320), ("H1 mask/save", 7, 8, 0), ("B6", 8, 9, 640)],
@@ -26,10 +26,10 @@ def main():
           (len(a), life.min(), np.median(life), life.max(), a[:, last].max() - a[:, 0].min()))
     order = np.argsort(life)
     fast, slow = order[: len(order) // 4], order[-(len(order) // 4):]
-    print("%-16s %9s %9s %9s %9s   %s" % ("phase", "mean", "fast25%", "slow25%", "min", "ideal"))
+    print("%-26s %9s %9s %9s %9s   %s" % ("phase", "mean", "fast25%", "slow25%", "min", "ideal"))
     for name, i, j, mf in PH[kind]:
         d = a[:, j] - a[:, i]
-        print("%-16s %9.0f %9.0f %9.0f %9d   %d" % (name, d.mean(), d[fast].mean(), d[slow].mean(), d.min(), mf * 64))
+        print("%-26s %9.0f %9.0f %9.0f %9d   %d" % (name, d.mean(), d[fast].mean(), d[slow].mean(), d.min(), mf * 64))
 
 if __name__ == "__main__":
     main()
