@@ -545,7 +545,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0;
             a.he = he; a.de = de; a.hn = hn; a.dn = dn; a.hc = cls.out_dims[0];
             a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
-            a.dAGG = p.dAGG; a.M = b.M; a.ARG = b.ARG; a.HF = b.HF[0]; a.HC = b.HC[0]; a.H1 = b.HE[0]; a.e_s = e_s;
+            a.dAGG = p.dAGG; a.mask = reinterpret_cast<const unsigned*>(b.MK); a.ARG = b.ARG;
             a.dlog = grad_logits + (size_t)b_ * E;
             a.dE_io = dzed[1]; a.dZM = dzfl[1]; a.dZF = dzfl[0]; a.dZc = dzcl[0]; a.dZ1 = dzed[0];
             a.dE0 = p.dE0; a.dEprev = step == 1 ? p.dE0 : p.dZed[ne - 1] + (size_t)(b_ - 1) * es;

@@ -38,6 +38,7 @@ struct EdgeChainArgs {
     float* save_h1;        // [E, he] / nullptr  (training: activations kept for the backward pass)
     float* save_hc;        // [E, hc] / nullptr
     float* save_hf;        // [E, hn] / nullptr
+    unsigned* save_mask;   // [chain_mask_ints(E, ...)] / nullptr: ReLU masks as bits, in the kernels' private lane layout
 #ifdef MPNHIP_CHAIN_TS
     long long* ts;         // debug build: 16 cycle stamps per wave
 #endif
@@ -53,12 +54,8 @@ struct EdgeChainBwdArgs {
     const int* perm;
     const int* seg_ptr;
     const float* dAGG;     // [N, 2dn] gradient of the aggregated messages [flow_in | flow_out]
-    const float* M;        // saved activations (sorted edge order)
+    const unsigned* mask;  // ReLU masks written by the forward kernel of this step (save_mask)
     const int* ARG;        // [N, 2dn] arg max (max aggregation) or nullptr
-    const float* HF;
-    const float* HC;
-    const float* H1;
-    const float* e_s;
     const float* dlog;     // [E] gradient of this step's logits, ORIGINAL edge order
     float* dE_io;          // [E, de] in: gradient w.r.t. e_s from the later step; out: dZ of the last edge layer
     float* dZM;            // [E, dn] out
@@ -80,6 +77,16 @@ struct EdgeChainBwdArgs {
 };
 int launch_edge_chain_bwd(const EdgeChainBwdArgs& a, hipStream_t s);
 
+// ReLU-mask words per lane (two 32-feature tiles per 32-bit word, one word range per section H1 | e' | HC | HF | M) and
+// the size of one step's mask buffer: every wave tile (4 per block of 128 edges, + the launchers' 3 spare blocks)
+// holds NW x 64 words
+static inline int chain_mask_words(int he, int de, int hn, int dn) {
+    auto w = [](int v) { return ((v + 31) / 32 + 1) / 2; };
+    return w(he) + w(de) + 1 + w(hn) + w(dn);
+}
+static inline size_t chain_mask_ints(int64_t E, int he, int de, int hn, int dn) {
+    return (size_t)((E + 127) / 128 + 3) * 4 * 64 * (size_t)chain_mask_words(he, de, hn, dn);
+}
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s);

@@ -103,6 +103,26 @@ __device__ __forceinline__ float4 get4(const f32x16& a, int g) {
     return make_float4(a[4 * g + 0], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
 }
 
+// ReLU masks travel from the forward to the backward chain kernel as bits: bit r of a tile's 16-bit mask = accumulator
+// register r of that lane is > 0.  Both kernels map (block, wave, lane) to the same edge and feature rows, so the
+// words are private to a lane: word w of wave-tile q sits at mask[(q * NW + w) * 64 + lane] (256 contiguous bytes per
+// wave store / load).  Word ranges per section (two tiles per word): H1 | e' | HC | HF | M.
+__device__ __forceinline__ unsigned mask16(const f32x16& a) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (a[r] > 0.f ? 1u : 0u) << r;
+    return m;
+}
+__device__ __forceinline__ void apply_mask(f32x16& a, unsigned word, int shift) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        // bit -> all-ones / zero, AND with the float's bits
+        const int keep = __builtin_amdgcn_sbfe(word, shift + r, 1);
+        const float x = a[r];  // (bit_cast straight on the vector element reads element 0: clang 19 / ROCm 7.2)
+        a[r] = __int_as_float(__float_as_int(x) & keep);
+    }
+}
+
 // One chained product step: `src` (a 32-feature accumulator tile, already activated) is the B operand for
 // the TOUT output tiles whose weights sit in the chunk image `ws` ([kc][nc], this source tile at rows
 // krow0 .. krow0+31, output tile t at columns ncol0 + 32 t).  lane_off = 4h * nc + i.
@@ -182,6 +202,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     // chunk buffer: whole 1 KiB DMA pieces of the largest chunk
     constexpr int CHF = 1024 * chunk_q(cmax(cmax(N4_1, N4_2_0), cmax(cmax(N4_3, N4_4_0), N4_5)));
     static_assert(CHF <= CH_FLOATS, "chunk too large");
+    // ReLU-mask words per lane for the backward kernel (edge_chain.h: chain_mask_words)
+    constexpr int W_H1 = 0, W_E = W_H1 + (T1 + 1) / 2, W_HC = W_E + (T2 + 1) / 2, W_HF = W_HC + 1, W_M = W_HF + (TF + 1) / 2,
+                  NW = W_M + (TD + 1) / 2;
     // ONE LDS object (a second one beside the LDS-DMA target makes hipcc drain vmcnt before unrelated ds_reads):
     // two weight-chunk buffers, two phase-1 input staging buffers, then the biases [b2 (DE) | bc1 (32) | wc2 (32) | bf2 (DN)], zero-padded
     constexpr int XS_FLOATS = 4 * 2 * 64 * 4;  // phase-1 input staging per buffer: 4 waves x 2 pieces x 64 lanes x 16 B
@@ -213,6 +236,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const int K1 = A.k1a + A.k1b;                 // columns of [e0 | e] (multiples of 16)
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
+    unsigned* const mkp = A.save_mask ? A.save_mask + ((int64_t)(blockIdx.x * 4 + wave) * NW) * 64 + lane : nullptr;
 
     const float* wf1 = grp == 1 ? A.wf1T_in : A.wf1T_out;   // NCH4 column-block images [DE][<=64], block i at DE * 64 * i
     const float* wf2 = grp == 1 ? A.wf2T_in : A.wf2T_out;
@@ -264,6 +288,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
                 if (2 * r + (g >> 2) < T1)
                     strow<EXACT>(sv, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[2 * r + (g >> 2)], g & 3), edge_ok);
         }
+        if (mkp) mkp[(W_H1 + r) * 64] = mask16(h1[2 * r]) | (2 * r + 1 < T1 ? mask16(h1[2 * r + 1]) << 16 : 0u);
     };
     {
         // lane (j, h) reads its edge's features 16 bytes at a time: k = 8u + 4h + (0..3)
@@ -370,6 +395,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, de, get4(en[t], g), edge_ok);
         }
+        if (mkp) {
+#pragma unroll
+            for (int t = 0; t < T2; t += 2) mkp[(W_E + (t >> 1)) * 64] = mask16(en[t]) | (t + 1 < T2 ? mask16(en[t + 1]) << 16 : 0u);
+        }
     }
 
     TS(4);
@@ -390,6 +419,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         __syncthreads();
         ++c;
         relu16(hcv);
+        if (mkp) mkp[W_HC * 64] = mask16(hcv);
         if (A.save_hc) {
             float* o = A.save_hc + (int64_t)edge * hc;
 #pragma unroll
@@ -441,6 +471,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
                 for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, hn, get4(hf[t], g), edge_ok);
             }
         }
+        if (mkp) {
+#pragma unroll
+            for (int t = 0; t < TF; t += 2) mkp[(W_HF + (t >> 1)) * 64] = mask16(hf[t]) | (t + 1 < TF ? mask16(hf[t + 1]) << 16 : 0u);
+        }
     }
 
     TS(6);
@@ -469,6 +503,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, dn, get4(mm[t], g), edge_ok);
         }
+        if (mkp) {
+#pragma unroll
+            for (int t = 0; t < TD; t += 2) mkp[(W_M + (t >> 1)) * 64] = mask16(mm[t]) | (t + 1 < TD ? mask16(mm[t + 1]) << 16 : 0u);
+        }
     }
     TS(8);
 }
@@ -490,9 +528,24 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     constexpr int NR3 = 64;   // B3 chunk: [<=64 n][DE]
     constexpr int NR5 = 16;   // B5 chunk: [16 n][HE]
     constexpr int NR6 = 64;   // B6 chunk: [<=64 n][64 k]
-    static_assert(NR2 * HN <= CH_FLOATS && NR3 * DE <= CH_FLOATS && NR5 * HE <= CH_FLOATS && NR6 * 64 <= CH_FLOATS, "chunk");
+    // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6; float4 counts of the contiguous chunks ------------
+    constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
+    constexpr int N4_2 = NR2 * HN / 4;                  // 16 rows of Wf2
+    constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4;      // first 64 rows of Wfe
+    constexpr int N4_4 = HC * DE / 4;                   // Wc1, whole
+    constexpr int N4_5 = NR5 * HE / 4;                  // 16 rows of W2
+    constexpr int N4_6MAX = cmin(NR6, HE) * 64 / 4;     // <= 64 rows of one W1e column-pass image [HE][ncol6]
+    constexpr int CHF = 1024 * chunk_q(cmax(cmax(N4_2, N4_3_0), cmax(cmax(N4_4, N4_5), N4_6MAX)));
+    static_assert(CHF <= CH_FLOATS, "chunk too large");
+    // mask words per lane (edge_chain.h: chain_mask_words)
+    constexpr int W_H1 = 0, W_E = W_H1 + (T1 + 1) / 2, W_HC = W_E + (T2 + 1) / 2, W_HF = W_HC + 1, W_M = W_HF + (TF + 1) / 2,
+                  NW = W_M + (TD + 1) / 2;
 
-    __shared__ __attribute__((aligned(16))) float wbuf[2][CH_FLOATS];
+    // one LDS object: two weight-chunk buffers, then wc2 (zero-padded to 32)
+    __shared__ __attribute__((aligned(16))) float smem[2 * CHF + 32];
+    float* const wbuf0 = smem;
+    float* const swc2 = smem + 2 * CHF;
+#define wbuf_at(i) (wbuf0 + ((i) & 1) * CHF)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
     const int he = A.he, de = A.de, hn = A.hn, dn = A.dn, hc = A.hc;
@@ -515,70 +568,81 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     const int npass6 = KEp / 64 > 0 ? KEp / 64 : 1;
     const int ncol6 = KEp < 64 ? KEp : 64;    // columns per B6 pass
 
-    // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6; float4 counts of the contiguous chunks ------------
-    constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
-    constexpr int N4_2 = NR2 * HN / 4;                  // 16 rows of Wf2
-    constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4;      // first 64 rows of Wfe
-    constexpr int N4_4 = HC * DE / 4;                   // Wc1, whole
-    constexpr int N4_5 = NR5 * HE / 4;                  // 16 rows of W2
-    constexpr int N4_6MAX = cmin(NR6, HE) * 64 / 4;     // <= 64 rows of one W1e column-pass image [HE][ncol6]
     const float* wf2 = grp == 1 ? A.wf2_in : A.wf2_out;
     const float* wfe = grp == 1 ? A.wfe_in : A.wfe_out;
     int c = 0;
     TS_INIT();
     TS(0);
     if (flow) {
-        chunk_fetch<chunk_q(N4_2)>(wf2, N4_2, tid, wbuf[0]);
+        chunk_fetch<chunk_q(N4_2)>(wf2, N4_2, tid, wbuf_at(0));
     } else {
-        chunk_fetch<chunk_q(N4_4)>(A.wc1, N4_4, tid, wbuf[0]);
+        chunk_fetch<chunk_q(N4_4)>(A.wc1, N4_4, tid, wbuf_at(0));
     }
+    if (tid < 32) swc2[tid] = tid < hc ? A.wc2[tid] : 0.f;
 
-    // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators (loaded after B2, when the
-    // dZM tiles are dead -- B2 is the register peak of this kernel)
-    f32x16 dE[T2];
-    auto load_de = [&]() {
+    // ---- everything this wave reads from global memory besides the weights goes out NOW, before the first barrier:
+    // the ReLU masks (a few words), the gathered aggregate gradient, the incoming edge gradient, the logit gradient.
+    unsigned mk[NW];
+    {
+        const unsigned* mp = A.mask + ((int64_t)(blockIdx.x * 4 + wave) * NW) * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mk[w] = mp[w * 64];
+    }
+    f32x16 dE[T2];   // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators
+    {
         const float* p = A.dE_io + (int64_t)edge * de;
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(dE[t], g, ldrow<EXACT>(p, 32 * t + 8 * g + 4 * lh, de));
-    };
-    __syncthreads();  // chunk 0 is in wbuf[0]
-    TS(1);
-
+    }
+    const float dl = A.dlog[A.perm[edge]];
+    f32x16 dzm[TD];
     if (flow) {
-        // ---- B1: dZM ------------------------------------------------------------------------------------
-        f32x16 dzm[TD];
-        {
-            const int row = A.srow[edge];
-            const float* da = A.dAGG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0);
-            const int* ar = A.ARG ? A.ARG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0) : nullptr;
-            float scale = 1.f;
-            if (A.agg == MPNHIP_AGG_MEAN) {
-                const int key = grp * A.N + row;
-                const int cnt = A.seg_ptr[key + 1] - A.seg_ptr[key];
-                scale = (float)(cnt > 0 ? cnt : 1);
-            }
-            const float* mp = A.M + (int64_t)edge * dn;
-            float* o2 = A.dZM + (int64_t)edge * dn;
+        // ---- B1 loads: dZM = gather(dAGG)[row] (node_agg_fn backward, mpn.py:89,96) ----------------------------
+        const int row = A.srow[edge];
+        const float* da = A.dAGG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0);
+#pragma unroll
+        for (int t = 0; t < TD; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) set4(dzm[t], g, ldrow<EXACT>(da, 32 * t + 8 * g + 4 * lh, dn));
+        if (A.agg == MPNHIP_AGG_MEAN) {
+            const int key = grp * A.N + row;
+            const int cnt = A.seg_ptr[key + 1] - A.seg_ptr[key];
+            const float scale = (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+            for (int t = 0; t < TD; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dzm[t][r] /= scale;
+        }
+        if (A.agg == MPNHIP_AGG_MAX) {
+            const int* ar = A.ARG + (int64_t)row * 2 * dn + (grp == 0 ? dn : 0);
 #pragma unroll
             for (int t = 0; t < TD; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = 32 * t + 8 * g + 4 * lh;
-                    float4 v = ldrow<EXACT>(da, n, dn);
-                    const float4 m = ldrow<EXACT>(mp, n, dn);
-                    if (A.agg == MPNHIP_AGG_MEAN) { v.x /= scale; v.y /= scale; v.z /= scale; v.w /= scale; }
-                    if (A.agg == MPNHIP_AGG_MAX) {
-                        const int4 a = *reinterpret_cast<const int4*>(ar + (n < dn ? n : 0));
-                        v.x = a.x == edge_raw ? v.x : 0.f; v.y = a.y == edge_raw ? v.y : 0.f;
-                        v.z = a.z == edge_raw ? v.z : 0.f; v.w = a.w == edge_raw ? v.w : 0.f;
-                    }
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    const int4 q = *reinterpret_cast<const int4*>(ar + (EXACT || n < dn ? n : 0));
+                    float4 v = get4(dzm[t], g);
+                    v.x = q.x == edge_raw ? v.x : 0.f; v.y = q.y == edge_raw ? v.y : 0.f;
+                    v.z = q.z == edge_raw ? v.z : 0.f; v.w = q.w == edge_raw ? v.w : 0.f;
                     set4(dzm[t], g, v);
-                    strow<EXACT>(o2, n, dn, v, edge_ok);
                 }
+        }
+    }
+    __syncthreads();  // chunk 0 is in wbuf[0]; every load above has landed
+    TS(1);
+
+    if (flow) {
+        // ---- B1: dZM = gathered gradient (.) [M > 0] -----------------------------------------------------------
+        {
+            float* o2 = A.dZM + (int64_t)edge * dn;
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+                apply_mask(dzm[t], mk[W_M + (t >> 1)], 16 * (t & 1));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, dn, get4(dzm[t], g), edge_ok);
+            }
         }
         TS(2);
         // ---- B2: dZF = (Wf2^T dZM) (.) [HF > 0] -------------------------------------------------------------
@@ -592,41 +656,32 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             const bool more = i + 1 < NCH2;  // folds: i is unrolled
             const float* nsrc = more ? wf2 + (i + 1) * NR2 * HN : wfe;
             const int nn4 = more ? N4_2 : N4_3_0;
-            chunk_fetch<chunk_q(cmax(N4_2, N4_3_0))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
+            chunk_fetch<chunk_q(cmax(N4_2, N4_3_0))>(nsrc, nn4, tid, wbuf_at(c + 1));
             // chunk rows = 16 contraction indices n = 16 i .. 16 i + 15 = registers 8 (i & 1) .. + 7 of source tile i / 2
-            chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf[c & 1], HN, 4 * lh * HN + lj);
+            chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf_at(c), HN, 4 * lh * HN + lj);
             __syncthreads();
             ++c;
         }
         TS(3);
         {
-            const float* hp = A.HF + (int64_t)edge * hn;
             float* o2 = A.dZF + (int64_t)edge * hn;
 #pragma unroll
             for (int t = 0; t < TF; ++t) {
+                apply_mask(dzf[t], mk[W_HF + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = 32 * t + 8 * g + 4 * lh;
-                    const float4 m = ldrow<EXACT>(hp, n, hn);
-                    float4 v = get4(dzf[t], g);
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                    set4(dzf[t], g, v);
-                    strow<EXACT>(o2, n, hn, v, edge_ok);
-                }
+                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, hn, get4(dzf[t], g), edge_ok);
             }
         }
         TS(4);
         // ---- B3: dE' += Wfe^T dZF -------------------------------------------------------------------------------
-        load_de();
 #pragma unroll
         for (int i = 0; i < NCH3; ++i) {
             const bool more = i + 1 < NCH3;
             const int rows_n = more ? (HN - (i + 1) * NR3 < NR3 ? HN - (i + 1) * NR3 : NR3) : 0;
             const float* nsrc = more ? wfe + (i + 1) * NR3 * DE : A.wc1;
             const int nn4 = more ? rows_n * DE / 4 : N4_4;
-            chunk_fetch<chunk_q(cmax(N4_3_0, N4_4))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
-            const float* ws = wbuf[c & 1];
+            chunk_fetch<chunk_q(cmax(N4_3_0, N4_4))>(nsrc, nn4, tid, wbuf_at(c + 1));
+            const float* ws = wbuf_at(c);
             chain_tile<T2>(dzf[2 * i], dE, ws, DE, 0, 0, 4 * lh * DE + lj);
             if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], dE, ws, DE, 32, 0, 4 * lh * DE + lj);
             __syncthreads();
@@ -635,45 +690,34 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     }
 
     TS(5);
-    if (!flow) load_de();
-    // ---- B4: classifier ---------------------------------------------------------------------------------------
+    // ---- B4: classifier: dZc = (dlog wc2) (.) [HC > 0];  dE' += Wc1^T dZc ----------------------------------------
     {
         f32x16 dzc;
-        const float dl = A.dlog[A.perm[edge]];
-        const float* hp = A.HC + (int64_t)edge * hc;
-        float* o2 = A.dZc + (int64_t)edge * hc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = 8 * g + 4 * lh;
-            const float4 w = ldrow<EXACT>(A.wc2, n, hc);
-            const float4 m = ldrow<EXACT>(hp, n, hc);
-            float4 v;
-            v.x = m.x > 0.f ? dl * w.x : 0.f; v.y = m.y > 0.f ? dl * w.y : 0.f;
-            v.z = m.z > 0.f ? dl * w.z : 0.f; v.w = m.w > 0.f ? dl * w.w : 0.f;
-            set4(dzc, g, v);
-            strow<EXACT>(o2, n, hc, v, edge_ok);
+            const float4 w = *reinterpret_cast<const float4*>(swc2 + 8 * g + 4 * lh);
+            set4(dzc, g, make_float4(dl * w.x, dl * w.y, dl * w.z, dl * w.w));
         }
-        chunk_fetch<chunk_q(N4_5)>(A.w2, N4_5, tid, wbuf[(c + 1) & 1]);
-        chain_tile<T2>(dzc, dE, wbuf[c & 1], DE, 0, 0, 4 * lh * DE + lj);
+        apply_mask(dzc, mk[W_HC], 0);
+        {
+            float* o2 = A.dZc + (int64_t)edge * hc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 8 * g + 4 * lh, hc, get4(dzc, g), edge_ok);
+        }
+        chunk_fetch<chunk_q(N4_5)>(A.w2, N4_5, tid, wbuf_at(c + 1));
+        chain_tile<T2>(dzc, dE, wbuf_at(c), DE, 0, 0, 4 * lh * DE + lj);
         __syncthreads();
         ++c;
     }
     // dZ2 = dE' (.) [e_s > 0]  (written over the incoming gradient)
     {
-        const float* ep = A.e_s + (int64_t)edge * de;
         float* o2 = A.dE_io + (int64_t)edge * de;
 #pragma unroll
-        for (int t = 0; t < T2; ++t)
+        for (int t = 0; t < T2; ++t) {
+            apply_mask(dE[t], mk[W_E + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * t + 8 * g + 4 * lh;
-                const float4 m = ldrow<EXACT>(ep, n, de);
-                float4 v = get4(dE[t], g);
-                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                set4(dE[t], g, v);
-                strow<EXACT>(o2, n, de, v, edge_ok);
-            }
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, de, get4(dE[t], g), edge_ok);
+        }
     }
 
     TS(6);
@@ -689,46 +733,52 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         const bool more = i + 1 < NCH5;
         const float* nsrc = more ? A.w2 + (i + 1) * NR5 * HE : A.w1e;
         const int nn4 = more ? N4_5 : rows6_0 * ncol6 / 4;
-        chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX))>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
+        chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX))>(nsrc, nn4, tid, wbuf_at(c + 1));
         // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
         constexpr int TA = (T1 + 1) / 2, TB = T1 - TA;
-        chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf[c & 1], HE, 4 * lh * HE + lj);
-        if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf[c & 1], HE, 4 * lh * HE + lj + 32 * TA);
+        chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf_at(c), HE, 4 * lh * HE + lj);
+        if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf_at(c), HE, 4 * lh * HE + lj + 32 * TA);
         __syncthreads();
         ++c;
     }
     TS(7);
     {
-        const float* hp = A.H1 + (int64_t)edge * he;
         float* o2 = A.dZ1 + (int64_t)edge * he;
 #pragma unroll
-        for (int t = 0; t < T1; t += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            float4 m[8];
+        for (int t = 0; t < T1; ++t) {
+            apply_mask(dz1[t], mk[W_H1 + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (t + (g >> 2) < T1) m[g] = ldrow<EXACT>(hp, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if (t + (g >> 2) < T1) {
-                    float4 v = get4(dz1[t + (g >> 2)], g & 3);
-                    v.x = m[g].x > 0.f ? v.x : 0.f; v.y = m[g].y > 0.f ? v.y : 0.f;
-                    v.z = m[g].z > 0.f ? v.z : 0.f; v.w = m[g].w > 0.f ? v.w : 0.f;
-                    set4(dz1[t + (g >> 2)], g & 3, v);
-                    strow<EXACT>(o2, 32 * (t + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, v, edge_ok);
-                }
-            }
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, he, get4(dz1[t], g), edge_ok);
         }
     }
 
     TS(8);
     // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, up to 64 (padded) output columns per pass ---------------------------------
     for (int pass = 0; pass < npass6; ++pass) {
+        // output tile tt (32 padded columns) of the pass belongs to half tt / T2 of [e0 | e_{s-1}], tile tt % T2 in it;
+        // the first half is the re-attached initial features (accumulated over all steps: C-in = the running sum, read
+        // here so that the MFMAs hide the load), the second e_{s-1} -- which IS e0 at the first step
         f32x16 dc[2];
+        float* dst[2];
+        bool live[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            const int tt = pass * 2 + t;
+            live[t] = tt * 32 < KEp;
+            const int half = tt / T2, tin = tt % T2;
+            const bool to_e0 = (A.cat_two && half == 0) || A.first_step;
+            dst[t] = (to_e0 ? A.dE0 : A.dEprev) + (int64_t)edge * de + 32 * tin;
+            // (T2 == 1, first step: both tiles of the pass add into the same dE0 columns -- the second starts from zero and
+            // is folded into the first after the MFMAs)
+            const bool second_of_same = t == 1 && T2 == 1 && A.cat_two && A.first_step;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dc[t][r] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const int n = 8 * g + 4 * lh;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live[t] && to_e0 && !second_of_same) v = ldrow<EXACT>(dst[t], n, de - 32 * tin);
+                set4(dc[t], g, v);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCH6; ++i) {
             // next: the following <= 64 rows of this pass's image [HE][ncol6], or the first rows of the next pass's
@@ -740,8 +790,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             const int rows_n = HE - in * NR6 < NR6 ? HE - in * NR6 : NR6;
             const float* nsrc = A.w1e + ((int64_t)pn * HE + in * NR6) * ncol6;
             const int nn4 = rows_n * ncol6 / 4;
-            chunk_fetch<chunk_q(N4_6MAX)>(nsrc, nn4, tid, wbuf[(c + 1) & 1]);
-            const float* ws = wbuf[c & 1];
+            chunk_fetch<chunk_q(N4_6MAX)>(nsrc, nn4, tid, wbuf_at(c + 1));
+            const float* ws = wbuf_at(c);
             if (ncol6 == 64) {
                 chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
                 if (2 * i + 1 < T1) chain_tile<2>(dz1[2 * i + 1], dc, ws, 64, 32, 0, 4 * lh * 64 + lj);
@@ -752,29 +802,21 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             __syncthreads();
             ++c;
         }
-        // output tile tt (32 padded columns) of the pass belongs to half tt / T2 of [e0 | e_{s-1}], tile tt % T2 in it;
-        // the first half is the re-attached initial features (accumulated over all steps), the second e_{s-1} --
-        // which IS e0 at the first step
+        if (T2 == 1 && A.cat_two && A.first_step && live[1]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dc[0][r] += dc[1][r];
+            live[1] = false;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int tt = pass * 2 + t;
-            if (tt * 32 >= KEp) break;
-            const int half = tt / T2, tin = tt % T2;
-            const bool to_e0 = (A.cat_two && half == 0) || A.first_step;
-            float* dst = (to_e0 ? A.dE0 : A.dEprev) + (int64_t)edge * de;
+            if (!live[t]) break;
+            const int tin = (pass * 2 + t) % T2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * tin + 8 * g + 4 * lh;
-                float4 v = get4(dc[t], g);
-                if (to_e0) {
-                    const float4 o = ldrow<EXACT>(dst, n, de);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                strow<EXACT>(dst, n, de, v, edge_ok);
-            }
+            for (int g = 0; g < 4; ++g) strow<EXACT>(dst[t], 8 * g + 4 * lh, de - 32 * tin, get4(dc[t], g), edge_ok);
         }
     }
     TS(9);
+#undef wbuf_at
 }
 
 // dst[r][c] = (r < rows && c < cols) ? src[r * lds + c0 + c] : 0   for r < rows_pad, c < cols_pad (ld = cols_pad)

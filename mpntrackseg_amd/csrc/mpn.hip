@@ -249,6 +249,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         a.save_h1 = save_acts ? b.HE[0] : nullptr;
         a.save_hc = save_acts ? b.HC[0] : nullptr;
         a.save_hf = save_acts ? b.HF[0] : nullptr;
+        a.save_mask = save_acts ? reinterpret_cast<unsigned*>(b.MK) : nullptr;
         prof_begin(PROF_GEMM, s);
         MPN_TRY(launch_edge_chain(a, s));
         prof_end(PROF_GEMM, s);

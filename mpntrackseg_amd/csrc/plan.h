@@ -103,6 +103,7 @@ struct StepBufs {
     float* M;                          // [E, dn]   messages (post-ReLU), sorted order
     float* AGG;                        // [N, 2dn]  [flow_in | flow_out]
     int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
+    int* MK;                           // ReLU masks of the fused chain kernels as bits (edge_chain.h: chain_mask_ints)
 };
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
@@ -143,6 +144,7 @@ static inline void carve_step(Arena& a, const mpnhip_model& m, const Dims& d, in
     s.M = a.f((size_t)E * d.dn);
     s.AGG = a.f((size_t)N * 2 * d.dn);
     s.ARG = with_arg ? a.i((size_t)N * 2 * d.dn) : nullptr;
+    s.MK = a.i(chain_mask_ints(E, d.he, d.de, d.hn, d.dn));
     if (sb) *sb = s;
 }
 
@@ -155,6 +157,7 @@ static inline StepBufs step_at(const FwdPlan& p, int s) {
     mv(b.M);
     mv(b.AGG);
     if (b.ARG) b.ARG = reinterpret_cast<int*>(reinterpret_cast<char*>(b.ARG) + sh);
+    if (b.MK) b.MK = reinterpret_cast<int*>(reinterpret_cast<char*>(b.MK) + sh);
     return b;
 }
 
