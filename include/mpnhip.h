@@ -184,6 +184,63 @@ int mpnhip_attention_aggregate_backward(const void* graph_buf, int n_nodes, int6
 int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Graph construction on the device: what MOTGraph.construct_graph_object
+ * (data/mot_graph.py:283-317) computes before the model runs.  All indices int64 like the reference's tensors.
+ * ------------------------------------------------------------------------------------------- */
+/* get_time_valid_conn_ixs(frame_num, max_frame_dist, return_undirected=True) (utils/graph.py:6-37): the pairs
+ * (i, j), i < j, whose frames differ and are at most max_frame_dist apart (max_frame_dist < 0 = the reference's
+ * 'max'), in the reference's order (ascending i, then j).  Two calls, because the caller allocates the result:
+ *   count: offsets [N + 1] (device) <- exclusive scan of the per-node pair counts; offsets[N] = number of pairs
+ *   fill : edge_ixs [2, n_pairs] row-major, n_pairs = offsets[N] read back by the caller. */
+size_t mpnhip_time_valid_conn_workspace_bytes(int n_nodes);
+int mpnhip_time_valid_conn_count(const int64_t* frame_num, int n_nodes, int64_t max_frame_dist, int64_t* offsets,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int mpnhip_time_valid_conn_fill(const int64_t* frame_num, int n_nodes, int64_t max_frame_dist, const int64_t* offsets,
+                                int64_t n_pairs, int64_t* edge_ixs, void* stream);
+/* compute_edge_feats_dict (utils/graph.py:90-124): edge_feats [E, 5] = secs_time_dists, norm_feet_x_dists,
+ * norm_feet_y_dists, bb_height_dists, bb_width_dists (the dict's order) for edge_ixs [2, E]; per-node columns of
+ * the detection frame: frame_num int64 [N], bb_height / bb_width / feet_x / feet_y float32 [N]. */
+int mpnhip_edge_features(const int64_t* edge_ixs, int64_t n_edges, int n_nodes, const int64_t* frame_num, float fps,
+                         const float* bb_height, const float* bb_width, const float* feet_x, const float* feet_y,
+                         float* edge_feats, void* stream);
+/* F.pairwise_distance(emb[edge_ixs[0]], emb[edge_ixs[1]]) (data/mot_graph.py:298-301; p = 2, eps as given, the
+ * reference uses torch's default 1e-6): dist [E]; emb [N, dim] with row stride ld. */
+int mpnhip_pairwise_distance(const float* emb, int64_t ld, int dim, const int64_t* edge_ixs, int64_t n_edges, float eps,
+                             float* dist, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-window inference: MPNTracker._predict_edges_and_masks /
+ * _evaluate_graph_in_batches (tracker/mpn_tracker.py:96-210) around mpnhip_forward.
+ * ------------------------------------------------------------------------------------------- */
+/* get_knn_mask (utils/graph.py:40-87): pruned_mask [E] (1 = keep) for edge_ixs [2, E] with distances pwise_dist [E].
+ * symmetric_edges != 0: edge_ixs lists both directions of every pair (inference); 0: one direction (training).
+ * Ties in distance rank by column index (stable argsort); the reference leaves them to torch.argsort. */
+size_t mpnhip_knn_mask_workspace_bytes(int64_t n_edges, int symmetric_edges);
+int mpnhip_knn_mask(const float* pwise_dist, const int64_t* edge_ixs, int n_nodes, int64_t n_edges, int top_k_nns,
+                    int reciprocal_k_nns, int symmetric_edges, unsigned char* pruned_mask, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* edges_mask of a window (mpn_tracker.py:171-173): flags [E] = both end points in [node_begin, node_end). */
+int mpnhip_window_flags(const int64_t* edge_index, int64_t n_edges, int64_t node_begin, int64_t node_end,
+                        unsigned char* flags, void* stream);
+/* torch.where(flags)[0] as int32 ids (ascending) + their number (device int32), e.g. tensor[mask] selections. */
+size_t mpnhip_compact_workspace_bytes(int64_t n);
+int mpnhip_compact(const unsigned char* flags, int64_t n, int32_t* ids, int32_t* count, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* out [n, dim] = src[ids] (rows of stride ld);  out [2, n] = edge_index[:, ids] - node_begin. */
+int mpnhip_gather_rows(const float* src, int64_t ld, const int32_t* ids, int64_t n, int dim, float* out, void* stream);
+int mpnhip_gather_edges(const int64_t* edge_index, int64_t n_edges, const int32_t* ids, int64_t n, int64_t node_begin,
+                        int64_t* out, void* stream);
+/* mpn_tracker.py:126-141,188-190: overall_edge_preds[full id] += sigmoid(logit) for the window's kept edges and
+ * overall_num_preds += 1 for the kept edges (or, with set_pruned_edges_to_inactive, for every edge of the window).
+ * logits [n_kept]; kept_ids [n_kept] index the window's edge list (NULL = identity); window_ids [n_window] index
+ * the full sequence graph's edges. */
+int mpnhip_window_accumulate(const float* logits, const int32_t* kept_ids, int64_t n_kept, const int32_t* window_ids,
+                             int64_t n_window, int set_pruned_edges_to_inactive, float* overall_edge_preds,
+                             float* overall_num_preds, void* stream);
+/* final_edge_preds = overall_edge_preds / overall_num_preds, NaN -> 0 (mpn_tracker.py:195-197). */
+int mpnhip_average_preds(const float* overall_preds, const float* overall_num, int64_t n, float* final_preds, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement helpers used by bench.py (HIP events on the launch stream; these synchronise).
  * ------------------------------------------------------------------------------------------- */
 /* In-stream kernel timing of the real hot path: while enabled, mpnhip_forward brackets (a) the first-layer

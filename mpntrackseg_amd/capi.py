@@ -69,6 +69,20 @@ SIGNATURES = {
     "mpnhip_attention_aggregate": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
     "mpnhip_attention_aggregate_backward": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
+    "mpnhip_time_valid_conn_workspace_bytes": (_Z, [_I]),
+    "mpnhip_time_valid_conn_count": (_I, [_P, _I, _L, _P, _P, _Z, _P]),
+    "mpnhip_time_valid_conn_fill": (_I, [_P, _I, _L, _P, _L, _P, _P]),
+    "mpnhip_edge_features": (_I, [_P, _L, _I, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "mpnhip_pairwise_distance": (_I, [_P, _L, _I, _P, _L, C.c_float, _P, _P]),
+    "mpnhip_knn_mask_workspace_bytes": (_Z, [_L, _I]),
+    "mpnhip_knn_mask": (_I, [_P, _P, _I, _L, _I, _I, _I, _P, _P, _Z, _P]),
+    "mpnhip_window_flags": (_I, [_P, _L, _L, _L, _P, _P]),
+    "mpnhip_compact_workspace_bytes": (_Z, [_L]),
+    "mpnhip_compact": (_I, [_P, _L, _P, _P, _P, _Z, _P]),
+    "mpnhip_gather_rows": (_I, [_P, _L, _P, _L, _I, _P, _P]),
+    "mpnhip_gather_edges": (_I, [_P, _L, _P, _L, _L, _P, _P]),
+    "mpnhip_window_accumulate": (_I, [_P, _P, _L, _P, _L, _I, _P, _P, _P]),
+    "mpnhip_average_preds": (_I, [_P, _P, _L, _P, _P]),
     "mpnhip_profile_enable": (_I, [_I]),
     "mpnhip_edge_chain_active": (_I, [C.POINTER(Model)]),
     "mpnhip_profile_read": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),

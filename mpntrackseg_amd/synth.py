@@ -245,6 +245,21 @@ def make_knn_graph(frames=20, dets=25, top_k=150, seed=1, node_in_dim=2048, edge
             "edge_attr": np.concatenate([ea, ea], axis=0), "frame": frame}
 
 
+def make_detections(frames=12, dets_lo=4, dets_hi=9, seed=3, emb_dim=64, node_in_dim=64, frame_stride=1):
+    """Synthetic detection table of one sequence, ordered by frame (data/mot_graph.py:145), with the columns the
+    reference's graph utilities read (utils/graph.py:104-113) plus ReID embeddings and pooled node inputs."""
+    u = uniform01(seed, frames, stream=1)
+    counts = (dets_lo + np.floor(u * (dets_hi - dets_lo + 1))).astype(np.int64)
+    frame = np.repeat(1 + frame_stride * np.arange(frames, dtype=np.int64), counts)
+    n = int(frame.shape[0])
+    bb_h = (80.0 + 120.0 * uniform01(seed, n, stream=2)).astype(np.float32)
+    bb_w = (30.0 + 60.0 * uniform01(seed, n, stream=3)).astype(np.float32)
+    feet_x = (1900.0 * uniform01(seed, n, stream=4)).astype(np.float32)
+    feet_y = (200.0 + 800.0 * uniform01(seed, n, stream=5)).astype(np.float32)
+    return dict(frame=frame, bb_height=bb_h, bb_width=bb_w, feet_x=feet_x, feet_y=feet_y,
+                reid=normal(seed, (n, emb_dim), stream=6), x=normal(seed, (n, node_in_dim), stream=7))
+
+
 def batch_graphs(graphs):
     """torch_geometric-style collation: node offsets added to edge_index, tensors concatenated.
     The (i<j) / (j<i) halves of the sub-graphs end up interleaved, so direction masks must be

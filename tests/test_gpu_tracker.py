@@ -1,0 +1,135 @@
+"""Graph construction and sliding-window inference (8f-3) through the C ABI.
+
+(a) `mpntrackseg_amd.graph` against the reference's own utils/graph.py outputs (tests/golden/g7_graph_utils.npz):
+    integer / boolean results bit-exact, fp32 features within 1e-6 relative (logf vs torch.log: 1 ulp; the embedding
+    norm is re-associated across a wavefront);
+(b) `mpntrackseg_amd.tracker.evaluate_graph_in_batches` against the oracle's restatement of
+    mpn_tracker.py:143-198 driven by the CPU oracle forward, same weights: |dp| <= 2e-5 on the averaged probabilities;
+(c) properties: windows batched block-diagonally == one by one; windows sharded over 2 "ranks" and summed == 1 rank."""
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import graph as G, synth, tracker
+from mpntrackseg_amd.mpn import MOTMPNet
+from oracle import mpn_oracle as O, tracker_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_graph_utils_match_reference(golden):
+    z = golden("g7_graph_utils.npz")
+    det = {k[4:]: z[k] for k in z.files if k.startswith("det:")}
+    emb = torch.from_numpy(det["reid"]).to(dev())
+    n = len(det["frame"])
+    for tag, mfd in (("max", "max"), ("d3", 3)):
+        ei = G.get_time_valid_conn_ixs(torch.from_numpy(det["frame"]).to(dev()), mfd)
+        assert ei.dtype == torch.int64 and np.array_equal(ei.cpu().numpy(), z[f"{tag}:edge_ixs"])
+        feats = G.compute_edge_feats_dict(ei, det, float(z["fps"]))
+        got = torch.stack([feats[k] for k in G.EDGE_FEAT_NAMES]).T.cpu().numpy()
+        assert np.allclose(got, z[f"{tag}:feats"], rtol=2e-6, atol=1e-6)
+        d = G.pairwise_distance(emb, ei)
+        assert np.allclose(d.cpu().numpy(), z[f"{tag}:emb_dist"], rtol=1e-5)
+        dref = torch.from_numpy(z[f"{tag}:emb_dist"]).to(dev())  # identical distances -> identical ranks
+        ei2 = torch.cat((ei, torch.stack((ei[1], ei[0]))), dim=1)
+        for k in (3, 8):
+            for rec in (0, 1):
+                m = G.get_knn_mask(dref, ei, n, k, reciprocal_k_nns=bool(rec), symmetric_edges=False)
+                assert np.array_equal(m.cpu().numpy(), z[f"{tag}:knn_k{k}_r{rec}_pairs"]), (tag, k, rec)
+                m2 = G.get_knn_mask(torch.cat((dref, dref)), ei2, n, k, reciprocal_k_nns=bool(rec), symmetric_edges=True)
+                assert np.array_equal(m2.cpu().numpy(), z[f"{tag}:knn_k{k}_r{rec}_sym"]), (tag, k, rec)
+
+
+def test_graph_utils_edge_cases():
+    d0 = dev()
+    # no nodes / one frame only: no pairs
+    assert G.get_time_valid_conn_ixs(torch.zeros(0, dtype=torch.int64, device=d0), 'max').shape == (2, 0)
+    assert G.get_time_valid_conn_ixs(torch.ones(5, dtype=torch.int64, device=d0), 'max').shape == (2, 0)
+    # unsorted frames are handled like the reference's dense formulation
+    f = torch.tensor([3, 1, 2, 1, 7], dtype=torch.int64)
+    assert np.array_equal(G.get_time_valid_conn_ixs(f.to(d0), 2).cpu().numpy(), T.get_time_valid_conn_ixs(f, 2).numpy())
+    # ties in distance: ranked by column index, like a stable argsort
+    ei = torch.tensor([[0, 0, 0, 1, 2, 3], [1, 2, 3, 0, 0, 0]], dtype=torch.int64)
+    dist = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0, 1.0])
+    for rec in (False, True):
+        want = T.get_knn_mask(dist, ei, 4, 2, rec, True)
+        got = G.get_knn_mask(dist.to(d0), ei.to(d0), 4, 2, reciprocal_k_nns=rec, symmetric_edges=True)
+        assert np.array_equal(got.cpu().numpy(), want.numpy())
+    assert G.get_knn_mask(torch.zeros(0, device=d0), torch.zeros((2, 0), dtype=torch.int64, device=d0), 3, 2).numel() == 0
+
+
+def test_construct_graph_matches_oracle():
+    det = synth.make_detections(frames=10, seed=11)
+    emb = torch.from_numpy(det["reid"])
+    names = list(G.EDGE_FEAT_NAMES) + ["emb_dist"]
+    for inference, mfd in ((True, 'max'), (False, 4)):
+        want = T.construct_graph(det, emb, 30.0, mfd, names, top_k_nns=6, reciprocal_k_nns=True, inference_mode=inference)
+        got = G.construct_graph(det, emb.to(dev()), 30.0, mfd, names, top_k_nns=6, reciprocal_k_nns=True,
+                                inference_mode=inference)
+        assert np.array_equal(got["edge_index"].cpu().numpy(), want["edge_index"].numpy())
+        assert np.allclose(got["edge_attr"].cpu().numpy(), want["edge_attr"].numpy(), rtol=1e-5, atol=1e-6)
+        assert np.allclose(got["reid_emb_dists"].cpu().numpy(), want["reid_emb_dists"].numpy(), rtol=1e-5)
+
+
+def _sequence(frames=14, seed=5):
+    det = synth.make_detections(frames=frames, seed=seed, node_in_dim=64)
+    names = list(G.EDGE_FEAT_NAMES) + ["emb_dist"]
+    g = T.construct_graph(det, torch.from_numpy(det["reid"]), 25.0, 'max', names)
+    params = synth.model_params(32, 4, "sum", num_class_steps=2, node_in_dim=64, edge_in_dim=6)
+    W = synth.make_weights(params, seed=7, gain=0.5)
+    return det, g, params, W
+
+
+def _native_model(params, W):
+    model = MOTMPNet(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    return model.to(dev()).eval()
+
+
+@pytest.mark.parametrize("set_inactive", [False, True])
+def test_sliding_window_matches_oracle(set_inactive):
+    det, g, params, W = _sequence()
+    Wt = O.to_tensors(W)
+
+    def fwd(xs, ei, ea):
+        _, logits, _, _ = O.forward(params, Wt, xs, ei, ea, return_state=True)
+        return logits[-1]
+
+    x = torch.from_numpy(det["x"])
+    want = T.evaluate_graph_in_batches(fwd, x, g["edge_index"], g["edge_attr"], g["reid_emb_dists"].view(-1), det["frame"],
+                                       frames_per_graph=5, top_k_nns=6, reciprocal_k_nns=True,
+                                       set_pruned_edges_to_inactive=set_inactive)
+    model = _native_model(params, W)
+    args = (model, x.to(dev()), g["edge_index"].to(dev()), g["edge_attr"].to(dev()), g["reid_emb_dists"].to(dev()), det["frame"])
+    got = tracker.evaluate_graph_in_batches(*args, frames_per_graph=5, top_k_nns=6, reciprocal_k_nns=True,
+                                            set_pruned_edges_to_inactive=set_inactive)
+    assert got.shape == want.shape
+    assert float((got.cpu() - want).abs().max()) <= 2e-5
+    assert float(want.max()) > 0.05  # the comparison is not vacuous
+    # (c) batching windows block-diagonally changes nothing
+    got4 = tracker.evaluate_graph_in_batches(*args, frames_per_graph=5, top_k_nns=6, reciprocal_k_nns=True,
+                                             set_pruned_edges_to_inactive=set_inactive, windows_per_launch=4)
+    assert float((got4 - got).abs().max()) <= 1e-6
+
+
+def test_sliding_window_sharded_over_ranks():
+    det, g, params, W = _sequence(frames=12, seed=9)
+    model = _native_model(params, W)
+    args = (model, torch.from_numpy(det["x"]).to(dev()), g["edge_index"].to(dev()), g["edge_attr"].to(dev()),
+            g["reid_emb_dists"].to(dev()), det["frame"])
+    one = tracker.evaluate_graph_in_batches(*args, frames_per_graph=4, top_k_nns=5)
+    # two "ranks": capture each rank's accumulators through reduce_fn and add them, as all_reduce(sum) would
+    acc = []
+
+    def grab(t):
+        acc.append(t.clone())
+
+    for r in range(2):
+        tracker.evaluate_graph_in_batches(*args, frames_per_graph=4, top_k_nns=5, rank=r, world_size=2, reduce_fn=grab)
+    preds, num = acc[0] + acc[2], acc[1] + acc[3]
+    both = torch.where(num > 0, preds / num, torch.zeros_like(preds))
+    assert float((both - one).abs().max()) <= 1e-6

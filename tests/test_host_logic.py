@@ -106,3 +106,20 @@ def test_synth_is_deterministic_and_structured():
     assert len({(a, b) for a, b in ei[:, :300].T.tolist()}) == 300
     v = synth.normal(5, (200000,))
     assert abs(float(v.mean())) < 0.01 and abs(float(v.std()) - 1.0) < 0.01
+
+
+def test_frame_windows_match_reference_loop():
+    """tracker.frame_windows: node ranges of the sliding windows of mpn_tracker.py:166-170 (no GPU needed)."""
+    from mpntrackseg_amd import tracker
+    frames = np.array([1, 1, 1, 3, 3, 4, 6, 6, 6, 6, 9, 10, 10])
+    wins = tracker.frame_windows(frames, 3)
+    all_frames = np.unique(frames)
+    want = []
+    for s, e in zip(all_frames, all_frames[2:]):
+        m = np.nonzero((s <= frames) & (frames <= e))[0]
+        want.append((int(m[0]), int(m[-1]) + 1))
+    assert wins == want and len(wins) == len(all_frames) - 2
+    # round-robin sharding of the windows covers each exactly once
+    assert sorted(wins[0::2] + wins[1::2]) == sorted(wins)
+    with pytest.raises(Exception):
+        tracker.frame_windows(np.array([2, 1, 3]), 2)

@@ -146,3 +146,27 @@ def test_g3_cfgB_mean(golden):
     lg = torch.stack(logits).numpy().reshape(c["L"], -1)
     assert rel_err(lg[:, z["edge_ids"]], z["logits"]) < 5e-6
     assert np.allclose(np.abs(lg).max(1), z["step_max"], rtol=1e-5)
+
+
+def test_g7_graph_utils_oracle_matches_reference(golden):
+    """oracle/tracker_oracle.py against the reference's utils/graph.py outputs (tests/golden/g7_graph_utils.npz)."""
+    import torch
+    from oracle import tracker_oracle as T
+    z = golden("g7_graph_utils.npz")
+    det = {k[4:]: z[k] for k in z.files if k.startswith("det:")}
+    emb = torch.from_numpy(det["reid"])
+    for tag, mfd in (("max", "max"), ("d3", 3)):
+        ei = T.get_time_valid_conn_ixs(det["frame"], mfd)
+        assert np.array_equal(ei.numpy(), z[f"{tag}:edge_ixs"])
+        feats = T.compute_edge_feats_dict(ei, det, float(z["fps"]))
+        got = torch.stack([feats[k] for k in T.EDGE_FEAT_NAMES]).T.numpy()
+        assert np.allclose(got, z[f"{tag}:feats"], rtol=1e-6, atol=1e-7)
+        d = T.pairwise_distance(emb, ei).view(-1)
+        assert np.allclose(d.numpy(), z[f"{tag}:emb_dist"], rtol=1e-6)
+        ei2 = torch.cat((ei, torch.stack((ei[1], ei[0]))), dim=1)
+        for k in (3, 8):
+            for rec in (0, 1):
+                m = T.get_knn_mask(d, ei, len(det["frame"]), k, bool(rec), symmetric_edges=False)
+                assert np.array_equal(m.numpy(), z[f"{tag}:knn_k{k}_r{rec}_pairs"])
+                m2 = T.get_knn_mask(torch.cat((d, d)), ei2, len(det["frame"]), k, bool(rec), symmetric_edges=True)
+                assert np.array_equal(m2.numpy(), z[f"{tag}:knn_k{k}_r{rec}_sym"])

@@ -19,6 +19,9 @@ Fixtures:
   g3_cfgB_{agg}.npz            cfg-B (5000/50000/d128/L12): logits at 4096 fixed edges x 12 steps +
                                per-step sum / abs-sum / max checksums.
   g0_l0.npz                    num_enc_steps == 0 special case (mpn.py:387-389).
+  g7_graph_utils.npz           the reference's utils/graph.py on a synthetic detection table (synth.make_detections):
+                               get_time_valid_conn_ixs ('max' and 3 frames), compute_edge_feats_dict, F.pairwise_distance,
+                               get_knn_mask (reciprocal on/off; one direction per pair and both directions).
   g6_mask_branch.npz           full forward WITH the attention / mask branch (deterministic weights for all 54
                                tensors): mask predictions + reference-autograd gradients through both branches.
 
@@ -342,9 +345,39 @@ def gen_cfg(mpn, name, tag, sample=None):
         print(tag, agg, "max|logit| per step", rec["step_max"][[0, -1]])
 
 
+def gen_g7():
+    """utils/graph.py of the reference (graph construction / kNN pruning helpers)."""
+    import pandas as pd
+    import torch.nn.functional as F
+    from mot_neural_solver.utils import graph as G
+    det = synth.make_detections()
+    df = pd.DataFrame({k: det[k] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y")})
+    emb = torch.from_numpy(det["reid"])
+    fps = 25.0
+    out = dict(fps=np.float32(fps), **{"det:" + k: det[k] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y", "reid")})
+    for tag, mfd in (("max", "max"), ("d3", 3)):
+        ei = G.get_time_valid_conn_ixs(torch.from_numpy(det["frame"]), mfd, use_cuda=False)
+        out[f"{tag}:edge_ixs"] = ei.numpy()
+        feats = G.compute_edge_feats_dict(ei, df, fps, use_cuda=False)
+        out[f"{tag}:feats"] = torch.stack([feats[k] for k in ("secs_time_dists", "norm_feet_x_dists", "norm_feet_y_dists",
+                                                              "bb_height_dists", "bb_width_dists")]).T.numpy()
+        d = F.pairwise_distance(emb[ei[0]], emb[ei[1]])
+        out[f"{tag}:emb_dist"] = d.numpy()
+        for k in (3, 8):
+            for rec in (0, 1):
+                m = G.get_knn_mask(d, ei, len(df), k, use_cuda=False, reciprocal_k_nns=bool(rec), symmetric_edges=False)
+                out[f"{tag}:knn_k{k}_r{rec}_pairs"] = m.numpy()
+                ei2 = torch.cat((ei, torch.stack((ei[1], ei[0]))), dim=1)
+                m2 = G.get_knn_mask(torch.cat((d, d)), ei2, len(df), k, use_cuda=False, reciprocal_k_nns=bool(rec),
+                                    symmetric_edges=True)
+                out[f"{tag}:knn_k{k}_r{rec}_sym"] = m2.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g7_graph_utils.npz"), **out)
+    print("g7_graph_utils.npz", {k: v.shape for k, v in out.items() if k.startswith("max:")})
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g2,g3")
+    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g2,g3")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     os.makedirs(GOLD, exist_ok=True)
@@ -355,6 +388,7 @@ def main():
     if "g4" in only: gen_g4(mpn)
     if "g5" in only: gen_g5(mpn)
     if "g6" in only: gen_g6(mpn)
+    if "g7" in only: gen_g7()
     if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
     if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
 
