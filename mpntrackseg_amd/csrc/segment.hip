@@ -29,7 +29,8 @@ struct SegArgs {
     int accumulate;
     int nmod;         // segment s -> out row s % nmod, column offset (s / nmod == 0 ? off0 : off1)
     int off0, off1;
-    int sub;          // lanes per segment (power of two <= 64)
+    int sub;          // lanes per work item (power of two <= 64)
+    int nblk;         // column blocks per segment: work item = (segment, block of sub * VEC columns); 0 / 1 = one item per segment
 };
 
 template <int VEC>
@@ -68,13 +69,15 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
     typedef typename Vec<VEC>::T V;
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = gtid / a.sub;
-    const int l = gtid % a.sub;
+    const int nblk = a.nblk > 1 ? a.nblk : 1;
+    const int item = gtid / a.sub;
+    const int s = item / nblk;
+    const int l = gtid % a.sub + (item % nblk) * a.sub;
     if (s >= a.nseg) return;
     const int beg = a.ptr[s], end = a.ptr[s + 1];
     const int64_t orow = (int64_t)(s % a.nmod) * a.ldo + ((s / a.nmod) == 0 ? a.off0 : a.off1);
     const bool is_max = a.agg == MPNHIP_AGG_MAX;
-    for (int c = l * VEC; c < a.dim; c += a.sub * VEC) {
+    for (int c = l * VEC; c < a.dim; c += a.sub * nblk * VEC) {
         V acc;
         vset(acc, is_max ? -INFINITY : 0.f);
         int arg_s[4] = {-1, -1, -1, -1};
@@ -261,8 +264,17 @@ static int launch_seg(SegArgs a, hipStream_t stream) {
     int per = vec ? a.dim / 4 : a.dim;
     int sub = 1;
     while (sub < per && sub < 64) sub <<= 1;
+    a.nblk = 1;
+    if (per > sub || (per & (per - 1))) {
+        // the row is not one power-of-two group of lanes (e.g. 80 or 56 x 16 bytes): column blocks of the largest
+        // power of two that divides it, one work item per (segment, block), so that no lane idles and no lane walks
+        // the segment twice; rows are still read in pieces of >= 128 contiguous bytes
+        int p2 = per & -per;
+        if (p2 > 64) p2 = 64;
+        if (p2 * (vec ? 16 : 4) >= 128) { sub = p2; a.nblk = per / p2; }
+    }
     a.sub = sub;
-    int64_t threads = (int64_t)a.nseg * sub;
+    int64_t threads = (int64_t)a.nseg * sub * a.nblk;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     if (vec) hipLaunchKernelGGL(k_segment_reduce<4>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(k_segment_reduce<1>, dim3(blocks), dim3(256), 0, stream, a);
