@@ -200,9 +200,65 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = tot;
 }
 
-// grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]
-// over the non-empty chunks, in chunk order; 8 lanes share one output element.
+// grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]  over the non-empty chunks.
+// Block = 32 x 16-byte columns of the padded slab image x 8 slab groups: a wave reads 512 contiguous bytes of one
+// slab, four slabs in flight per lane; the eight groups' partial sums meet in LDS in a fixed order (deterministic).
+// Needs k_in % 4 == 0 (then the slab pitch k_in + 4 is a multiple of 4 floats); otherwise the scalar kernel below.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
+    __shared__ float4 part[8][32];
+    const int kpad = args.k_in + 4;
+    const int64_t total4 = (int64_t)args.n_out * kpad / 4;
+    const int64_t q = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const int grp = threadIdx.x >> 5;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    int nvalid = (re - rb + args.chunk - 1) / args.chunk;
+    nvalid = nvalid < 0 ? 0 : (nvalid > args.nsplit ? args.nsplit : nvalid);
+    const int nslab = nvalid * args.nbatch;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < total4) {
+        const float* p = TN_G(slab) + q * 4;
+        const size_t stride = (size_t)args.n_out * kpad;
+        for (int j0 = grp; j0 < nslab; j0 += 32) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int j = j0 + 8 * u;
+                j = j < nslab ? j : nslab - 1;  // clamped, unconditional loads
+                const int b = j / nvalid, i = j - b * nvalid;
+                v[u] = *reinterpret_cast<const float4*>(p + ((size_t)b * args.nsplit + i) * stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 8 * u < nslab) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    part[grp][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (grp == 0 && q < total4) {
+        float4 s = part[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+            const float4 o = part[g][threadIdx.x];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+        float* gw = TN_G(grad_w);
+        float* gb = TN_G(grad_b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t t = q * 4 + e;
+            const int o = (int)(t / kpad), c = (int)(t - (int64_t)o * kpad);
+            if (c < args.k_in) { if (gw) gw[(int64_t)o * TN_G(ldw) + c] += sv[e]; }
+            else if (c == args.k_in) { if (gb) gb[o] += sv[e]; }
+        }
+    }
+}
+
+// scalar variant (k_in % 4 != 0): 8 lanes share one output element
+__global__ __launch_bounds__(256) void slab_reduce_scalar_kernel(TnArgs args) {
     const int kpad = args.k_in + 4;
     const int64_t total = (int64_t)args.n_out * (args.k_in + 1);
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
@@ -294,8 +350,15 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
                            dim3(256), 0, s, a);
     }
     MPN_LAUNCH_CHECK();
-    int64_t total = (int64_t)a.n_out * (a.k_in + 1) * 8;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, a.ngroups), dim3(256), 0, s, a);
+    bool slab16 = a.k_in % 4 == 0;
+    for (int i = 0; i < a.ngroups; ++i) slab16 = slab16 && al16t(a.g[i].slab);
+    if (slab16) {
+        const int64_t total4 = (int64_t)a.n_out * (a.k_in + 4) / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 31) / 32), 1, a.ngroups), dim3(256), 0, s, a);
+    } else {
+        const int64_t total = (int64_t)a.n_out * (a.k_in + 1) * 8;
+        hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3((unsigned)((total + 255) / 256), 1, a.ngroups), dim3(256), 0, s, a);
+    }
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
