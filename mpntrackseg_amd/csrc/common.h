@@ -111,6 +111,7 @@ struct TnArgs {
     int64_t m_upper;       // upper bound of the rows of ONE batch
     int nbatch;            // >= 1
     int chunk, nsplit;     // filled by tn_plan: rows per chunk, chunks per batch
+    int red_ny, red_stage; // slab reduction in two stages (launch_gemm_tn): ny partial sums first, then their sum
 };
 void tn_plan(TnArgs& a);
 size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);

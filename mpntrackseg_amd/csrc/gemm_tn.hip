@@ -216,23 +216,30 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
     const int re = rep ? *rep : (int)TN_G(m_static);
     int nvalid = (re - rb + args.chunk - 1) / args.chunk;
     nvalid = nvalid < 0 ? 0 : (nvalid > args.nsplit ? args.nsplit : nvalid);
-    const int nslab = nvalid * args.nbatch;
+    const int nslab_all = nvalid * args.nbatch;
+    // two-stage form for outputs too small to fill the chip with one block per 32 columns: stage 1 (grid.y = ny) sums
+    // the slabs j = y (mod ny) into slab y IN PLACE (the thread that writes an element is the one that read it), stage
+    // 2 sums those ny partial slabs into the gradient.  Single stage: ny = 1, stage = 2.
+    const int ny = args.red_ny > 1 ? args.red_ny : 1;
+    const int first = args.red_stage == 1 ? (int)blockIdx.y : 0;
+    const int step = args.red_stage == 1 ? ny : 1;
+    const int nslab = args.red_stage == 1 ? nslab_all : (nslab_all < ny ? nslab_all : (ny > 1 ? ny : nslab_all));
+    auto slab_at = [&](int j) { const int b = j / nvalid, i = j - b * nvalid; return (size_t)b * args.nsplit + i; };
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)args.n_out * kpad;
     if (q < total4) {
         const float* p = TN_G(slab) + q * 4;
-        const size_t stride = (size_t)args.n_out * kpad;
-        for (int j0 = grp; j0 < nslab; j0 += 32) {
+        for (int j0 = first + step * grp; j0 < nslab; j0 += 32 * step) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int j = j0 + 8 * u;
-                j = j < nslab ? j : nslab - 1;  // clamped, unconditional loads
-                const int b = j / nvalid, i = j - b * nvalid;
-                v[u] = *reinterpret_cast<const float4*>(p + ((size_t)b * args.nsplit + i) * stride);
+                int j = j0 + 8 * step * u;
+                j = j < nslab ? j : j0;  // clamped, unconditional loads
+                v[u] = *reinterpret_cast<const float4*>(p + slab_at(j) * stride);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (j0 + 8 * u < nslab) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                if (j0 + 8 * step * u < nslab) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     }
     part[grp][threadIdx.x & 31] = acc;
@@ -243,6 +250,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
         for (int g = 1; g < 8; ++g) {
             const float4 o = part[g][threadIdx.x];
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        if (args.red_stage == 1) {
+            if (first < nslab) *reinterpret_cast<float4*>(TN_G(slab) + q * 4 + slab_at(first) * stride) = s;
+            return;
         }
         const float sv[4] = {s.x, s.y, s.z, s.w};
         float* gw = TN_G(grad_w);
@@ -354,7 +365,23 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
     for (int i = 0; i < a.ngroups; ++i) slab16 = slab16 && al16t(a.g[i].slab);
     if (slab16) {
         const int64_t total4 = (int64_t)a.n_out * (a.k_in + 4) / 4;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 31) / 32), 1, a.ngroups), dim3(256), 0, s, a);
+        const unsigned bx = (unsigned)((total4 + 31) / 32);
+        const int nslab_upper = a.nsplit * a.nbatch;
+        a.red_ny = 1;
+        a.red_stage = 2;
+        if (bx * a.ngroups < 512 && nslab_upper >= 64) {
+            int ny = (int)(1024 / (bx * a.ngroups));
+            ny = ny > 32 ? 32 : ny;
+            ny = ny > nslab_upper / 8 ? nslab_upper / 8 : ny;
+            if (ny >= 2) {
+                a.red_ny = ny;
+                a.red_stage = 1;
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, ny, a.ngroups), dim3(256), 0, s, a);
+                MPN_LAUNCH_CHECK();
+                a.red_stage = 2;
+            }
+        }
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, 1, a.ngroups), dim3(256), 0, s, a);
     } else {
         const int64_t total = (int64_t)a.n_out * (a.k_in + 1) * 8;
         hipLaunchKernelGGL(slab_reduce_scalar_kernel, dim3((unsigned)((total + 255) / 256), 1, a.ngroups), dim3(256), 0, s, a);
