@@ -291,4 +291,7 @@ CONFIGS = {
     "E": dict(N=20000, E=400000, d=256, L=12),
     # MOTS20-02-like stand-in (SURVEY.md section 8d cfg-C): 20 frames x 25 detections, reciprocal top-150 kNN, reference dims
     "C": dict(N=500, E=None, d=32, L=12, knn=dict(frames=20, dets=25, top_k=150)),
+    # KITTIMOTS-like sequence graph (SURVEY.md section 8d cfg-D, configs/kitti.yaml:66,71,136): 20 frames x ~7 detections,
+    # top-100 kNN, reference dims, L = 4; one graph per GPU, a different seed per rank
+    "D": dict(N=140, E=None, d=32, L=4, knn=dict(frames=20, dets=7, top_k=100)),
 }
