@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--config", default="B")
     ap.add_argument("--agg", default="sum", help="node_agg_fn (reference default: sum, configs/tracking_cfg.yaml:135)")
     ap.add_argument("--mode", default="auto", choices=["auto", "fwd", "train"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="operand precision of the Linear products; bf16 (fp32 accumulate) is inference only and is NOT the "
+                         "headline configuration (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -126,7 +129,11 @@ def main():
     have_bwd = mtrain.backward_available()
     mode = args.mode
     if mode == "auto":
-        mode = "train" if have_bwd else "fwd"
+        mode = "train" if have_bwd and args.precision == "fp32" else "fwd"
+    if args.precision != "fp32":
+        if mode == "train":
+            raise SystemExit("--precision bf16 is an inference mode")
+        model.gemm_precision = args.precision
     if mode == "train" and not have_bwd:
         raise SystemExit("--mode train needs mpnhip_backward")
 
@@ -193,7 +200,7 @@ def main():
         "metric": "edges/ms (MPN %s) on synthetic tracking graph" % ("forward+backward" if mode == "train" else "forward"),
         "value": value, "unit": "edges/ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
         "config": {"workload": "cfg-%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, "
                                "%s, one graph per GPU" % (args.config, N, E, c["d"], c["L"], args.agg,
                                                           "training step (fwd+bwd%s)" % ("+RCCL grad all-reduce" if world > 1 else "")

@@ -27,6 +27,13 @@ extern "C" {
 
 #define MPNHIP_MAX_LAYERS 8
 
+/* Operand precision of every Linear layer's product.  FP32 (default): fp32 operands and accumulation, the reference's
+ * arithmetic.  BF16: activations and weights are rounded to bf16 (round to nearest even) as they enter the product,
+ * accumulation, biases, gather-adds and aggregation stay fp32 -- BASELINE.json's "bf16 MLP GEMMs on MFMA"
+ * configuration (SURVEY.md section 8d cfg-E); forward only (mpnhip_backward refuses it). */
+#define MPNHIP_PREC_FP32 0
+#define MPNHIP_PREC_BF16 1
+
 #define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
 #define MPNHIP_AGG_MEAN 1 /* torch_scatter.scatter_mean (models/mpn.py:267) */
 #define MPNHIP_AGG_MAX 2  /* torch_scatter.scatter_max  (models/mpn.py:270), empty segment -> 0 */
@@ -61,6 +68,7 @@ typedef struct {
     mpnhip_mlp flow_out;  /* MPNet.node_model.flow_out_model (mpn.py:304) */
     mpnhip_mlp node;      /* MPNet.node_model.node_model: ONE Linear(2dn -> dn) + ReLU (mpn.py:309-310) */
     mpnhip_mlp classifier;/* classifier.edge_model    (mpn.py:238) */
+    int precision;        /* MPNHIP_PREC_*: operand precision of the Linear layers' products (inference only) */
 } mpnhip_model;
 
 const char* mpnhip_version(void);

@@ -38,7 +38,7 @@ class Model(C.Structure):
         ("dn", C.c_int), ("de", C.c_int), ("reattach_nodes", C.c_int), ("reattach_edges", C.c_int),
         ("agg", C.c_int), ("num_enc_steps", C.c_int),
         ("enc_node", Mlp), ("enc_edge", Mlp), ("edge", Mlp), ("flow_in", Mlp), ("flow_out", Mlp),
-        ("node", Mlp), ("classifier", Mlp),
+        ("node", Mlp), ("classifier", Mlp), ("precision", C.c_int),
     ]
 
 

@@ -369,6 +369,10 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     const int64_t N = n_nodes, E = n_edges;
     MPN_CHECK_ARG(N >= 0 && E >= 0, "backward: negative sizes");
     MPN_CHECK_ARG((x || N == 0) && (edge_attr || E == 0) && (grad_logits || E == 0), "backward: null tensor");
+    if (m.precision != MPNHIP_PREC_FP32) {
+        set_error("backward: bf16-operand products are an inference mode; train with MPNHIP_PREC_FP32");
+        return MPNHIP_ERR_UNSUPPORTED;
+    }
     {
         const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge, &m.edge, &m.flow_in, &m.flow_out, &m.node, &m.classifier};
         for (const mpnhip_mlp* q : all)

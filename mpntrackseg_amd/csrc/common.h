@@ -85,6 +85,9 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);
+// operand precision of the calling thread's GEMMs (mpnhip_model.precision): 0 fp32, 1 bf16 operands / fp32 accumulate
+void set_gemm_precision(int p);
+int gemm_precision();
 
 // ------------------------------------------------------------------------------------ weight gradients
 // dW[o, c] += sum_m dZ[m, o] * H[m, c], db[o] += sum_m dZ[m, o] over a (device-resident) row range.

@@ -33,8 +33,18 @@
 namespace mpnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Operand precision of the MFMA products of the calling thread's current forward (set by mpnhip_forward from
+// mpnhip_model.precision): 0 = fp32 operands (v_mfma_f32_32x32x2_f32), 1 = operands rounded to bf16 (RNE) when they
+// are staged into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- BASELINE.json's "bf16 MLP GEMMs on MFMA" mode.
+static thread_local int g_precision = 0;
+void set_gemm_precision(int p) { g_precision = p; }
+int gemm_precision() { return g_precision; }
 
 constexpr int BK = 32;
+constexpr int PKB = 40;  // bf16 images: row pitch in elements (32 k + 8 pad = 80 bytes: 16-byte aligned rows)
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -47,9 +57,12 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v) {
 // waves per SIMD the register allocation must leave room for (accumulators: 16 TN registers)
 constexpr int min_waves(int tn) { return tn <= 2 ? 4 : (tn <= 4 ? 3 : 2); }
 
-template <int WM, int WN, int TN, int BLAY>
+// BF16: same loader / epilogue; the LDS images are row-major bf16 [m][k], [n][k] (k contiguous: the fp32 rows are
+// rounded and written without a transpose) and every MFMA operand is one ds_read_b128 of 8 consecutive k.
+template <int WM, int WN, int TN, int BLAY, bool BF16 = false>
 __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs args) {
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(!BF16 || BLAY == B_KCONTIG, "bf16 operands: nn.Linear weights only");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int PA = BM + 1;                                 // pitch % 8 == 1 (transposing stores)
@@ -57,12 +70,14 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
     constexpr int A_F4 = BM / 32;                              // float4 loads per thread and K step
     constexpr int B_F4 = BN / 32;
     constexpr int PATCH = 32 * 36;                             // per-wave epilogue patch [32][36]
-    constexpr int TILE_FLOATS = BK * (PA + PB);
+    constexpr int TILE_FLOATS = BF16 ? (BM + BN) * PKB / 2 : BK * (PA + PB);
     constexpr int SMEM_FLOATS = TILE_FLOATS > 4 * PATCH ? TILE_FLOATS : 4 * PATCH;
 
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * PA;
+    __bf16* const Ab = reinterpret_cast<__bf16*>(smem);   // BF16: [BM][PKB], then [BN][PKB]
+    __bf16* const Bb = Ab + BM * PKB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -157,6 +172,21 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
 
     auto store_tile = [&](int kt) {
         const bool k_ok = kt * BK + ld_k4 < K;   // K % 4 == 0: a float4 is entirely in or out
+        if (BF16) {
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) {
+                const float4 v = keep4(k_ok, a_reg[j]);
+                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<bf16x4*>(Ab + (ld_r + 32 * j) * PKB + ld_k4) = o;
+            }
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) {
+                const float4 v = keep4(k_ok, b_reg[j]);
+                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<bf16x4*>(Bb + (ld_r + 32 * j) * PKB + ld_k4) = o;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int r = ld_r + 32 * j;
@@ -197,6 +227,24 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
         store_tile(kt);
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        if (BF16) {
+            // two 16-deep k blocks per K step; lane (i, h) supplies k = 8h .. 8h+7 of its row
+            const __bf16* ap = Ab + (wm * 32 + li) * PKB + lh * 8;
+            const __bf16* bp = Bb + (wn * 32 * TN + li) * PKB + lh * 8;
+            bf16x8 av[2], bv[2][TN];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                av[kb] = *reinterpret_cast<const bf16x8*>(ap + kb * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[kb][j] = *reinterpret_cast<const bf16x8*>(bp + 32 * j * PKB + kb * 16);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kb], bv[kb][j], acc[j], 0, 0, 0);
+            __syncthreads();
+            continue;
+        }
         // operand fetch one k pair ahead of the MFMAs that use it (explicit register double buffer)
         float a_cur = a_ptr[0], b_cur[TN];
 #pragma unroll
@@ -307,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
 
 // Any shape / alignment, one thread per output element: the K = 6 / 18-wide encoder layers of the
 // d = 32 configuration and other operands that are not 16-byte aligned.  Not a hot kernel.
-__global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, int b_layout) {
+__global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, int b_layout, int bf16) {
     const int N = args.N, K = args.K, ksplit = args.ksplit;
     for (int grp = 0; grp < args.ngroups; ++grp) {
         const GemmGroup& G = args.g[grp];
@@ -323,6 +371,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, i
             for (int k = 0; k < K; ++k) {
                 float av = (k >= ksplit ? a2 : a1)[k];
                 float bv = b_layout == B_KCONTIG ? G.B[(int64_t)n * G.ldb + k] : G.B[(int64_t)k * G.ldb + n];
+                if (bf16) { av = (float)(__bf16)av; bv = (float)(__bf16)bv; }  // same operand rounding as the MFMA path
                 acc = fmaf(av, bv, acc);
             }
             if (G.bias) acc += G.bias[n];
@@ -342,7 +391,9 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * TN * WN;
     int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
     dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
-    if (bl == B_KCONTIG)
+    if (bl == B_KCONTIG && g_precision == 1)
+        hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_KCONTIG, true>), grid, dim3(NTHREADS), 0, s, a);
+    else if (bl == B_KCONTIG)
         hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_KCONTIG>), grid, dim3(NTHREADS), 0, s, a);
     else
         hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_NCONTIG>), grid, dim3(NTHREADS), 0, s, a);
@@ -382,7 +433,7 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         int64_t total = a.m_upper * a.N;
         unsigned blocks = (unsigned)((total + NTHREADS - 1) / NTHREADS);
         if (blocks > 65535u * 16) blocks = 65535u * 16;
-        hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks), dim3(NTHREADS), 0, s, a, bl);
+        hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks), dim3(NTHREADS), 0, s, a, bl, g_precision == 1 ? 1 : 0);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
     }

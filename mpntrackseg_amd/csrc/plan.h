@@ -220,6 +220,7 @@ static inline void hidden_ptrs(const mpnhip_mlp& m, float* const two[2], int64_t
 // the fused edge-chain kernels (edge_chain.hip) cover this model's per-edge modules
 static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
     if (getenv("MPNHIP_NO_CHAIN")) return false;  // tuning / A-B switch
+    if (m.precision != MPNHIP_PREC_FP32) return false;  // the fused chain kernels are fp32-operand kernels
     return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
            edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
 }

@@ -345,6 +345,12 @@ class MOTMPNet(nn.Module):
         m.reattach_nodes = int(bool(self.reattach_initial_nodes))
         m.reattach_edges = int(bool(self.reattach_initial_edges))
         m.num_enc_steps = int(self.num_enc_steps)
+        # operand precision of the Linear products: 'fp32' (the reference's arithmetic) or 'bf16' (inference only:
+        # operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs on MFMA" configuration)
+        prec = getattr(self, 'gemm_precision', 'fp32')
+        if prec not in ('fp32', 'bf16'):
+            raise capi.MpnhipError("gemm_precision must be 'fp32' or 'bf16', not %r" % (prec,))
+        m.precision = 1 if prec == 'bf16' else 0
         m.enc_node = self.encoder.node_model.c_struct(keep, grads)
         m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
         m.classifier = self.classifier.edge_model.c_struct(keep, grads)

@@ -53,13 +53,40 @@ AGG = {"sum": scatter_add, "mean": scatter_mean, "max": scatter_max}
 
 
 # ----------------------------------------------------------------------------- models/mlp.py:4-28
+# Operand precision of every Linear product (mpnhip_model.precision): "fp32" = the reference's arithmetic; "bf16" =
+# activations and weights rounded to bfloat16 (round to nearest even) as they enter the product, fp32 accumulation and
+# fp32 bias -- the restatement of BASELINE.json's "bf16 MLP GEMMs" configuration ("compare
+# against the CPU restatement with inputs/weights rounded to bf16 and fp32 accumulation").  Set with `precision(...)`.
+_PRECISION = ["fp32"]
+
+
+class precision:
+    """``with oracle.precision("bf16"): ...`` -- scoped switch of the Linear operand precision."""
+    def __init__(self, p):
+        assert p in ("fp32", "bf16")
+        self.p = p
+
+    def __enter__(self):
+        self.old = _PRECISION[0]
+        _PRECISION[0] = self.p
+
+    def __exit__(self, *a):
+        _PRECISION[0] = self.old
+
+
+def linear(x, w, b):
+    if _PRECISION[0] == "bf16":
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    return F.linear(x, w, b)
+
+
 def mlp(x, W, prefix):
     """MLP.forward (models/mlp.py:27-28) for dropout_p=0, use_batchnorm=False: Linear (+ReLU
     unless the layer's out-dim is 1, mlp.py:17).  ``W`` maps state_dict keys to tensors."""
     i = 0
     while f"{prefix}.fc_layers.{i}.weight" in W:
         w, b = W[f"{prefix}.fc_layers.{i}.weight"], W[f"{prefix}.fc_layers.{i}.bias"]
-        x = F.linear(x, w, b)
+        x = linear(x, w, b)
         if w.shape[0] != 1:
             x = torch.relu(x)
             i += 2
@@ -87,7 +114,7 @@ def node_model(x, edge_index, e, W, agg):
     in_in = torch.cat([x[col[in_mask]], e[in_mask]], dim=1)                  # :92-93
     flow_in = AGG[agg](mlp(in_in, W, "MPNet.node_model.flow_in_model"), row[in_mask], n)       # :94-96
     flow = torch.cat((flow_in, flow_out), dim=1)                             # :97
-    return torch.relu(F.linear(flow, W["MPNet.node_model.node_model.0.weight"],
+    return torch.relu(linear(flow, W["MPNet.node_model.node_model.0.weight"],
                                W["MPNet.node_model.node_model.0.bias"]))    # :99, :309-310
 
 

@@ -335,3 +335,69 @@ def test_cfgE_size_properties():
     b, xb, _ = run_hot(model, g["x"], g["edge_index"][:, p], g["edge_attr"][p])
     assert rel_err(b, a[:, p]) < 1e-5
     assert rel_err(xb, xa) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ bf16-operand products
+def _oracle_logits(params, W, g, prec):
+    Wt = O.to_tensors(W)
+    with torch.no_grad(), O.precision(prec):
+        _, logits, xo, eo = O.forward(params, Wt, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
+                                      torch.from_numpy(g["edge_attr"]), return_state=True)
+    return torch.stack([l.view(-1) for l in logits]).numpy(), xo.numpy(), eo.numpy()
+
+
+@pytest.mark.parametrize("d,N,E,L,agg", [(256, 1500, 12000, 2, "mean"), (128, 1200, 9000, 3, "sum"), (32, 300, 2500, 4, "max")])
+def test_bf16_operand_mode_matches_bf16_oracle(d, N, E, L, agg):
+    """BASELINE.json configs[4] arithmetic ("bf16 MLP GEMMs on MFMA"): every Linear product takes
+    bf16-rounded activations and weights, accumulates in fp32.  Checked against the oracle with the SAME rounding
+    (tolerance 2e-2 relative, SURVEY's figure: a different fp32 summation order can flip a bf16 rounding of a later
+    layer's input) at the 256-d widths of cfg-E (unfused path), at 128-d (where fp32 would take the fused chain) and
+    at the reference's 32-d dims; and it must differ from the fp32 result (the mode is really on)."""
+    g = synth.make_graph(N, E, seed=13)
+    params = synth.model_params(d, L, agg)
+    W = synth.make_weights(params, seed=7, gain=0.7)
+    model = make_model(params, W)
+    model.gemm_precision = 'bf16'
+    got, xg, eg = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    want, xw, ew = _oracle_logits(params, W, g, "bf16")
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < 2e-2
+    assert rel_err(xg, xw) < 2e-2 and rel_err(eg, ew) < 2e-2
+    model.gemm_precision = 'fp32'
+    fp32, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    want32, _, _ = _oracle_logits(params, W, g, "fp32")
+    assert rel_err(fp32, want32) < 1e-4
+    assert rel_err(got, fp32) > 1e-4  # bf16 rounding is visible
+    # the bf16 result is closer to the bf16 oracle than the fp32 result is
+    assert rel_err(got, want) < rel_err(fp32, want)
+
+
+def test_bf16_mode_refuses_training():
+    g = synth.make_graph(60, 400, seed=3, node_in_dim=64)
+    params = synth.model_params(32, 2, "sum", node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=7)).train()
+    model.gemm_precision = 'bf16'
+    x = torch.from_numpy(g["x"]).to(dev()).requires_grad_(True)
+    with pytest.raises(capi.MpnhipError):
+        model.hot_path(x, torch.from_numpy(g["edge_index"]).to(dev()), torch.from_numpy(g["edge_attr"]).to(dev()))
+    model.gemm_precision = 'fp16'
+    with pytest.raises(capi.MpnhipError):
+        with torch.no_grad():
+            model.hot_path(x.detach(), torch.from_numpy(g["edge_index"]).to(dev()), torch.from_numpy(g["edge_attr"]).to(dev()))
+
+
+def test_cfgE_bf16_size_properties():
+    """BASELINE.json configs[4] at full size (20k nodes / 400k edges / 256-d), bf16-operand mode, 2 steps: finite, and
+    equivariant under an edge permutation (each edge's product rows are rounded independently of their position)."""
+    c = synth.CONFIGS["E"]
+    g = synth.make_graph(c["N"], c["E"], seed=5)
+    params = synth.model_params(c["d"], 2, "mean")
+    model = make_model(params, synth.make_weights(params, seed=7))
+    model.gemm_precision = 'bf16'
+    a, xa, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert np.isfinite(a).all() and np.isfinite(xa).all()
+    p = np.argsort(synth.uniform01(8, c["E"]), kind="stable")
+    b, xb, _ = run_hot(model, g["x"], g["edge_index"][:, p], g["edge_attr"][p])
+    # (the aggregation's fp32 summation order follows the edge order; a changed last bit can flip a later bf16 rounding)
+    assert rel_err(b, a[:, p]) < 1e-2
+    assert rel_err(xb, xa) < 1e-2
