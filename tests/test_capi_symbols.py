@@ -47,4 +47,6 @@ def test_version_and_sizes_without_gpu(lib):
 def test_struct_layout_matches_c():
     # sizeof(mpnhip_mlp) = 2 ints + 8 ints + 4 * 8 pointers, padded to 8
     assert ctypes.sizeof(capi.Mlp) == 8 + 32 + 4 * 8 * 8
-    assert ctypes.sizeof(capi.Model) == 24 + 7 * ctypes.sizeof(capi.Mlp)
+    # 6 ints, 7 MLPs, the trailing precision int padded to the struct's 8-byte alignment
+    assert ctypes.sizeof(capi.Model) == 24 + 7 * ctypes.sizeof(capi.Mlp) + 8
+    assert capi.Model.precision.offset == 24 + 7 * ctypes.sizeof(capi.Mlp)
