@@ -252,10 +252,9 @@ def rooflines(prof, c, args, N, E, chain):
     """Roofline fractions from the in-stream HIP-event timings taken over the timed region:
     dominant kernel = first-layer edge-MLP GEMM (fp32 MFMA); HBM-bound kernel = segmented aggregation."""
     gemm_us, gemm_n, agg_us, agg_n, empty_us = prof
-    # avg_us is the raw begin/end event bracket around ONE launch on the launch stream.  It includes the cost
-    # of the two event records themselves (`empty_event_pair_us`, measured with nothing between the records;
-    # a few us): negligible for the ~70 us GEMM, a conservative over-estimate for the ~7 us aggregation kernel
-    # (rocprofv3's pure kernel duration for it is in profiles/).  No correction is applied.
+    # avg_us: HIP events attached to the kernel's own dispatch on the launch stream (hipExtLaunchKernelGGL start / stop
+    # events): the dispatch's begin -> end, what rocprofv3's kernel trace reports too (profiles/).  `empty_event_pair_us`
+    # is what a plain record pair with nothing between costs on this box -- the overhead the attached events avoid.
     d = c["d"]
     dn, de, he = d, d // 2, 5 * d // 2
     res = {}

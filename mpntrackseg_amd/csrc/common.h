@@ -1,6 +1,7 @@
 // Shared declarations of the mpnhip library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -160,6 +161,17 @@ int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const in
 enum { PROF_GEMM = 0, PROF_AGG = 1 };
 void prof_begin(int kind, hipStream_t s);
 void prof_end(int kind, hipStream_t s);
+// true (once per bracket) while a bracket is open: the events to attach to the designated kernel's dispatch
+bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop);
+// launch `kernel` normally, or with the open bracket's events attached to the dispatch (hipExtLaunchKernelGGL)
+#define MPN_LAUNCH_PROFILED(kernel, grid, block, stream, ...)                                              \
+    do {                                                                                                  \
+        hipEvent_t _e0, _e1;                                                                              \
+        if (mpnhip::prof_launch_events(&_e0, &_e1))                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, _e0, _e1, 0, __VA_ARGS__);              \
+        else                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                              \
+    } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

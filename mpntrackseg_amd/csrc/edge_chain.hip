@@ -910,12 +910,12 @@ int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
             if (exact)
-                hipLaunchKernelGGL((edge_chain_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), s, a);
             else
-                hipLaunchKernelGGL((edge_chain_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), s, a);
             break;
-        case 64: hipLaunchKernelGGL((edge_chain_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((edge_chain_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 64: MPN_LAUNCH_PROFILED((edge_chain_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), s, a); break;
+        case 32: MPN_LAUNCH_PROFILED((edge_chain_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), s, a); break;
         default: set_error("edge_chain: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
 #ifdef MPNHIP_CHAIN_TS

@@ -392,9 +392,9 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
     dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
     if (bl == B_KCONTIG && g_precision == 1)
-        hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_KCONTIG, true>), grid, dim3(NTHREADS), 0, s, a);
+        MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, true>), grid, dim3(NTHREADS), s, a);
     else if (bl == B_KCONTIG)
-        hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_KCONTIG>), grid, dim3(NTHREADS), 0, s, a);
+        MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG>), grid, dim3(NTHREADS), s, a);
     else
         hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, B_NCONTIG>), grid, dim3(NTHREADS), 0, s, a);
     MPN_LAUNCH_CHECK();

@@ -37,6 +37,8 @@ struct ProfState {
     bool made[2] = {false, false};
     int n[2] = {0, 0};
     int open_kind = -1;
+    bool taken = false;
+    hipStream_t stream = nullptr;
 } g_prof;
 }  // namespace
 
@@ -49,14 +51,26 @@ void prof_begin(int kind, hipStream_t s) {
         }
         g_prof.made[kind] = true;
     }
-    (void)hipEventRecord(g_prof.ev[kind][g_prof.n[kind]][0], s);
+    // The designated kernel's launch site picks the pair up with prof_launch_events() and hands it to
+    // hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end times -- no record packets
+    // before and after the kernel inflate a 7 us measurement.  A site that does not pick them up falls back to records.
     g_prof.open_kind = kind;
+    g_prof.taken = false;
+    g_prof.stream = s;
+}
+
+bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof.on || g_prof.open_kind < 0 || g_prof.taken) return false;
+    const int kind = g_prof.open_kind;
+    *start = g_prof.ev[kind][g_prof.n[kind]][0];
+    *stop = g_prof.ev[kind][g_prof.n[kind]][1];
+    g_prof.taken = true;
+    return true;
 }
 
 void prof_end(int kind, hipStream_t s) {
     if (!g_prof.on || g_prof.open_kind != kind || g_prof.n[kind] >= PROF_MAX - 64) return;
-    (void)hipEventRecord(g_prof.ev[kind][g_prof.n[kind]][1], s);
-    g_prof.n[kind]++;
+    if (g_prof.taken) g_prof.n[kind]++;  // (a bracket nobody launched into is dropped)
     g_prof.open_kind = -1;
 }
 

@@ -253,7 +253,7 @@ static bool try_launch_block(SegArgs& a, int64_t total_rows, hipStream_t stream)
     int sub = 1;
     while (sub < a.dim / 4) sub <<= 1;
     a.sub = sub;
-    hipLaunchKernelGGL(k_segment_reduce_block, dim3(a.nseg), dim3(256), 0, stream, a);
+    MPN_LAUNCH_PROFILED(k_segment_reduce_block, dim3(a.nseg), dim3(256), stream, a);
     return true;
 }
 
@@ -306,7 +306,7 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
         while (sub < dim / 4 && sub < 64) sub <<= 1;
         a.sub = sub;
         const int64_t threads = (int64_t)a.nseg * sub;
-        hipLaunchKernelGGL(k_aggregate, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
+        MPN_LAUNCH_PROFILED(k_aggregate, dim3((unsigned)((threads + 255) / 256)), dim3(256), stream, a);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
     }
