@@ -71,8 +71,13 @@ class EdgeModel(nn.Module):
         self.edge_model = edge_model
 
     def forward(self, node_feats, edge_index, edge_attr):
-        raise capi.MpnhipError("EdgeModel is evaluated fused inside MetaLayer.forward / MOTMPNet.forward "
-                               "(project-then-gather); call those")
+        """mpn.py:67-69, operator level (inference): native row gathers, the reference's cat, the native MLP.
+        ``MetaLayer.forward`` / ``MOTMPNet.forward`` evaluate the same module fused (project-then-gather)."""
+        from .graph import gather_rows
+        capi.require_device(node_feats, edge_index, edge_attr)
+        row, col = edge_index[0].to(torch.int32).contiguous(), edge_index[1].to(torch.int32).contiguous()
+        out = torch.cat([gather_rows(node_feats, row), gather_rows(node_feats, col), capi.f32c(edge_attr)], dim=1)
+        return self.edge_model(out)
 
 
 class TimeAwareNodeModel(nn.Module):
@@ -86,8 +91,27 @@ class TimeAwareNodeModel(nn.Module):
         self.node_agg_fn = node_agg_fn
 
     def forward(self, x, edge_index, edge_attr):
-        raise capi.MpnhipError("TimeAwareNodeModel is evaluated fused inside MetaLayer.forward / MOTMPNet.forward; "
-                               "call those")
+        """mpn.py:83-99, operator level (inference): the boolean-mask selections become native compactions, the
+        gathers / MLPs / ``node_agg_fn`` / Linear native calls.  ``MetaLayer.forward`` evaluates the same module fused."""
+        from .graph import compact, gather_rows
+        capi.require_device(x, edge_index, edge_attr)
+        row, col = edge_index
+        ea = capi.f32c(edge_attr)
+        flows = []
+        for mask, mlp in (((row > col), self.flow_in_model), ((row < col), self.flow_out_model)):   # :91-96, :85-89
+            ids, _ = compact(mask.to(torch.uint8).contiguous())
+            sel_col = col.to(torch.int32)[ids.long()].contiguous()
+            sel_row = row[ids.long()]
+            inp = torch.cat([gather_rows(x, sel_col), gather_rows(ea, ids)], dim=1)
+            flows.append(self.node_agg_fn(mlp(inp), sel_row, x.size(0)))
+        flow = torch.cat((flows[0], flows[1]), dim=1)                                                # :97
+        lin = self.node_model[0]                                                                      # Linear + ReLU, :99
+        out = torch.empty((flow.shape[0], lin.out_features), dtype=torch.float32, device=flow.device)
+        lib = capi.load()
+        capi.check(lib.mpnhip_linear(capi.ptr(flow), flow.shape[1], capi.ptr(lin.weight), capi.ptr(lin.bias), capi.ptr(out),
+                                     out.shape[1], flow.shape[0], lin.out_features, lin.in_features, 1, capi.stream_ptr()),
+                   "mpnhip_linear")
+        return out
 
 
 class MetaLayer(nn.Module):

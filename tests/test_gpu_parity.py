@@ -401,3 +401,27 @@ def test_cfgE_bf16_size_properties():
     # (the aggregation's fp32 summation order follows the edge order; a changed last bit can flip a later bf16 rounding)
     assert rel_err(b, a[:, p]) < 1e-2
     assert rel_err(xb, xa) < 1e-2
+
+
+def test_edge_and_node_model_operator_level():
+    """EdgeModel.forward / TimeAwareNodeModel.forward called on their own (mpn.py:59-99) against the oracle's
+    edge_model / node_model, all three aggregations; the fused MetaLayer path must agree with their composition."""
+    g = synth.make_graph(90, 700, seed=21, node_in_dim=64)
+    for agg in ("sum", "mean", "max"):
+        params = synth.model_params(32, 2, agg, node_in_dim=64)
+        W = synth.make_weights(params, seed=7)
+        model = make_model(params, W)
+        Wt = O.to_tensors(W)
+        dn, de = 32, 16
+        x = torch.from_numpy(synth.normal(5, (90, 2 * dn), stream=1))
+        e = torch.from_numpy(synth.normal(5, (700, 2 * de), stream=2))
+        ei = torch.from_numpy(g["edge_index"])
+        with torch.no_grad():
+            e_ref = O.edge_model(x, ei, e, Wt)
+            x_ref = O.node_model(x, ei, e_ref, Wt, agg)
+            e_got = model.MPNet.edge_model(x.to(dev()), ei.to(dev()), e.to(dev()))
+            x_got = model.MPNet.node_model(x.to(dev()), ei.to(dev()), e_got)
+            x_fused, e_fused = model.MPNet(x.to(dev()), ei.to(dev()), e.to(dev()))
+        assert rel_err(e_got.cpu().numpy(), e_ref.numpy()) < 1e-5
+        assert rel_err(x_got.cpu().numpy(), x_ref.numpy()) < 1e-5
+        assert rel_err(e_fused.cpu().numpy(), e_ref.numpy()) < 1e-5 and rel_err(x_fused.cpu().numpy(), x_ref.numpy()) < 1e-5
