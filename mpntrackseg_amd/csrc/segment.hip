@@ -268,10 +268,10 @@ static int launch_seg(SegArgs a, hipStream_t stream) {
     if (per > sub || (per & (per - 1))) {
         // the row is not one power-of-two group of lanes (e.g. 80 or 56 x 16 bytes): column blocks of the largest
         // power of two that divides it, one work item per (segment, block), so that no lane idles and no lane walks
-        // the segment twice; rows are still read in pieces of >= 128 contiguous bytes
+        // the segment twice; rows are still read in pieces of >= 256 contiguous bytes
         int p2 = per & -per;
         if (p2 > 64) p2 = 64;
-        if (p2 * (vec ? 16 : 4) >= 128) { sub = p2; a.nblk = per / p2; }
+        if (p2 * (vec ? 16 : 4) >= 256) { sub = p2; a.nblk = per / p2; }  // (128-byte pieces measured slower than idle lanes)
     }
     a.sub = sub;
     int64_t threads = (int64_t)a.nseg * sub * a.nblk;
