@@ -191,6 +191,12 @@ int mpnhip_attention_aggregate_backward(const void* graph_buf, int n_nodes, int6
  * the hw contiguous spatial positions (rows = N * C). */
 int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream);
 
+/* torch.optim.Adam(lr, betas, eps, weight_decay).step() (the optimizer of pl_module.py:76-77, configs/tracking_cfg.yaml:6-10)
+ * over FLAT fp32 buffers of n elements: parameters, gradients (as the backward / all-reduce left them) and the two
+ * moment buffers (zero before step 1); step = 1, 2, ... counts the calls. */
+int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Graph construction on the device: what MOTGraph.construct_graph_object
  * (data/mot_graph.py:283-317) computes before the model runs.  All indices int64 like the reference's tensors.

@@ -10,6 +10,8 @@
 // straight into k-major LDS images (the row index IS the MFMA k index, so nothing is transposed).
 // H may come as two column segments (the reference's torch.cat([initial, current]) input), rows of
 // either operand may be gathered through an index (edge_attr / dlogits live in original edge order).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mpnhip {
@@ -322,7 +324,8 @@ void tn_plan(TnArgs& a) {
     if (a.nbatch < 1) a.nbatch = 1;
     const int tbn = a.k_in <= 64 ? 64 : 128;
     int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn) * a.nbatch;
-    int target = 1536 / (tiles > 0 ? tiles : 1);
+    static const int blocks_wanted = [] { const char* e = getenv("MPNHIP_TN_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 1536; }();  // tuning override
+    int target = blocks_wanted / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
     if (target > 128) target = 128;
     int64_t chunk = (a.m_upper + target - 1) / target;

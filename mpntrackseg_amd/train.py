@@ -45,18 +45,23 @@ def allreduce_mean_(flat, world_size, group=None):
 
 
 class FlatBucket:
-    """Parameters' gradients as views of one flat fp32 buffer (one collective per step)."""
+    """Parameters AND their gradients as views of two flat fp32 buffers: one collective and one optimizer kernel per
+    step.  The parameters' storage is moved into ``flat_params`` (values preserved; ``state_dict`` unaffected)."""
 
     def __init__(self, params):
         self.params = list(params)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
         self.views = {}
         off = 0
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views[id(p)] = v
+            pv = self.flat_params[off:off + p.numel()].view_as(p)
+            pv.copy_(p.data)
+            p.data = pv
             p.grad = v
             off += p.numel()
 
@@ -64,18 +69,39 @@ class FlatBucket:
         self.flat.zero_()
 
 
+class FlatAdam:
+    """``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` (the reference's optimizer, pl_module.py:76-77) as ONE
+    native kernel over a ``FlatBucket``'s flat parameter / gradient buffers (``mpnhip_adam_step``)."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.bucket = bucket
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(bucket.flat_params)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat_params)
+        self.t = 0
+
+    def step(self):
+        import ctypes as C
+        self.t += 1
+        b = self.bucket
+        capi.check(capi.load().mpnhip_adam_step(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
+                                                capi.ptr(self.exp_avg_sq), b.flat.numel(), C.c_float(self.lr),
+                                                C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                                C.c_float(self.weight_decay), self.t, capi.stream_ptr()), "mpnhip_adam_step")
+
+
 class TrainStep:
     """fwd (saving activations) -> loss gradient -> hand-written bwd into the flat bucket ->
     all-reduce(sum)/W over RCCL (world_size > 1) -> Adam.  Graph prep is cached on `holder`."""
 
-    def __init__(self, model, world_size=1, lr=1e-3, process_group=None):
+    def __init__(self, model, world_size=1, lr=1e-3, process_group=None, weight_decay=0.0):
         if not backward_available():
             raise capi.MpnhipError("TrainStep needs mpnhip_backward")
         self.model = model
         self.world_size = world_size
         self.pg = process_group
         self.bucket = FlatBucket(model.hot_path_parameters())
-        self.opt = torch.optim.Adam(self.bucket.params, lr=lr)
+        self.opt = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay)
         self.first_class_step = max(int(model.num_enc_steps) - int(model.num_class_steps), 0)
 
     def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True):

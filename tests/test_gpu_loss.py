@@ -57,3 +57,27 @@ def test_step_metrics_match_reference_formulas():
     ref = LO.compute_perform_metrics([logit], torch.from_numpy(ei), labels, N)
     for k in ("accuracy", "recall", "precision", "constr_sr"):
         assert abs(got[k] - ref[k]) < 1e-6, k
+
+
+def test_flat_adam_matches_torch_adam():
+    """mpnhip_adam_step over a FlatBucket == torch.optim.Adam (pl_module.py:76-77 with configs/tracking_cfg.yaml:6-10)."""
+    import torch
+    from mpntrackseg_amd.train import FlatAdam, FlatBucket
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(37, 5), (128,), (16, 16), (1,)]
+    for wd in (0.0, 1e-4):
+        ref = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+        mine = [r.detach().clone().requires_grad_(True) for r in ref]
+        opt = torch.optim.Adam(ref, lr=1e-3, weight_decay=wd)
+        bucket = FlatBucket(mine)
+        fopt = FlatAdam(bucket, lr=1e-3, weight_decay=wd)
+        for it in range(6):
+            grads = [torch.randn(s, device=dev) * (1 + it) for s in shapes]
+            for r, m, g in zip(ref, mine, grads):
+                r.grad = g.clone()
+                bucket.views[id(m)].copy_(g)
+            opt.step()
+            fopt.step()
+            for r, m in zip(ref, mine):
+                assert float((r.detach() - m.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
