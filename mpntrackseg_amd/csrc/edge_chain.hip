@@ -40,9 +40,14 @@ namespace {
 #ifdef MPNHIP_CHAIN_TS
 #define TS_INIT() long long* tsp = A.ts ? A.ts + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 : nullptr
 #define TS(i) do { if (tsp && (threadIdx.x & 63) == 0) tsp[i] = clock64(); } while (0)
+// slot 15: where the wave ran -- HW_ID (wave / simd / cu / sh / se fields) | XCC_ID << 32
+#define TS_WHERE() do { if (tsp && (threadIdx.x & 63) == 0) { unsigned hw, xcc; \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+    tsp[15] = (long long)hw | ((long long)(xcc & 0xf) << 32); } } while (0)
 #else
 #define TS_INIT() do {} while (0)
 #define TS(i) do {} while (0)
+#define TS_WHERE() do {} while (0)
 #endif
 
 constexpr int CH_FLOATS = 5120;  // floats per weight chunk buffer (20 KB)
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     int c = 0;  // chunk being computed (buffer parity)
     TS_INIT();
     TS(0);
+    TS_WHERE();
     chunk_fetch<chunk_q(N4_1)>(A.w1T, N4_1, tid, wbuf_at(0));
     {
         // biases -> LDS (ordinary loads; drained with chunk 0 by the first barrier)

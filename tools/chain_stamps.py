@@ -30,6 +30,26 @@ def main():
     for name, i, j, mf in PH[kind]:
         d = a[:, j] - a[:, i]
         print("%-26s %9.0f %9.0f %9.0f %9d   %d" % (name, d.mean(), d[fast].mean(), d[slow].mean(), d.min(), mf * 64))
+    placement(a, last)
+
+def placement(a, last):
+    """How the dispatcher spread the waves: waves per CU from the HW_ID / XCC_ID stamp (slot 15)."""
+    w = a[:, 15]
+    if not (w > 0).any():
+        return
+    hw, xcc = w & 0xffffffff, (w >> 32) & 0xf
+    cu, sh, se, simd = (hw >> 8) & 0xf, (hw >> 12) & 0x1, (hw >> 13) & 0x7, (hw >> 4) & 0x3
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    cus, counts = np.unique(key, return_counts=True)
+    print("placement: %d CUs used; waves per CU histogram:" % len(cus), dict(zip(*np.unique(counts, return_counts=True))))
+    life = a[:, last] - a[:, 0]
+    for c in sorted(set(counts)):
+        sel = np.isin(key, cus[counts == c])
+        print("  CUs with %2d waves: mean wave life %8.0f cycles, last end %d" % (c, life[sel].mean(), (a[sel, last] - a[:, 0].min()).max()))
+    skey = key * 4 + simd
+    _, sc = np.unique(skey, return_counts=True)
+    print("  waves per SIMD histogram:", dict(zip(*np.unique(sc, return_counts=True))))
+
 
 if __name__ == "__main__":
     main()
