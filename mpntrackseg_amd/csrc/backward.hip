@@ -515,11 +515,17 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         }
         return MPNHIP_OK;
     };
-    // Steps L .. fork_at are finished first; their weight gradients then run on a side stream UNDER the remaining
-    // steps' chain kernels (which leave about half of the MFMA pipe idle: 1.5 wave tiles per SIMD at cfg-B).
-    const int fork_at = L / 2 + 1;
-    bool forked = false;
+    // The steps are finished from L down to 1.  Their weight gradients go in groups: as soon as a group's steps are done
+    // its batched products run on a side stream UNDER the remaining steps' chain kernels (which leave 120 of the 256
+    // CUs idle for the last third of their run at cfg-B); only the last group runs after the loop.  Groups are issued
+    // to ONE side stream in order, so they can share its slab buffer and their "+=" into the gradients stay ordered.
     const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready() == MPNHIP_OK;
+    static const int groups_wanted = [] { const char* e = getenv("MPNHIP_WGRAD_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 2 ? v : 3; }();
+    const int ngroups = !want_fork ? 1 : (L >= 2 * groups_wanted ? groups_wanted : 2);
+    // group g (g = 0 is finished first) covers batches [glo(g), glo(g - 1)): the top L / ngroups steps, and so on
+    auto glo = [&](int g) { return g < 0 ? (int)L : (int)(L - (int64_t)(g + 1) * L / ngroups); };
+    int next_group = 0;
+    bool forked = false;
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
@@ -608,23 +614,22 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             }
         }
         cx ^= 1;
-        if (want_fork && step == fork_at) {
+        if (next_group < ngroups - 1 && b_ == glo(next_group)) {
             MPN_HIP(hipEventRecord(g_side.ready, s));
             MPN_HIP(hipStreamWaitEvent(g_side.stream, g_side.ready, 0));
-            MPN_TRY(mp_weight_grads(fork_at - 1, L - fork_at + 1, g_side.stream, p.slab_side));
-            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
+            MPN_TRY(mp_weight_grads(glo(next_group), glo(next_group - 1) - glo(next_group), g_side.stream, p.slab_side));
+            ++next_group;
             forked = true;
         }
     }
 
     if (L > 0) {
-        // second half of the steps (if it was not forked to the side stream already), then join
+        // the last group of steps, after the side stream's groups ("+=" into the same gradients: they come first)
         if (forked) {
-            MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));  // the side stream's "+=" into the gradients come first
-            MPN_TRY(mp_weight_grads(0, fork_at - 1, s, p.slab));
-        } else {
-            MPN_TRY(mp_weight_grads(0, L, s, p.slab));
+            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
+            MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));
         }
+        MPN_TRY(mp_weight_grads(0, glo(ngroups - 2 < 0 ? -1 : ngroups - 2), s, p.slab));
         {   // unpack the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] (their biases were handled above)
             struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
                 {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
