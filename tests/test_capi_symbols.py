@@ -50,3 +50,27 @@ def test_struct_layout_matches_c():
     # 6 ints, 7 MLPs, the trailing precision int padded to the struct's 8-byte alignment
     assert ctypes.sizeof(capi.Model) == 24 + 7 * ctypes.sizeof(capi.Mlp) + 8
     assert capi.Model.precision.offset == 24 + 7 * ctypes.sizeof(capi.Mlp)
+
+
+def test_new_entry_points_argument_checks_without_gpu():
+    """Size queries and the argument checks of the f-3 / f-4 / optimizer entry points run on the host: no device work is
+    reached for empty inputs, null pointers or undersized workspaces (error codes as include/mpnhip.h states)."""
+    l = capi.load()
+    assert l.mpnhip_knn_mask_workspace_bytes(1000, 0) > l.mpnhip_knn_mask_workspace_bytes(1000, 1) > 0
+    assert l.mpnhip_time_valid_conn_workspace_bytes(500) >= 501 * 8
+    assert l.mpnhip_compact_workspace_bytes(1000) > 0
+    # empty inputs are successful no-ops
+    assert l.mpnhip_knn_mask(None, None, 0, 0, 5, 1, 1, None, None, 0, None) == 0
+    assert l.mpnhip_edge_features(None, 0, 0, None, ctypes.c_float(25.0), None, None, None, None, None, None) == 0
+    assert l.mpnhip_pairwise_distance(None, 0, 0, None, 0, ctypes.c_float(1e-6), None, None) == 0
+    assert l.mpnhip_gather_rows(None, 4, None, 0, 4, None, None) == 0
+    assert l.mpnhip_average_preds(None, None, 0, None, None) == 0
+    assert l.mpnhip_adam_step(None, None, None, None, 0, ctypes.c_float(1e-3), ctypes.c_float(0.9), ctypes.c_float(0.999),
+                              ctypes.c_float(1e-8), ctypes.c_float(0.0), 1, None) == 0
+    # null pointers / bad sizes are refused before anything is launched
+    assert l.mpnhip_knn_mask(None, None, 10, 5, 5, 1, 1, None, None, 0, None) != 0
+    assert b"knn_mask" in l.mpnhip_last_error()
+    assert l.mpnhip_edge_features(None, 3, 2, None, ctypes.c_float(25.0), None, None, None, None, None, None) != 0
+    assert l.mpnhip_adam_step(None, None, None, None, 5, ctypes.c_float(1e-3), ctypes.c_float(0.9), ctypes.c_float(0.999),
+                              ctypes.c_float(1e-8), ctypes.c_float(0.0), 0, None) != 0
+    assert l.mpnhip_window_accumulate(None, None, 3, None, 2, 0, None, None, None) != 0   # more kept than window edges
