@@ -261,7 +261,10 @@ def rooflines(prof, c, args, N, E, chain):
     hn, hc = 7 * d // 4, d // 4
     if gemm_n and chain:
         # fused per-edge chain (edge MLP e-part + classifier + flow MLP e-part): MACs per edge, DESIGN.md section 4
-        macs = 2 * de * he + he * de + de * hc + hc + de * hn + hn * dn
+        # the re-attached e0's share of the first layer is computed once per forward (Q0, one GEMM) when de >= 32: the
+        # kernel then contracts de, not 2 de, columns there -- EXECUTED flops are what the MFMA fraction is quoted on
+        k1 = de if (de >= 32 and c["L"] > 1) else 2 * de
+        macs = k1 * he + he * de + de * hc + hc + de * hn + hn * dn
         flops = 2.0 * E * macs
         ach = flops / (gemm_us * 1e-6) / 1e12
         res["roofline"] = {"bound": "mfma", "kernel": "edge_chain_kernel<%s>: fused edge MLP + classifier + flow MLPs of one MP step, "

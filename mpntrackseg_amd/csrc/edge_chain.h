@@ -15,6 +15,8 @@ struct EdgeChainArgs {
     const float* xb;
     int64_t ldxa, ldxb;
     int k1a, k1b;
+    const float* Q0;       // [E, he] or nullptr: per-edge C-in of the first layer (the re-attached e0's share, computed once
+                           // per forward: e0 does not change from step to step); then xa / w1T cover the remaining columns only
     const float* P;        // [N, pw] per-node projections: [Pr (he) | Pc (he) | Pf_out (hn) | Pf_in (hn)]
     int pw;
     // pre-transposed, zero-padded weight images WT[k][n] (capital = width rounded up to 32) and biases

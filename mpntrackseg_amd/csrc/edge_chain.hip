@@ -271,6 +271,13 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(h1[t], g, ldrow<EXACT>(pr, 32 * t + 8 * g + 4 * lh, he));
+        if (A.Q0) {  // + the step-invariant share of the layer (hoisted out of the step loop like P0)
+            const float* q0 = A.Q0 + (int64_t)edge * he;
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) add4(h1[t], g, ldrow<EXACT>(q0, 32 * t + 8 * g + 4 * lh, he));
+        }
     }
     // Pc[col] joins H1 after the MFMAs, two tiles (8 row pieces) per gather round; round r is issued one chunk before
     // the phase-2 chunk that consumes tiles 2r, 2r+1 (round 0: in the last phase-1 chunk)

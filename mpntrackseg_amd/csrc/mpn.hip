@@ -218,6 +218,7 @@ struct StepIO {
     float* logits;                        // [E] original order, or nullptr (operator-level call)
     const float* P0;                      // optional: xa's share of the projections (+ biases), precomputed [N, pw];
                                           // then only xb is multiplied here (the weights are shared by all steps)
+    const float* Q0;                      // optional (fused chain): ea's share of the edge MLP's first layer, [E, he]
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -256,6 +257,14 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         a.xb = io.eb; a.ldxb = io.ldeb; a.k1b = io.eb ? d.ke - io.kea : 0;
         a.P = b.P; a.pw = d.pw;
         a.w1T = cw->w1T; a.w2T = cw->w2T; a.b2 = m.edge.bias[1];
+        if (io.Q0 && io.eb) {
+            // ea = the re-attached initial edge features: their product with W1's e0 columns is Q0 (once per forward);
+            // the kernel multiplies the current features only (rows kea.. of the [k][n] weight image)
+            a.Q0 = io.Q0;
+            a.xa = io.eb; a.ldxa = io.ldeb; a.k1a = d.ke - io.kea;
+            a.xb = nullptr; a.ldxb = 0; a.k1b = 0;
+            a.w1T = cw->w1T + (size_t)io.kea * pad32(d.he);
+        }
         a.wc1T = cw->wc1T; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
         a.wf1T_out = cw->wf1T[0]; a.wf1T_in = cw->wf1T[1]; a.wf2T_out = cw->wf2T[0]; a.wf2T_in = cw->wf2T[1];
         a.bf2_out = m.flow_out.bias[1]; a.bf2_in = m.flow_in.bias[1];
@@ -420,6 +429,19 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         G.A = x0; G.lda = d.dn; G.B = p.Wnode; G.ldb = d.kx; G.bias = p.bnode; G.C = p.P0; G.ldc = d.pw; G.m_static = N;
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
+    // the same for the edge side of the fused chain: Q0 = e0 W1[:, e0 columns]^T, [E, he] (64 MB at cfg-B), saves a
+    // quarter of the chain's first-layer MFMAs in every step
+    // (measured: pays from de = 32 up; at the reference's de = 16 the extra C-in loads cost more than the one chunk saved)
+    const bool hoist_e = p.cw.ok && d.ef == 2 && d.L > 1 && E > 0 && d.de >= 32 && (d.ke - d.de) % 16 == 0 && d.de % 16 == 0 &&
+                         !getenv("MPNHIP_NO_Q0");
+    if (hoist_e) {
+        GemmArgs a = {};
+        a.ngroups = 1; a.N = d.he; a.K = d.de; a.ksplit = d.de; a.m_upper = E;
+        GemmGroup& G = a.g[0];
+        init_group(G);
+        G.A = e0; G.lda = d.de; G.B = m.edge.weight[0] + 2 * d.kx; G.ldb = m.edge.in_dim; G.C = p.Q0; G.ldc = d.he; G.m_static = E;
+        MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
+    }
     int prev = 0;
     for (int step = 0; step < d.L; ++step) {
         int cur = save ? step + 1 : 1 + (step & 1);
@@ -435,6 +457,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.x_new = p.x_hist + xs * cur;
         io.logits = logits + (size_t)step * E;
         io.P0 = hoist ? p.P0 : nullptr;
+        io.Q0 = hoist_e ? p.Q0 : nullptr;
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
         prev = cur;
     }

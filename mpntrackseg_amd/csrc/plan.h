@@ -123,6 +123,7 @@ struct FwdPlan {
     float* bnode;  // [pw]
     ChainWeights cw;
     float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
+    float* Q0;     // [E, he] step-invariant share of the edge MLP's first layer: e0 W1[:, e0 columns]^T (fused chain only)
     float* enc_n[2];
     float* enc_e[2];
     float* x_hist;  // [(L+1) or 3][N, dn]   x_hist[0] = encoder output
@@ -167,6 +168,7 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.Wnode = a.f((size_t)d.pw * d.kx);
     p.bnode = a.f((size_t)d.pw);
     p.P0 = a.f((size_t)N * d.pw);
+    p.Q0 = a.f((size_t)E * d.he);
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
         p.cw.w1T = a.f((size_t)d.ke * HE);
