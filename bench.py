@@ -272,7 +272,11 @@ def rooflines(prof, c, args, N, E, chain):
                                                           {128: "10,2,7,4", 64: "5,1,4,2", 32: "3,1,2,1"}.get(d, "?"), E, macs),
                            "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
                            "traffic": pmc_traffic("edge_chain", args.config), "avg_us": gemm_us,
-                           "empty_event_pair_us": empty_us, "launches": gemm_n, "algorithmic_flops": flops}
+                           "empty_event_pair_us": empty_us, "launches": gemm_n, "algorithmic_flops": flops,
+                           # what the reference executes for the same per-edge modules (gathered
+                           # [x_row | x_col | e] and [x_col | e'] inputs multiplied per edge), for comparability
+                           "naive_flop_equivalent_tflops": 2.0 * E * ((4 * dn + 2 * de) * he + he * de + (2 * dn + de) * hn + hn * dn
+                                                                      + de * hc + hc) / (gemm_us * 1e-6) / 1e12}
     elif gemm_n:
         K, Nn = 2 * de, he
         flops = 2.0 * E * K * Nn  # algorithmic: E rows x [e0|e] (2 de) x he outputs
