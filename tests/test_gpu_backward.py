@@ -210,3 +210,19 @@ def test_fused_chain_kernels_d128(agg):
     keep = []
     assert lib.mpnhip_edge_chain_active(model.c_model(keep)) == 1
     check_against_oracle(params, W, g, robust=(agg == "max"))
+
+
+@pytest.mark.parametrize("d,reattach_edges", [(64, True), (64, False), (128, False)])
+def test_fused_chain_other_widths_and_no_edge_reattach(d, reattach_edges):
+    """The 64-d template (tiles 5/1/4/2) and the fused chain WITHOUT re-attached initial edge features (then the
+    first layer has a single input segment and no hoisted Q0 share); forward + gradients against the oracle."""
+    lib = capi.load()
+    gs = [synth.make_graph(n, e, T=6, seed=60 + i, node_in_dim=48) for i, (n, e) in enumerate([(64, 410), (40, 290)])]
+    g = synth.batch_graphs(gs)
+    params = synth.model_params(d, 3, "sum", node_in_dim=48)
+    params["reattach_initial_edges"] = reattach_edges
+    W = synth.make_weights(params, seed=9)
+    model = make_model(params, W)
+    keep = []
+    assert lib.mpnhip_edge_chain_active(model.c_model(keep)) == 1
+    check_against_oracle(params, W, g, robust=False)
