@@ -69,6 +69,9 @@ typedef struct {
     mpnhip_mlp node;      /* MPNet.node_model.node_model: ONE Linear(2dn -> dn) + ReLU (mpn.py:309-310) */
     mpnhip_mlp classifier;/* classifier.edge_model    (mpn.py:238) */
     int precision;        /* MPNHIP_PREC_*: operand precision of the Linear layers' products (inference only) */
+    int weights_prepacked;/* != 0: the head of `workspace` still holds the weight images a previous mpnhip_forward
+                           * (save_for_backward = 0) of THIS model wrote there and no weight has changed since: skip
+                           * re-packing them (about 20 small launches).  The caller vouches for it; 0 is always safe. */
 } mpnhip_model;
 
 const char* mpnhip_version(void);

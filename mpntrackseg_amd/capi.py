@@ -38,7 +38,7 @@ class Model(C.Structure):
         ("dn", C.c_int), ("de", C.c_int), ("reattach_nodes", C.c_int), ("reattach_edges", C.c_int),
         ("agg", C.c_int), ("num_enc_steps", C.c_int),
         ("enc_node", Mlp), ("enc_edge", Mlp), ("edge", Mlp), ("flow_in", Mlp), ("flow_out", Mlp),
-        ("node", Mlp), ("classifier", Mlp), ("precision", C.c_int),
+        ("node", Mlp), ("classifier", Mlp), ("precision", C.c_int), ("weights_prepacked", C.c_int),
     ]
 
 
@@ -145,6 +145,10 @@ def f32c(t):
 
 
 _ws_cache = {}
+# weight images left at the head of a forward workspace: buffer address -> (model id, weight key); see MOTMPNet.hot_path
+_packed_state = {}
+# bumped by every native in-place parameter update (train.FlatAdam writes through raw pointers: no torch version bump)
+_weights_epoch = [0]
 
 
 def workspace(nbytes, device, tag="ws"):
@@ -154,6 +158,7 @@ def workspace(nbytes, device, tag="ws"):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        _packed_state.clear()  # a new buffer (possibly at a recycled address) holds no weight images
     return buf
 
 

@@ -407,8 +407,12 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         ~PrecisionScope() { set_gemm_precision(old); }
     } precision_scope(m.precision);
 
-    MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
-    MPN_TRY(pack_chain_weights(m, d, p.cw, s));
+    if (m.weights_prepacked && !save) {
+        p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace
+    } else {
+        MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
+        MPN_TRY(pack_chain_weights(m, d, p.cw, s));
+    }
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
     float* hid[MPNHIP_MAX_LAYERS];

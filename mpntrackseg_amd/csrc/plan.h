@@ -165,10 +165,10 @@ static inline StepBufs step_at(const FwdPlan& p, int s) {
 static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, int save, void* base, FwdPlan* out) {
     Arena a = {static_cast<char*>(base), 0};
     FwdPlan p = {};
+    // weight images first: their offsets depend on the model's dims only, never on N / E, so a caller that keeps the
+    // workspace can keep them across calls (mpnhip_model.weights_prepacked)
     p.Wnode = a.f((size_t)d.pw * d.kx);
     p.bnode = a.f((size_t)d.pw);
-    p.P0 = a.f((size_t)N * d.pw);
-    p.Q0 = a.f((size_t)E * d.he);
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
         p.cw.w1T = a.f((size_t)d.ke * HE);
@@ -180,6 +180,8 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
         }
         p.cw.ok = false;
     }
+    p.P0 = a.f((size_t)N * d.pw);
+    p.Q0 = a.f((size_t)E * d.he);
     int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
     if (save) {
         // keep every encoder activation for the backward pass: one buffer per hidden layer

@@ -403,9 +403,16 @@ class MOTMPNet(nn.Module):
         e_out = torch.empty((E, m.de), dtype=torch.float32, device=x.device) if return_state else None
         with torch.cuda.device(x.device):
             ws = capi.workspace(lib.mpnhip_forward_workspace_bytes(m, N, E, 0), x.device, "fwd")
+            # the packed weight images at the head of the workspace survive between calls: skip re-packing them while
+            # the buffer, the model and every weight (address, torch version, native-update epoch) are unchanged
+            key = (m.precision, capi._weights_epoch[0]) + tuple((p_.data_ptr(), p_._version) for p_ in self.hot_path_parameters())
+            state = (id(self), key)
+            m.weights_prepacked = 1 if capi._packed_state.get(ws.data_ptr()) == state else 0
+            capi._packed_state.pop(ws.data_ptr(), None)
             capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits),
                                           capi.ptr(x_out), capi.ptr(e_out), capi.ptr(ws), ws.numel(), 0,
                                           capi.stream_ptr()), "mpnhip_forward")
+            capi._packed_state[ws.data_ptr()] = state
         if return_state:
             return logits, x_out, e_out
         return logits

@@ -83,6 +83,7 @@ class FlatAdam:
     def step(self):
         import ctypes as C
         self.t += 1
+        capi._weights_epoch[0] += 1   # raw-pointer update: invalidates packed weight images kept by MOTMPNet.hot_path
         b = self.bucket
         capi.check(capi.load().mpnhip_adam_step(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
                                                 capi.ptr(self.exp_avg_sq), b.flat.numel(), C.c_float(self.lr),

@@ -47,9 +47,10 @@ def test_version_and_sizes_without_gpu(lib):
 def test_struct_layout_matches_c():
     # sizeof(mpnhip_mlp) = 2 ints + 8 ints + 4 * 8 pointers, padded to 8
     assert ctypes.sizeof(capi.Mlp) == 8 + 32 + 4 * 8 * 8
-    # 6 ints, 7 MLPs, the trailing precision int padded to the struct's 8-byte alignment
+    # 6 ints, 7 MLPs, then precision and weights_prepacked (two ints)
     assert ctypes.sizeof(capi.Model) == 24 + 7 * ctypes.sizeof(capi.Mlp) + 8
     assert capi.Model.precision.offset == 24 + 7 * ctypes.sizeof(capi.Mlp)
+    assert capi.Model.weights_prepacked.offset == capi.Model.precision.offset + 4
 
 
 def test_new_entry_points_argument_checks_without_gpu():

@@ -425,3 +425,40 @@ def test_edge_and_node_model_operator_level():
         assert rel_err(e_got.cpu().numpy(), e_ref.numpy()) < 1e-5
         assert rel_err(x_got.cpu().numpy(), x_ref.numpy()) < 1e-5
         assert rel_err(e_fused.cpu().numpy(), e_ref.numpy()) < 1e-5 and rel_err(x_fused.cpu().numpy(), x_ref.numpy()) < 1e-5
+
+
+def test_packed_weights_are_reused_only_while_valid():
+    """MOTMPNet.hot_path keeps the packed weight images in its workspace between inference calls
+    (mpnhip_model.weights_prepacked): same results as a fresh pack, and any weight change -- torch in-place op,
+    load_state_dict, the native Adam step -- makes the next call pack again."""
+    from mpntrackseg_amd.train import TrainStep
+    g = synth.make_graph(200, 1500, seed=31, node_in_dim=64)
+    for d in (32, 128):
+        params = synth.model_params(d, 2, "sum", node_in_dim=64)
+        W = synth.make_weights(params, seed=7)
+        model = make_model(params, W)
+        a, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])           # packs
+        b, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])           # reuses
+        assert np.array_equal(a, b)
+        ws_ptr = capi._ws_cache[(str(dev()), "fwd")].data_ptr()
+        assert capi._packed_state.get(ws_ptr, (None,))[0] == id(model)
+        with torch.no_grad():
+            model.classifier.edge_model.fc_layers[0].weight.mul_(1.5)                 # torch version bump
+        W2 = dict(W)
+        W2["classifier.edge_model.fc_layers.0.weight"] = W["classifier.edge_model.fc_layers.0.weight"] * np.float32(1.5)
+        c, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+        want = torch.stack([l.view(-1) for l in O.forward(params, O.to_tensors(W2), torch.from_numpy(g["x"]),
+                                                          torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"]),
+                                                          return_state=True)[1]]).numpy()
+        assert rel_err(c, want) < 1e-4 and rel_err(c, a) > 1e-3
+        # a native optimizer step writes the weights through raw pointers: the epoch bump must invalidate the images
+        model.train()
+        step = TrainStep(model, lr=1e-2)
+        step(torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["edge_index"]).to(dev()), torch.from_numpy(g["edge_attr"]).to(dev()))
+        model.eval()
+        e1, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+        W3 = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        want3 = torch.stack([l.view(-1) for l in O.forward(params, O.to_tensors(W3), torch.from_numpy(g["x"]),
+                                                           torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"]),
+                                                           return_state=True)[1]]).numpy()
+        assert rel_err(e1, want3) < 1e-4 and rel_err(e1, c) > 1e-6
