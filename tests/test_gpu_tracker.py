@@ -133,3 +133,51 @@ def test_sliding_window_sharded_over_ranks():
     preds, num = acc[0] + acc[2], acc[1] + acc[3]
     both = torch.where(num > 0, preds / num, torch.zeros_like(preds))
     assert float((both - one).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("n,deg,k,seed", [(50, 12, 3, 1), (200, 40, 10, 2), (400, 150, 50, 3), (64, 5, 8, 4)])
+def test_knn_mask_random_graphs_match_oracle(n, deg, k, seed):
+    """get_knn_mask on random symmetric graphs of several densities (k below, near and above the typical degree),
+    reciprocal and union forms, both edge-list conventions, against the dense-matrix restatement of graph.py:40-87."""
+    rng = np.random.default_rng(seed)
+    pairs = set()
+    while len(pairs) < n * deg // 2:
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+            pairs.add((min(i, j), max(i, j)))
+    pr = np.array(sorted(pairs), dtype=np.int64).T
+    d = rng.random(pr.shape[1]).astype(np.float32) + 0.01
+    ei_pairs, d_pairs = torch.from_numpy(pr), torch.from_numpy(d)
+    ei_sym = torch.cat((ei_pairs, torch.stack((ei_pairs[1], ei_pairs[0]))), dim=1)
+    d_sym = torch.cat((d_pairs, d_pairs))
+    # shuffle the symmetric list: the halves need not be aligned for the native lookup
+    p = torch.from_numpy(rng.permutation(ei_sym.shape[1]))
+    ei_sym, d_sym = ei_sym[:, p], d_sym[p]
+    for rec in (False, True):
+        want = T.get_knn_mask(d_pairs, ei_pairs, n, k, rec, symmetric_edges=False)
+        got = G.get_knn_mask(d_pairs.to(dev()), ei_pairs.to(dev()), n, k, reciprocal_k_nns=rec, symmetric_edges=False)
+        assert np.array_equal(got.cpu().numpy(), want.numpy())
+        want = T.get_knn_mask(d_sym, ei_sym, n, k, rec, symmetric_edges=True)
+        got = G.get_knn_mask(d_sym.to(dev()), ei_sym.to(dev()), n, k, reciprocal_k_nns=rec, symmetric_edges=True)
+        assert np.array_equal(got.cpu().numpy(), want.numpy())
+
+
+def test_sliding_window_degenerate_sequences():
+    det, g, params, W = _sequence(frames=6, seed=13)
+    model = _native_model(params, W)
+    args = (model, torch.from_numpy(det["x"]).to(dev()), g["edge_index"].to(dev()), g["edge_attr"].to(dev()),
+            g["reid_emb_dists"].to(dev()), det["frame"])
+    # more frames per window than the sequence has: no window, every edge unpredicted -> 0 (NaN -> 0, mpn_tracker.py:197)
+    out = tracker.evaluate_graph_in_batches(*args, frames_per_graph=10, top_k_nns=5)
+    assert out.shape[0] == g["edge_index"].shape[1] and float(out.abs().max()) == 0.0
+    # one window covering everything == one forward over the kNN-pruned full graph
+    out = tracker.evaluate_graph_in_batches(*args, frames_per_graph=6, top_k_nns=5)
+    keep = G.get_knn_mask(g["reid_emb_dists"].view(-1).to(dev()), g["edge_index"].to(dev()), len(det["frame"]), 5,
+                          reciprocal_k_nns=True, symmetric_edges=True)
+    with torch.no_grad():
+        logits = model.hot_path(args[1], args[2][:, keep].contiguous(), args[3][keep].contiguous())[-1]
+    want = torch.zeros_like(out)
+    want[keep] = torch.sigmoid(logits)
+    assert float((out - want).abs().max()) <= 1e-6
+    # top_k = 0 prunes every edge: nothing is predicted
+    assert float(tracker.evaluate_graph_in_batches(*args, frames_per_graph=3, top_k_nns=0).abs().max()) == 0.0
