@@ -160,6 +160,16 @@ def test_cfgB_mean():
     check_against_oracle(params, synth.make_weights(params, seed=7), g, robust=True)
 
 
+def test_cfgB_sum_default_aggregation():
+    """The shipped default node_agg_fn ('sum', configs/tracking_cfg.yaml:135) at the BASELINE.json configs[1] graph size and
+    widths, 6 steps with down-scaled He weights (12 steps of sum aggregation with unit-gain weights overflow the fp32
+    range of the GRADIENTS in oracle and kernel alike), fwd+bwd against oracle autograd, overall-error criterion."""
+    c = synth.CONFIGS["B"]
+    params = synth.model_params(c["d"], 6, "sum")
+    g = synth.make_graph(c["N"], c["E"], seed=3)
+    check_against_oracle(params, synth.make_weights(params, seed=7, gain=0.6), g, robust=True)
+
+
 def test_linearity_in_upstream_gradient():
     """Size-independent property at full size: backward is linear in grad_logits."""
     c = synth.CONFIGS["B"]
