@@ -94,6 +94,18 @@ __global__ void k_split_cat(const float* __restrict__ src, int64_t rows, int d, 
     }
 }
 
+// out[i] = sum_b src[b * stride + i]   (n4 float4 elements, ascending b: deterministic)
+__global__ void k_sum_blocks(const float* __restrict__ src, int64_t stride, int nb, int64_t n4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = *reinterpret_cast<const float4*>(src + 4 * i);
+    for (int b = 1; b < nb; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)b * stride + 4 * i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * i) = acc;
+}
+
 // dst[i][:] = src[idx[i]][:]
 __global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
                               int64_t rows, int cols) {
@@ -142,6 +154,7 @@ struct BwdPlan {
     float* dE0;                         // [E, de]
     float* dAGG;                        // [N, 2dn]
     float* dCat;                        // [max(E ke, N kx)] gradient w.r.t. the concatenated [initial | current] features
+    float* dPsum;                       // [N, pw] sum over the steps of dP (the re-attached x0's share is one product)
     float* dZn;                         // [L][N, dn]
     float* dP;                          // [L][N, pw]
     float* dZfl[MPNHIP_MAX_LAYERS];     // flow MLP layer i:   [L][E, out_i]
@@ -181,6 +194,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     const size_t L = d.L > 0 ? d.L : 1;
     for (int i = 0; i < 2; ++i) p.dX[i] = a.f((size_t)N * d.dn);
     p.dX0 = a.f((size_t)N * d.dn);
+    p.dPsum = a.f((size_t)N * d.pw);
     p.dE0 = a.f((size_t)E * d.de);
     p.dAGG = a.f((size_t)N * 2 * d.dn);
     {
@@ -526,6 +540,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     auto glo = [&](int g) { return g < 0 ? (int)L : (int)(L - (int64_t)(g + 1) * L / ngroups); };
     int next_group = 0;
     bool forked = false;
+    const bool hoist_x = d.nf == 2 && L > 1 && N > 0 && pw % 4 == 0 && dn % 4 == 0 && !getenv("MPNHIP_NO_DX0_HOIST");
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
@@ -605,12 +620,20 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         // ---- F. per-node projections  P = [x0 | x_{s-1}] Wnode^T -----------------------------------
         {
             float* dXp = p.dX[cx ^ 1];
-            const float* Wa[2] = {f.Wnode, nullptr};
-            MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
-            if (xs) {
-                hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dCat, N, dn, d.nf == 2 ? 1 : 0,
-                                   p.dX0, step == 1 ? p.dX0 : dXp, step == 1 ? 1 : 0);
-                MPN_LAUNCH_CHECK();
+            if (hoist_x) {
+                // only the x_{s-1} columns here (at step 1 x_0 IS x0); the re-attached x0's columns take the SUM of the steps'
+                // dP after the loop: one product instead of L
+                const float* Wa[2] = {f.Wnode + dn, nullptr};
+                MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, dn, step == 1 ? p.dX0 : dXp, dn, nullptr, nullptr, 0, step == 1 ? 1 : 0,
+                                 nullptr, N, s));
+            } else {
+                const float* Wa[2] = {f.Wnode, nullptr};
+                MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
+                if (xs) {
+                    hipLaunchKernelGGL(k_split_cat, dim3((unsigned)((xs + 255) / 256)), dim3(256), 0, s, p.dCat, N, dn, d.nf == 2 ? 1 : 0,
+                                       p.dX0, step == 1 ? p.dX0 : dXp, step == 1 ? 1 : 0);
+                    MPN_LAUNCH_CHECK();
+                }
             }
         }
         cx ^= 1;
@@ -623,6 +646,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         }
     }
 
+    if (hoist_x) {
+        const int64_t n4 = N * pw / 4;
+        hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dP, N * pw, (int)L, n4, p.dPsum);
+        MPN_LAUNCH_CHECK();
+        const float* Wa[2] = {f.Wnode, nullptr};
+        MPN_TRY(act_grad(1, p.dPsum, pw, nullptr, Wa, kx, pw, dn, p.dX0, dn, nullptr, nullptr, 0, 1, nullptr, N, s));
+    }
     if (L > 0) {
         // the last group of steps, after the side stream's groups ("+=" into the same gradients: they come first)
         if (forked) {
