@@ -149,6 +149,7 @@ _ws_cache = {}
 _packed_state = {}
 # bumped by every native in-place parameter update (train.FlatAdam writes through raw pointers: no torch version bump)
 _weights_epoch = [0]
+_model_uid = [0]  # source of MOTMPNet._mpnhip_uid tokens
 
 
 def workspace(nbytes, device, tag="ws"):

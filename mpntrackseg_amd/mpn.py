@@ -406,7 +406,12 @@ class MOTMPNet(nn.Module):
             # the packed weight images at the head of the workspace survive between calls: skip re-packing them while
             # the buffer, the model and every weight (address, torch version, native-update epoch) are unchanged
             key = (m.precision, capi._weights_epoch[0]) + tuple((p_.data_ptr(), p_._version) for p_ in self.hot_path_parameters())
-            state = (id(self), key)
+            # (a token that is never reused: id() of a collected model can come back, together with recycled parameter
+            # addresses and equal version counts, for a model with other weights)
+            if getattr(self, '_mpnhip_uid', None) is None:
+                capi._model_uid[0] += 1
+                self._mpnhip_uid = capi._model_uid[0]
+            state = (self._mpnhip_uid, key)
             m.weights_prepacked = 1 if capi._packed_state.get(ws.data_ptr()) == state else 0
             capi._packed_state.pop(ws.data_ptr(), None)
             capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits),

@@ -441,7 +441,7 @@ def test_packed_weights_are_reused_only_while_valid():
         b, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])           # reuses
         assert np.array_equal(a, b)
         ws_ptr = capi._ws_cache[(str(dev()), "fwd")].data_ptr()
-        assert capi._packed_state.get(ws_ptr, (None,))[0] == id(model)
+        assert capi._packed_state.get(ws_ptr, (None,))[0] == model._mpnhip_uid
         with torch.no_grad():
             model.classifier.edge_model.fc_layers[0].weight.mul_(1.5)                 # torch version bump
         W2 = dict(W)
@@ -462,3 +462,12 @@ def test_packed_weights_are_reused_only_while_valid():
                                                            torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"]),
                                                            return_state=True)[1]]).numpy()
         assert rel_err(e1, want3) < 1e-4 and rel_err(e1, c) > 1e-6
+        # a NEW model object with other weights never inherits the images, whatever addresses its tensors land on
+        del model, step
+        W4 = synth.make_weights(params, seed=8)
+        model = make_model(params, W4)
+        f1, _, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+        want4 = torch.stack([l.view(-1) for l in O.forward(params, O.to_tensors(W4), torch.from_numpy(g["x"]),
+                                                           torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"]),
+                                                           return_state=True)[1]]).numpy()
+        assert rel_err(f1, want4) < 1e-4
