@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="B")
+    ap.add_argument("--graph-file", default=None,
+                    help="a precomputed detection graph (mpntrackseg_amd/graphfile.py .npz, e.g. MOTS20-02) instead of the "
+                         "synthetic one; --config then only selects the model dims and step count")
     ap.add_argument("--agg", default="sum", help="node_agg_fn (reference default: sum, configs/tracking_cfg.yaml:135)")
     ap.add_argument("--mode", default="auto", choices=["auto", "fwd", "train"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
@@ -112,7 +115,14 @@ def main():
     c = synth.CONFIGS[args.config]
     params = synth.model_params(c["d"], c["L"], args.agg)
     W = synth.make_weights(params, seed=7)
-    if c.get("knn"):
+    if args.graph_file:
+        from mpntrackseg_amd import graphfile
+        z = graphfile.load_graph(args.graph_file)
+        g = {k: z[k].numpy() for k in ("x", "edge_index", "edge_attr")}
+        c = dict(c, N=int(g["x"].shape[0]), E=int(g["edge_index"].shape[1]))
+        params = synth.model_params(c["d"], c["L"], args.agg, node_in_dim=int(g["x"].shape[1]), edge_in_dim=int(g["edge_attr"].shape[1]))
+        W = synth.make_weights(params, seed=7)
+    elif c.get("knn"):
         g = synth.make_knn_graph(seed=1 + rank, **c["knn"])
         c = dict(c, E=int(g["edge_index"].shape[1]))
     else:
@@ -200,7 +210,8 @@ def main():
         "metric": "edges/ms (MPN %s) on synthetic tracking graph" % ("forward+backward" if mode == "train" else "forward"),
         "value": value, "unit": "edges/ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate",
+        "data": "synthetic" if not args.graph_file else "graph file %s (random-init weights)" % os.path.basename(args.graph_file),
         "config": {"workload": "cfg-%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, "
                                "%s, one graph per GPU" % (args.config, N, E, c["d"], c["L"], args.agg,
                                                           "training step (fwd+bwd%s)" % ("+RCCL grad all-reduce" if world > 1 else "")

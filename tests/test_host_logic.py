@@ -123,3 +123,24 @@ def test_frame_windows_match_reference_loop():
     assert sorted(wins[0::2] + wins[1::2]) == sorted(wins)
     with pytest.raises(Exception):
         tracker.frame_windows(np.array([2, 1, 3]), 2)
+
+
+def test_graph_file_round_trip(tmp_path):
+    """mpntrackseg_amd.graphfile: save / load of a precomputed detection graph, pooling of 4-D node inputs, validation."""
+    from mpntrackseg_amd import graphfile
+    g = synth.make_graph(40, 200, seed=3, node_in_dim=16)
+    x4 = np.repeat(np.repeat(g["x"][:, :, None, None], 2, axis=2), 3, axis=3) + synth.normal(4, (40, 16, 2, 3)) * 0
+    labels = (np.arange(200) % 5 == 0).astype(np.float32)
+    path = str(tmp_path / "seq.npz")
+    graphfile.save_graph(path, x4, g["edge_index"], g["edge_attr"], edge_labels=labels, frame=np.arange(40) // 4)
+    z = graphfile.load_graph(path)
+    assert z["x"].shape == (40, 16) and np.allclose(z["x"].numpy(), g["x"], atol=1e-6)      # pooled (mpn.py:351-352)
+    assert np.array_equal(z["edge_index"].numpy(), g["edge_index"]) and z["edge_index"].dtype == torch.int64
+    assert np.array_equal(z["edge_labels"].numpy(), labels) and "reid_emb_dists" not in z
+    bad = g["edge_index"].copy()
+    bad[0, 0] = 40
+    with pytest.raises(ValueError):
+        graphfile.save_graph(path, g["x"], bad, g["edge_attr"])
+    np.savez(str(tmp_path / "junk.npz"), a=np.zeros(3))
+    with pytest.raises(ValueError):
+        graphfile.load_graph(str(tmp_path / "junk.npz"))
