@@ -207,7 +207,8 @@ def main():
     value = world * E / ms_per_step
 
     out = {
-        "metric": "edges/ms (MPN %s) on synthetic tracking graph" % ("forward+backward" if mode == "train" else "forward"),
+        "metric": "edges/ms (MPN %s) on %s tracking graph" % ("forward+backward" if mode == "train" else "forward",
+                                                                 "the supplied" if args.graph_file else "synthetic"),
         "value": value, "unit": "edges/ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate",
