@@ -653,25 +653,33 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         const float* Wa[2] = {f.Wnode, nullptr};
         MPN_TRY(act_grad(1, p.dPsum, pw, nullptr, Wa, kx, pw, dn, p.dX0, dn, nullptr, nullptr, 0, 1, nullptr, N, s));
     }
-    if (L > 0) {
-        // the last group of steps, after the side stream's groups ("+=" into the same gradients: they come first)
-        if (forked) {
-            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
-            MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));
+    auto unpack_node_grads = [&]() -> int {
+        // the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] back into the layers' grads (their biases were handled above)
+        struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
+            {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
+            {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
+            {m.flow_out.grad_weight[0], m.flow_out.in_dim, 0, 2 * he, hn},
+            {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
+        for (auto& q : parts) {
+            int64_t tot = (int64_t)q.rows * kx;
+            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.gWnode + (size_t)q.r0 * kx,
+                               kx, q.dst, q.ld, q.c0, q.rows, kx);
+            MPN_LAUNCH_CHECK();
         }
-        MPN_TRY(mp_weight_grads(0, glo(ngroups - 2 < 0 ? -1 : ngroups - 2), s, p.slab));
-        {   // unpack the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] (their biases were handled above)
-            struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
-                {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
-                {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
-                {m.flow_out.grad_weight[0], m.flow_out.in_dim, 0, 2 * he, hn},
-                {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
-            for (auto& q : parts) {
-                int64_t tot = (int64_t)q.rows * kx;
-                hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.gWnode + (size_t)q.r0 * kx,
-                                   kx, q.dst, q.ld, q.c0, q.rows, kx);
-                MPN_LAUNCH_CHECK();
-            }
+        return MPNHIP_OK;
+    };
+    if (L > 0) {
+        // the last group of steps.  With a side stream it goes there as well (in order behind the earlier groups) and
+        // runs under the encoder's backward below, which touches none of its buffers; the join is at the very end.
+        const int last_n = glo(ngroups - 2 < 0 ? -1 : ngroups - 2);
+        if (forked) {
+            MPN_HIP(hipEventRecord(g_side.ready, s));
+            MPN_HIP(hipStreamWaitEvent(g_side.stream, g_side.ready, 0));
+            MPN_TRY(mp_weight_grads(0, last_n, g_side.stream, p.slab_side));
+            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
+        } else {
+            MPN_TRY(mp_weight_grads(0, last_n, s, p.slab));
+            MPN_TRY(unpack_node_grads());
         }
     } else {
         // mpn.py:387-389: only the classifier sits between the encoder output and the logits
@@ -752,6 +760,10 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
                                  ee.in_dim, g.perm, nullptr, 0, 0, nullptr, E, s));
             }
         }
+    }
+    if (L > 0 && forked) {  // join: every "+=" of the side stream's groups is in; then the unpacking, on the caller's stream
+        MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));
+        MPN_TRY(unpack_node_grads());
     }
     return MPNHIP_OK;
 }
