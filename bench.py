@@ -181,7 +181,7 @@ def main():
         step()
     profiled = rank == 0 and not args.no_roofline
     if profiled:
-        lib.mpnhip_profile_enable(1)  # HIP events around the dominant GEMM and the aggregation kernel, in-stream
+        lib.mpnhip_profile_enable(6)  # HIP events attached to every 6th launch of the dominant kernel and of the aggregation kernel
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -265,7 +265,7 @@ int mpnhip_average_preds(const float* overall_preds, const float* overall_num, i
  * message-passing step with HIP events on the launch stream.  mpnhip_profile_read synchronises, returns
  * the average duration (us) and launch count of each since the last read, and resets the counters.
  * The empty-pair cost applies to the default (NULL) stream the calibration pairs are recorded on. */
-int mpnhip_profile_enable(int on);
+int mpnhip_profile_enable(int on);   /* 0 = off, 1 = time every launch of the two kernels, n > 1 = every n-th launch */
 /* 1 when mpnhip_forward evaluates the per-edge chain (edge MLP + classifier + flow MLPs) of this model with the
  * fused edge_chain kernel (then THAT kernel is the one bracketed as "gemm" by the profile hooks), else 0. */
 int mpnhip_edge_chain_active(const mpnhip_model* model);

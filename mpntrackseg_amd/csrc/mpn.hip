@@ -39,11 +39,14 @@ struct ProfState {
     int open_kind = -1;
     bool taken = false;
     hipStream_t stream = nullptr;
+    int stride = 1;        // time every stride-th launch of each kind
+    int seen[2] = {0, 0};
 } g_prof;
 }  // namespace
 
 void prof_begin(int kind, hipStream_t s) {
     if (!g_prof.on || g_prof.n[kind] >= PROF_MAX - 64) return;
+    if (g_prof.seen[kind]++ % g_prof.stride != 0) return;  // sampled: the attached events are not free (~0.5 us each)
     if (!g_prof.made[kind]) {
         for (int i = 0; i < PROF_MAX; ++i) {
             (void)hipEventCreate(&g_prof.ev[kind][i][0]);
@@ -590,6 +593,8 @@ extern "C" int mpnhip_edge_chain_active(const mpnhip_model* model) {
 
 extern "C" int mpnhip_profile_enable(int on) {
     g_prof.on = on != 0;
+    g_prof.stride = on > 1 ? on : 1;
+    g_prof.seen[0] = g_prof.seen[1] = 0;
     g_prof.n[0] = g_prof.n[1] = 0;
     g_prof.open_kind = -1;
     return MPNHIP_OK;
