@@ -534,10 +534,47 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     // CUs idle for the last third of their run at cfg-B); only the last group runs after the loop.  Groups are issued
     // to ONE side stream in order, so they can share its slab buffer and their "+=" into the gradients stay ordered.
     const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready() == MPNHIP_OK;
-    static const int groups_wanted = [] { const char* e = getenv("MPNHIP_WGRAD_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 2 ? v : 3; }();
-    const int ngroups = !want_fork ? 1 : (L >= 2 * groups_wanted ? groups_wanted : 2);
-    // group g (g = 0 is finished first) covers batches [glo(g), glo(g - 1)): the top L / ngroups steps, and so on
-    auto glo = [&](int g) { return g < 0 ? (int)L : (int)(L - (int64_t)(g + 1) * L / ngroups); };
+    // Group sizes (in steps, first-finished group first).  The side stream is serial, so the last group should be the
+    // smallest: it starts only when the loop is over and what it has not finished when the encoder's backward ends is
+    // exposed.  Default for L = 12: 5 + 4 + 3; in general three groups with sizes ~ (5 : 4 : 3), two below six steps.
+    int gsize[8] = {0};
+    int ngroups = 1;
+    if (want_fork) {
+        static const char* spec = getenv("MPNHIP_WGRAD_SPLIT");  // tuning override, e.g. "4,4,4"
+        int parsed = 0, total = 0;
+        if (spec) {
+            const char* q = spec;
+            while (*q && parsed < 8) {
+                gsize[parsed] = atoi(q);
+                total += gsize[parsed] > 0 ? gsize[parsed] : 0;
+                ++parsed;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+        bool ok = parsed >= 2 && total == (int)L;
+        for (int i = 0; i < parsed; ++i) ok = ok && gsize[i] > 0;
+        if (ok) {
+            ngroups = parsed;
+        } else if (L >= 6) {
+            ngroups = 3;
+            gsize[0] = (int)((5 * L + 6) / 12);
+            gsize[2] = (int)(L / 4);
+            gsize[1] = (int)L - gsize[0] - gsize[2];
+        } else {
+            ngroups = 2;
+            gsize[0] = (int)(L - L / 2);
+            gsize[1] = (int)(L / 2);
+        }
+    } else {
+        gsize[0] = (int)L;
+    }
+    // group g (g = 0 is finished first) covers batches [glo(g), glo(g - 1))
+    auto glo = [&](int g) {
+        int lo = (int)L;
+        for (int i = 0; i <= g && i < ngroups; ++i) lo -= gsize[i];
+        return g < 0 ? (int)L : lo;
+    };
     int next_group = 0;
     bool forked = false;
     const bool hoist_x = d.nf == 2 && L > 1 && N > 0 && pw % 4 == 0 && dn % 4 == 0 && !getenv("MPNHIP_NO_DX0_HOIST");
