@@ -155,7 +155,8 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 
 // total_rows (optional hint): rows summed over all segments; long average segments use a block-per-segment kernel
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
-                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows = 0);
+                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows = 0, int runs = 1,
+                        int run_stride = 0);
 
 // in-stream event timing of two designated kernels (see mpnhip_profile_enable)
 enum { PROF_GEMM = 0, PROF_AGG = 1 };

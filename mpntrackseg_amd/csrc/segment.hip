@@ -30,6 +30,8 @@ struct SegArgs {
     int nmod;         // segment s -> out row s % nmod, column offset (s / nmod == 0 ? off0 : off1)
     int off0, off1;
     int sub;          // lanes per work item (power of two <= 64)
+    int runs, run_stride;  // runs > 1 (sum only, no list): segment s is the union of the runs [ptr[s + r * run_stride],
+                      // ptr[s + r * run_stride + 1]), r < runs -- e.g. a node's rows of all three directions of the (dir,row) CSR
     int nblk;         // column blocks per segment: work item = (segment, block of sub * VEC columns); 0 / 1 = one item per segment
 };
 
@@ -81,22 +83,26 @@ __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
         V acc;
         vset(acc, is_max ? -INFINITY : 0.f);
         int arg_s[4] = {-1, -1, -1, -1};
-        for (int j = beg; j < end; j += 8) {
-            // eight rows in flight: clamped (unconditional) index and row loads, predicated accumulation
-            V v[8];
-            int id[8];
+        const int nruns = a.runs > 1 ? a.runs : 1;
+        for (int r = 0; r < nruns; ++r) {
+            const int rbeg = r == 0 ? beg : a.ptr[s + r * a.run_stride], rend = r == 0 ? end : a.ptr[s + r * a.run_stride + 1];
+            for (int j = rbeg; j < rend; j += 8) {
+                // eight rows in flight: clamped (unconditional) index and row loads, predicated accumulation
+                V v[8];
+                int id[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int jj = j + u < end ? j + u : end - 1;
-                id[u] = a.list ? a.list[jj] : jj;
-            }
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = j + u < rend ? j + u : rend - 1;
+                    id[u] = a.list ? a.list[jj] : jj;
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
+                for (int u = 0; u < 8; ++u) v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (j + u < end) {
-                    if (is_max) vmax(acc, arg_s, v[u], id[u]);
-                    else vadd(acc, v[u]);
+                for (int u = 0; u < 8; ++u) {
+                    if (j + u < rend) {
+                        if (is_max) vmax(acc, arg_s, v[u], id[u]);
+                        else vadd(acc, v[u]);
+                    }
                 }
             }
         }
@@ -333,7 +339,7 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 
 // segments [0, nmod) go to column offset off0, segments [nmod, 2 nmod) to off1 of out row (s % nmod)
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
-                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows) {
+                        int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows, int runs, int run_stride) {
     SegArgs a = {};
     a.src = src;
     a.lds = lds;
@@ -347,7 +353,9 @@ int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const in
     a.nmod = nmod > 0 ? nmod : 1;
     a.off0 = off0;
     a.off1 = off1;
-    if (try_launch_block(a, total_rows, stream)) {
+    a.runs = runs;
+    a.run_stride = run_stride;
+    if (runs <= 1 && try_launch_block(a, total_rows, stream)) {
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
     }
