@@ -236,3 +236,19 @@ def test_fused_chain_other_widths_and_no_edge_reattach(d, reattach_edges):
     keep = []
     assert lib.mpnhip_edge_chain_active(model.c_model(keep)) == 1
     check_against_oracle(params, W, g, robust=False)
+
+
+def test_backward_is_bitwise_reproducible():
+    """Two runs of the same training step give bit-identical gradients: the weight-gradient groups on the side stream,
+    the slab sums and every scatter-add have a fixed summation order (no float atomics), and no buffer is read before the
+    stream that writes it has been joined."""
+    c = synth.CONFIGS["B"]
+    params = synth.model_params(c["d"], 6, "sum")
+    g = synth.make_graph(2000, 20000, seed=4)
+    model = make_model(params, synth.make_weights(params, seed=7, gain=0.6))
+    r = synth.normal(3, (6, 20000))
+    runs = [native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r) for _ in range(3)]
+    for lg, gx, gea, pg in runs[1:]:
+        assert np.array_equal(lg, runs[0][0]) and np.array_equal(gx, runs[0][1]) and np.array_equal(gea, runs[0][2])
+        for k in pg:
+            assert np.array_equal(pg[k], runs[0][3][k]), k
