@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel breakdown of ONE training step from a rocprofv3 kernel trace (steps delimited by Adam kernels)."""
+"""Per-kernel breakdown of ONE training step from a rocprofv3 kernel trace (steps delimited by the optimizer kernel)."""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'multi_tensor' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'multi_tensor' in r['Kernel_Name'] or 'k_adam' in r['Kernel_Name']]
 groups = []
 for i in idx:
     if not groups or i - groups[-1][-1] > 1: groups.append([i])
