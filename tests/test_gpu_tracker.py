@@ -181,3 +181,26 @@ def test_sliding_window_degenerate_sequences():
     assert float((out - want).abs().max()) <= 1e-6
     # top_k = 0 prunes every edge: nothing is predicted
     assert float(tracker.evaluate_graph_in_batches(*args, frames_per_graph=3, top_k_nns=0).abs().max()) == 0.0
+
+
+def test_graph_build_more_shapes():
+    """Pair enumeration on a larger unsorted frame vector, distances for embedding widths off the vector path, one-edge and
+    duplicate-edge kNN inputs."""
+    d0 = dev()
+    rng = np.random.default_rng(7)
+    f = torch.from_numpy(rng.integers(0, 40, 1500))
+    for mfd in (0, 1, 7, 'max'):
+        want = T.get_time_valid_conn_ixs(f, mfd)
+        got = G.get_time_valid_conn_ixs(f.to(d0), mfd)
+        assert np.array_equal(got.cpu().numpy(), want.numpy()), mfd
+    ei = T.get_time_valid_conn_ixs(f[:200], 3)
+    for dim in (1, 3, 30, 257):
+        emb = torch.from_numpy(rng.standard_normal((200, dim)).astype(np.float32))
+        want = T.pairwise_distance(emb, ei).view(-1)
+        got = G.pairwise_distance(emb.to(d0), ei.to(d0))
+        assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6), dim
+    # one edge; top_k larger than any degree keeps everything
+    one = torch.tensor([[0], [1]], dtype=torch.int64)
+    assert bool(G.get_knn_mask(torch.tensor([0.5]).to(d0), one.to(d0), 2, 1, reciprocal_k_nns=True, symmetric_edges=False)[0])
+    big = G.get_knn_mask(torch.rand(ei.shape[1]).to(d0), ei.to(d0), 200, 10 ** 6, reciprocal_k_nns=True, symmetric_edges=False)
+    assert bool(big.all())
