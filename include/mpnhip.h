@@ -93,6 +93,11 @@ size_t mpnhip_graph_bytes(int n_nodes, int64_t n_edges);
 size_t mpnhip_graph_prep_workspace_bytes(int n_nodes, int64_t n_edges);
 int mpnhip_graph_prep(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf, size_t graph_bytes,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The primary (direction, row) order only -- all that mpnhip_forward / mpnhip_meta_layer_forward / the forward of
+ * mpnhip_attention_aggregate read (a quarter of the sorting work; sliding-window inference prepares a graph per window).
+ * mpnhip_backward, mpnhip_attention_aggregate_backward and mpnhip_step_metrics need mpnhip_graph_prep. */
+int mpnhip_graph_prep_forward(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf, size_t graph_bytes,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronising debug helper: host copy of {error_flag, E_flow_out, E_flow_in, E_self}. */
 int mpnhip_graph_status(const void* graph_buf, int n_nodes, int64_t n_edges, int32_t status[4], void* stream);
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mpnhip_graph_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep_workspace_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep": (_I, [_P, _I, _L, _P, _Z, _P, _Z, _P]),
+    "mpnhip_graph_prep_forward": (_I, [_P, _I, _L, _P, _Z, _P, _Z, _P]),
     "mpnhip_graph_status": (_I, [_P, _I, _L, C.POINTER(C.c_int32), _P]),
     "mpnhip_forward_workspace_bytes": (_Z, [C.POINTER(Model), _I, _L, _I]),
     "mpnhip_forward": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
@@ -183,7 +184,9 @@ def fill_mlp(dst, linears, with_grads=False, keep=None):
 class PreparedGraph:
     """Device-side sort of an edge_index (see ``mpnhip_graph_prep``)."""
 
-    def __init__(self, edge_index, n_nodes, validate=False):
+    def __init__(self, edge_index, n_nodes, validate=False, full=True):
+        """``full=False``: the primary order only (inference forward); anything that differentiates or evaluates the step
+        metrics needs ``full=True`` (``self.full`` records which one this is)."""
         require_device(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise MpnhipError("edge_index must be int64 [2, E] (reference data/mot_graph.py:312)")
@@ -192,13 +195,15 @@ class PreparedGraph:
         self.N = int(n_nodes)
         self.E = int(ei.shape[1])
         self.device = ei.device
+        self.full = bool(full)
         nb = lib.mpnhip_graph_bytes(self.N, self.E)
         self.buf = torch.empty(max(nb, 256), dtype=torch.uint8, device=ei.device)
         wsb = lib.mpnhip_graph_prep_workspace_bytes(self.N, self.E)
         ws = workspace(wsb, ei.device, "prep")
         with torch.cuda.device(ei.device):
-            check(lib.mpnhip_graph_prep(ptr(ei), self.N, self.E, ptr(self.buf), self.buf.numel(), ptr(ws), ws.numel(),
-                                        stream_ptr()), "mpnhip_graph_prep")
+            fn = lib.mpnhip_graph_prep if full else lib.mpnhip_graph_prep_forward
+            check(fn(ptr(ei), self.N, self.E, ptr(self.buf), self.buf.numel(), ptr(ws), ws.numel(), stream_ptr()),
+                  "mpnhip_graph_prep")
         if validate:
             st = self.status()
             if st[0] != 0:

@@ -131,8 +131,21 @@ extern "C" size_t mpnhip_graph_prep_workspace_bytes(int n_nodes, int64_t n_edges
     return 3 * align_up(e * 4, 256) + align_up(sort_temp_bytes(n_edges), 256) + 256;
 }
 
+static int graph_prep_impl(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf, size_t graph_bytes,
+                           void* workspace, size_t workspace_bytes, bool secondary, void* stream_);
+
 extern "C" int mpnhip_graph_prep(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf,
                                  size_t graph_bytes, void* workspace, size_t workspace_bytes, void* stream_) {
+    return graph_prep_impl(edge_index, n_nodes, n_edges, graph_buf, graph_bytes, workspace, workspace_bytes, true, stream_);
+}
+
+extern "C" int mpnhip_graph_prep_forward(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf,
+                                         size_t graph_bytes, void* workspace, size_t workspace_bytes, void* stream_) {
+    return graph_prep_impl(edge_index, n_nodes, n_edges, graph_buf, graph_bytes, workspace, workspace_bytes, false, stream_);
+}
+
+static int graph_prep_impl(const int64_t* edge_index, int n_nodes, int64_t n_edges, void* graph_buf, size_t graph_bytes,
+                           void* workspace, size_t workspace_bytes, bool secondary, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int N = n_nodes;
     const int64_t E = n_edges;
@@ -179,6 +192,7 @@ extern "C" int mpnhip_graph_prep(const int64_t* edge_index, int n_nodes, int64_t
     hipLaunchKernelGGL(k_header, dim3(1), dim3(64), 0, stream, g.seg_ptr, N, E, g.header);
     MPN_LAUNCH_CHECK();
 
+    if (!secondary) return MPNHIP_OK;  // inference: mpnhip_forward reads the primary order only
     // secondary orders for the backward scatter-adds (index_put_ of x[row], x[col])
     struct { int mode; int* perm; int* ptr; int nkeys; } sec[3] = {
         {0, g.cperm, g.cseg_ptr, 3 * N}, {1, g.rperm, g.rseg_ptr, N}, {2, g.cperm_all, g.cseg_all, N}};

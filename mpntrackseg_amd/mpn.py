@@ -16,14 +16,15 @@ from .cnn import CNN, MaskRCNNPredictor
 from .mlp import MLP
 
 
-def _prepared(edge_index, n_nodes, holder=None):
+def _prepared(edge_index, n_nodes, holder=None, full=True):
     """Graph prep (``mpnhip_graph_prep``) cached on the object that owns edge_index (the reference's
-    ``Graph`` sample), validated by tensor identity and version counter."""
+    ``Graph`` sample), validated by tensor identity and version counter.  ``full=False`` (inference forward) accepts
+    or builds a prep with the primary order only; a cached forward-only prep is replaced when a full one is asked for."""
     if holder is not None:
         c = getattr(holder, "_mpnhip_prep", None)
-        if c is not None and c[0] is edge_index and c[1] == edge_index._version and c[2].N == n_nodes:
+        if c is not None and c[0] is edge_index and c[1] == edge_index._version and c[2].N == n_nodes and (c[2].full or not full):
             return c[2]
-    g = capi.PreparedGraph(edge_index, n_nodes)
+    g = capi.PreparedGraph(edge_index, n_nodes, full=full)
     if holder is not None:
         try:
             object.__setattr__(holder, "_mpnhip_prep", (edge_index, edge_index._version, g))
@@ -396,7 +397,7 @@ class MOTMPNet(nn.Module):
         if x.dim() != 2 or x.shape[1] != m.enc_node.in_dim or ea.dim() != 2 or ea.shape[1] != m.enc_edge.in_dim:
             raise capi.MpnhipError("input feature widths do not match the encoder (node %s, edge %s)"
                                    % (tuple(x.shape), tuple(ea.shape)))
-        g = _prepared(edge_index, N, holder)
+        g = _prepared(edge_index, N, holder, full=False)   # inference: the primary order is all mpnhip_forward reads
         L = max(int(self.num_enc_steps), 1)
         logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
         x_out = torch.empty((N, m.dn), dtype=torch.float32, device=x.device) if return_state else None
