@@ -6,6 +6,7 @@ namespace mpnhip {
 
 struct EdgeChainArgs {
     int E;                 // edges (sorted order)
+    int split;             // 1: weight images are three-piece bf16 split images (pack_split), products from six bf16 MFMAs
     int he, de, hn, dn, hc;  // real widths; the kernel pads them to multiples of 32 (zero-padded weight images)
     const int* header;     // graph header: [1] = E_out, [2] = E_in
     const int* srow;
@@ -91,6 +92,9 @@ static inline size_t chain_mask_ints(int64_t E, int he, int de, int hn, int dn) 
 }
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
+// Split image of the logical operand A[k][n] = src[k * sk + n * sn] (zero beyond K x N), padded to Kp x Np (multiples of
+// 16 / 32): Kp Np 6 bytes at dst, in the unit order edge_chain.hip documents.
+int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s);
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s);
 int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
                 int dst_c0, hipStream_t s);

@@ -50,7 +50,7 @@ namespace {
 #define TS_WHERE() do {} while (0)
 #endif
 
-constexpr int CH_FLOATS = 5120;  // floats per weight chunk buffer (20 KB)
+constexpr int CH_FLOATS = 7680;  // floats per weight chunk buffer (20 KB fp32 images, 30 KB split images)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -61,12 +61,20 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // __syncthreads() carries.  Every load is unconditional (source index clamped into the chunk; surplus lanes land in
 // the unused tail of the 20 KB buffer) and sizes are compile-time constants wherever the schedule is static: a load
 // behind a branch makes the compiler's s_waitcnt bookkeeping conservative.
-template <int Q>
+template <int Q, bool EXACT_UNITS = false>
 __device__ __forceinline__ void chunk_fetch(const float* src, int n4, int tid, float* buf) {
-    static_assert(Q >= 1 && Q <= 5, "chunk larger than the largest buffer");
+    static_assert(Q >= 1 && Q <= 8, "chunk larger than the largest buffer");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
+        if (EXACT_UNITS) {
+            // split images: chunks are whole 1 KiB units = whole wave instructions; a wave skips the pieces past the end
+            // (wave-uniform), so the buffer needs no tail
+            if (256 * q + 64 * wave < n4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (tid + 256 * q)),
+                                                 (__attribute__((address_space(3))) void*)(buf + 4 * (256 * q + 64 * wave)), 16, 0, 0);
+            continue;
+        }
         int f = tid + 256 * q;
         f = f < n4 ? f : n4 - 1;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * f),
@@ -125,6 +133,84 @@ __device__ __forceinline__ void apply_mask(f32x16& a, unsigned word, int shift) 
         const int keep = __builtin_amdgcn_sbfe(word, shift + r, 1);
         const float x = a[r];  // (bit_cast straight on the vector element reads element 0: clang 19 / ROCm 7.2)
         a[r] = __int_as_float(__float_as_int(x) & keep);
+    }
+}
+
+// ---- split operands (EdgeChainArgs.split): every fp32 operand x is the exact sum of three bfloat16 pieces
+//   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round to nearest even; residuals are exact in fp32)
+// and a product a b is accumulated (fp32) from the six piece products of relative weight >= 2^-16:
+//   a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h ;   the dropped a_m b_l + a_l b_m + a_l b_l < 2^-24 |a b|,
+// i.e. below fp32 rounding: the same accuracy class as the fp32 MFMA (measured against float64: tools/gemm_bench.py
+// --check, tests/test_gpu_parity.py), at 6 x 32 instead of 8 x 64 MFMA cycles per 16 contraction steps
+// (v_mfma_f32_32x32x16_bf16 against v_mfma_f32_32x32x2_f32).
+// Weight images: units of 1 KiB = one MFMA A operand (64 lanes x 8 bf16), [k block of 16][n tile of 32][piece]; element i
+// of lane (m, g) holds W[n0 + m][k0 + (i & 3) + 8 (i >> 2) + 4 g] -- the contraction order of the accumulator layout, so
+// that registers 8c .. 8c+7 of an activation tile ARE the B operand of k block c.  A [K][N] image takes K N 6 bytes,
+// 3/2 of the fp32 image: the chunk schedule is the fp32 one with every offset and size scaled by 3/2.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split8 { bf16x8 p[3]; };
+
+__device__ __forceinline__ Split8 split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    const float x[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+    Split8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const __bf16 h0 = (__bf16)x[i], h1 = (__bf16)x[i + 1];
+        const float a0 = x[i] - (float)h0, a1 = x[i + 1] - (float)h1;
+        const __bf16 m0 = (__bf16)a0, m1 = (__bf16)a1;
+        const __bf16 l0 = (__bf16)(a0 - (float)m0), l1 = (__bf16)(a1 - (float)m1);
+        o.p[0][i] = h0; o.p[0][i + 1] = h1;
+        o.p[1][i] = m0; o.p[1][i + 1] = m1;
+        o.p[2][i] = l0; o.p[2][i + 1] = l1;
+    }
+    return o;
+}
+__device__ __forceinline__ Split8 split_regs(const f32x16& s, int r0) {
+    return r0 == 0 ? split8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]) : split8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// The three pieces of one unit.  Inline assembly on purpose: a compiler-visible ds_read_b128 of the object the LDS-DMA
+// writes into is preceded by s_waitcnt vmcnt(0) (the next chunk's DMA would be drained in front of every operand
+// fetch); the waits for these reads are placed by hand (lds_wait: LDS operations of a wave complete in order).
+__device__ __forceinline__ void lds_read3(unsigned addr, bf16x8 (&a)[3]) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8 (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
+}
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const Split8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[0], acc, 0, 0, 0);
+}
+
+// Split counterpart of chain_tile / chain_half: NKB k blocks (registers 8 c0 .. of `src`) against the units
+// [kb0 + c][t0 + t] of the chunk image at LDS address wsaddr (+ lane * 16 already added), NTR tiles per k block.
+// One step = one unit: the next unit's three reads go out before this unit's six MFMAs.
+template <int TOUT, int NKB>
+__device__ __forceinline__ void chain_units(const f32x16& src, int c0, f32x16* out, unsigned wsaddr, int ntr, int kb0, int t0) {
+    bf16x8 a[2][3];
+    auto unit = [&](int st) { return wsaddr + (unsigned)((((kb0 + st / TOUT) * ntr + t0 + st % TOUT) * 3) << 10); };
+    lds_read3(unit(0), a[0]);
+    Split8 b = split_regs(src, 8 * c0);
+#pragma unroll
+    for (int st = 0; st < NKB * TOUT; ++st) {
+        if (st + 1 < NKB * TOUT) {
+            lds_read3(unit(st + 1), a[(st + 1) & 1]);
+            lds_wait<3>(a[st & 1]);
+        } else {
+            lds_wait<0>(a[st & 1]);
+        }
+        if (NKB == 2 && st == TOUT) b = split_regs(src, 8);
+        mfma6(out[st % TOUT], a[st & 1], b);
     }
 }
 
@@ -187,7 +273,7 @@ __device__ __forceinline__ void chain_half(const f32x16& src, int r0, f32x16* ou
 // (weight-image pitches, loop bounds); A.he / A.de / ... = real widths (global row strides, load / store masks).
 constexpr int chain_waves(int t1) { return t1 <= 3 ? 3 : 2; }  // waves per SIMD the register budget allows
 
-template <int T1, int T2, int TF, int TD, bool EXACT>
+template <int T1, int T2, int TF, int TD, bool EXACT, bool SP>
 __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeChainArgs A) {
     constexpr int HE = 32 * T1, DE = 32 * T2, HN = 32 * TF, DN = 32 * TD, HC = 32;
     constexpr int KC1 = 16;                       // phase-1 chunk: [16 k][HE]
@@ -199,13 +285,15 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     constexpr int NCH2 = (HE + KC2 - 1) / KC2;
     constexpr int NCH4 = (HN + NC4 - 1) / NC4;
     constexpr int NCH5 = HN / KC5;
-    constexpr int N4_1 = KC1 * HE / 4;                       // phase 1: 16 rows of W1T
-    constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4;           // phase 2, first chunk
-    constexpr int N4_3 = DE * HC / 4;                        // classifier layer 0, whole
-    constexpr int N4_4_0 = DE * cmin(NC4, HN) / 4;           // phase 4, first column block
-    constexpr int N4_5 = KC5 * DN / 4;                       // phase 5: 32 rows of Wf2T
-    // chunk buffer: whole 1 KiB DMA pieces of the largest chunk
-    constexpr int CHF = 1024 * chunk_q(cmax(cmax(N4_1, N4_2_0), cmax(cmax(N4_3, N4_4_0), N4_5)));
+    constexpr int SCN = SP ? 3 : 2;                          // image size in halves of the fp32 image's (split images: 3/2)
+    constexpr int N4_1 = KC1 * HE / 4 * SCN / 2;             // phase 1: 16 rows of W1T
+    constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4 * SCN / 2; // phase 2, first chunk
+    constexpr int N4_3 = DE * HC / 4 * SCN / 2;              // classifier layer 0, whole
+    constexpr int N4_4_0 = DE * cmin(NC4, HN) / 4 * SCN / 2; // phase 4, first column block
+    constexpr int N4_5 = KC5 * DN / 4 * SCN / 2;             // phase 5: 32 rows of Wf2T
+    constexpr int N4_MAX = cmax(cmax(N4_1, N4_2_0), cmax(cmax(N4_3, N4_4_0), N4_5));
+    // chunk buffer: whole 1 KiB DMA pieces of the largest chunk (split images: exactly the largest chunk)
+    constexpr int CHF = SP ? 4 * N4_MAX : 1024 * chunk_q(N4_MAX);
     static_assert(CHF <= CH_FLOATS, "chunk too large");
     // ReLU-mask words per lane for the backward kernel (edge_chain.h: chain_mask_words)
     constexpr int W_H1 = 0, W_E = W_H1 + (T1 + 1) / 2, W_HC = W_E + (T2 + 1) / 2, W_HF = W_HC + 1, W_M = W_HF + (TF + 1) / 2,
@@ -250,7 +338,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     TS_INIT();
     TS(0);
     TS_WHERE();
-    chunk_fetch<chunk_q(N4_1)>(A.w1T, N4_1, tid, wbuf_at(0));
+    chunk_fetch<chunk_q(N4_1), SP>(A.w1T, N4_1, tid, wbuf_at(0));
     {
         // biases -> LDS (ordinary loads; drained with chunk 0 by the first barrier)
         const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
@@ -323,7 +411,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         // One phase-1 chunk (16 contraction rows).  `last`: the chunk also carries the first Pc gather round.
         auto p1_chunk = [&](int i, bool last1) {
             // next chunk: the following 16 rows of W1T, or the first chunk of phase 2
-            const float* nsrc = last1 ? A.w2T : A.w1T + (int64_t)(i + 1) * KC1 * HE;
+            const float* nsrc = last1 ? A.w2T : A.w1T + (int64_t)(i + 1) * (KC1 * HE * SCN / 2);
             const int nn4 = last1 ? N4_2_0 : N4_1;
             // (read this chunk's inputs BEFORE the DMAs go out: hipcc drains vmcnt in front of a plain ds_read_b128 that
             // follows an LDS-DMA into the same object)
@@ -332,27 +420,45 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
             for (int u = 0; u < 2; ++u)
                 xcur[u] = *reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_FLOATS + (wave * 2 + u) * 256 + lane * 4);
             __builtin_amdgcn_sched_barrier(0);
-            chunk_fetch<chunk_q(cmax(N4_1, N4_2_0))>(nsrc, nn4, tid, wbuf_at(c + 1));
+            chunk_fetch<chunk_q(cmax(N4_1, N4_2_0)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
             if (last1) pc_issue(0);
             else xfetch((i + 1) * KC1, c + 1);
-            const float* ws = wbuf_at(c) + 4 * lh * HE + lj;
-            // 8 steps (u, q) of T1 MFMAs each; the weights of step s+1 are fetched before the MFMAs of step s
-            float a[2][T1];
+            if constexpr (SP) {
+                // one k block: the lane's 8 inputs (k = 4h + 0..3, 8 + 4h + 0..3) are the B operand as they are
+                const Split8 xb8 = split8(xcur[0].x, xcur[0].y, xcur[0].z, xcur[0].w, xcur[1].x, xcur[1].y, xcur[1].z, xcur[1].w);
+                const unsigned wa = lds_addr(wbuf_at(c)) + lane * 16;
+                bf16x8 wv[2][3];
+                lds_read3(wa, wv[0]);
 #pragma unroll
-            for (int t = 0; t < T1; ++t) a[0][t] = ws[32 * t];
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int u = st >> 2, q = st & 3;
-                if (st + 1 < 8) {
-                    const int u1 = (st + 1) >> 2, q1 = (st + 1) & 3;
-#pragma unroll
-                    for (int t = 0; t < T1; ++t) a[(st + 1) & 1][t] = ws[(8 * u1 + q1) * HE + 32 * t];
+                for (int t = 0; t < T1; ++t) {
+                    if (t + 1 < T1) {
+                        lds_read3(wa + (unsigned)(((t + 1) * 3) << 10), wv[(t + 1) & 1]);
+                        lds_wait<3>(wv[t & 1]);
+                    } else {
+                        lds_wait<0>(wv[t & 1]);
+                    }
+                    mfma6(h1[t], wv[t & 1], xb8);
                 }
-                const float xv = q == 0 ? xcur[u].x : (q == 1 ? xcur[u].y : (q == 2 ? xcur[u].z : xcur[u].w));
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                const float* ws = wbuf_at(c) + 4 * lh * HE + lj;
+                // 8 steps (u, q) of T1 MFMAs each; the weights of step s+1 are fetched before the MFMAs of step s
+                float a[2][T1];
 #pragma unroll
-                for (int t = 0; t < T1; ++t) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][t], xv, h1[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < T1; ++t) a[0][t] = ws[32 * t];
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    const int u = st >> 2, q = st & 3;
+                    if (st + 1 < 8) {
+                        const int u1 = (st + 1) >> 2, q1 = (st + 1) & 3;
+#pragma unroll
+                        for (int t = 0; t < T1; ++t) a[(st + 1) & 1][t] = ws[(8 * u1 + q1) * HE + 32 * t];
+                    }
+                    const float xv = q == 0 ? xcur[u].x : (q == 1 ? xcur[u].y : (q == 2 ? xcur[u].z : xcur[u].w));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < T1; ++t) h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][t], xv, h1[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __syncthreads();
             ++c;
@@ -385,18 +491,24 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         // next: rows 64 (i + 1) .. of W2T, or the classifier image
         const bool more = i + 1 < NCH2;
         const int rows_n = more ? (HE - (i + 1) * KC2 < KC2 ? HE - (i + 1) * KC2 : KC2) : 0;  // folds: i is unrolled
-        const float* nsrc = more ? A.w2T + (i + 1) * KC2 * DE : A.wc1T;
-        const int nn4 = more ? rows_n * DE / 4 : N4_3;
+        const float* nsrc = more ? A.w2T + (i + 1) * (KC2 * DE * SCN / 2) : A.wc1T;
+        const int nn4 = more ? rows_n * DE / 4 * SCN / 2 : N4_3;
         __builtin_amdgcn_sched_barrier(0);
-        chunk_fetch<chunk_q(cmax(N4_2_0, N4_3))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        chunk_fetch<chunk_q(cmax(N4_2_0, N4_3)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
         if (more) pc_issue(i + 1);
         if (i >= 1) {
             if (2 * (i - 1) < TF) pf_issue(2 * (i - 1));
             if (2 * (i - 1) + 1 < TF) pf_issue(2 * (i - 1) + 1);
         }
         const float* ws = wbuf_at(c);
-        chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
-        if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
+        if constexpr (SP) {
+            const unsigned wa = lds_addr(ws) + lane * 16;
+            chain_units<T2, 2>(h1[2 * i], 0, en, wa, T2, 0, 0);
+            if (2 * i + 1 < T1) chain_units<T2, 2>(h1[2 * i + 1], 0, en, wa, T2, 2, 0);
+        } else {
+            chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
+            if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
+        }
         __syncthreads();
         ++c;
     }
@@ -423,11 +535,14 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         f32x16 hcv;
 #pragma unroll
         for (int g = 0; g < 4; ++g) set4(hcv, g, *reinterpret_cast<const float4*>(sbias + DE + 8 * g + 4 * lh));
-        chunk_fetch<chunk_q(N4_4_0)>(wf1, N4_4_0, tid, wbuf_at(c + 1));  // (self-loop blocks fetch it too and never use it)
+        chunk_fetch<chunk_q(N4_4_0), SP>(wf1, N4_4_0, tid, wbuf_at(c + 1));  // (self-loop blocks fetch it too and never use it)
         {
             const float* ws = wbuf_at(c);
 #pragma unroll
-            for (int t = 0; t < T2; ++t) chain_tile<1>(en[t], &hcv, ws, HC, 32 * t, 0, 4 * lh * HC + lj);
+            for (int t = 0; t < T2; ++t) {
+                if constexpr (SP) chain_units<1, 2>(en[t], 0, &hcv, lds_addr(ws) + lane * 16, 1, 2 * t, 0);
+                else chain_tile<1>(en[t], &hcv, ws, HC, 32 * t, 0, 4 * lh * HC + lj);
+            }
         }
         __syncthreads();
         ++c;
@@ -460,16 +575,21 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     for (int i = 0; i < NCH4; ++i) {
         const bool more = i + 1 < NCH4;
         const int ncw_n = more ? ((HN - (i + 1) * NC4) < NC4 ? (HN - (i + 1) * NC4) : NC4) : 0;
-        const float* nsrc = more ? wf1 + DE * NC4 * (i + 1) : wf2;
-        const int nn4 = more ? DE * ncw_n / 4 : N4_5;
-        chunk_fetch<chunk_q(cmax(N4_4_0, N4_5))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        const float* nsrc = more ? wf1 + (DE * NC4 * SCN / 2) * (i + 1) : wf2;
+        const int nn4 = more ? DE * ncw_n / 4 * SCN / 2 : N4_5;
+        chunk_fetch<chunk_q(cmax(N4_4_0, N4_5)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
         const float* ws = wbuf_at(c);
         constexpr int full = NC4 / 32;
         const int ncw = (HN - i * NC4) < NC4 ? (HN - i * NC4) : NC4;  // compile-time per unrolled i
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
-            if (ncw == NC4) chain_tile<full>(en[t], &hf[i * full], ws, NC4, 32 * t, 0, 4 * lh * NC4 + lj);
-            else chain_tile<1>(en[t], &hf[i * full], ws, 32, 32 * t, 0, 4 * lh * 32 + lj);
+            if constexpr (SP) {
+                if (ncw == NC4) chain_units<full, 2>(en[t], 0, &hf[i * full], lds_addr(ws) + lane * 16, full, 2 * t, 0);
+                else chain_units<1, 2>(en[t], 0, &hf[i * full], lds_addr(ws) + lane * 16, 1, 2 * t, 0);
+            } else {
+                if (ncw == NC4) chain_tile<full>(en[t], &hf[i * full], ws, NC4, 32 * t, 0, 4 * lh * NC4 + lj);
+                else chain_tile<1>(en[t], &hf[i * full], ws, 32, 32 * t, 0, 4 * lh * 32 + lj);
+            }
         }
         __syncthreads();
         ++c;
@@ -499,9 +619,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         for (int g = 0; g < 4; ++g) set4(mm[t], g, *reinterpret_cast<const float4*>(sbias + DE + 64 + 32 * t + 8 * g + 4 * lh));
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
-        if (i + 1 < NCH5) chunk_fetch<chunk_q(N4_5)>(wf2 + (i + 1) * KC5 * DN, N4_5, tid, wbuf_at(c + 1));  // static: i is unrolled
+        if (i + 1 < NCH5) chunk_fetch<chunk_q(N4_5), SP>(wf2 + (i + 1) * (KC5 * DN * SCN / 2), N4_5, tid, wbuf_at(c + 1));  // static: i is unrolled
         const float* ws = wbuf_at(c);
-        chain_tile<TD>(hf[i], mm, ws, DN, 0, 0, 4 * lh * DN + lj);
+        if constexpr (SP) chain_units<TD, 2>(hf[i], 0, mm, lds_addr(ws) + lane * 16, TD, 0, 0);
+        else chain_tile<TD>(hf[i], mm, ws, DN, 0, 0, 4 * lh * DN + lj);
         if (i + 1 < NCH5) {
             __syncthreads();
             ++c;
@@ -850,6 +971,37 @@ __global__ void k_transpose_padded(const float* __restrict__ W, int64_t ldw, int
     WT[i] = (k < k_cols && n < n_rows) ? W[(int64_t)n * ldw + k0 + k] : 0.f;
 }
 
+// Split image (see the comment at split8): thread = one element of one unit; writes its three pieces.
+__global__ void k_pack_split(const float* __restrict__ src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np,
+                             unsigned short* __restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ntr = Np / 32;
+    if (idx >= (int64_t)(Kp / 16) * ntr * 512) return;
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const int64_t unit = idx >> 9;
+    const int t = (int)(unit % ntr), kb = (int)(unit / ntr);
+    const int k = 16 * kb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), n = 32 * t + (lane & 31);
+    const float x = (k < K && n < N) ? src[k * sk + n * sn] : 0.f;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    unsigned short* o = dst + unit * 3 * 512 + lane * 8 + i;
+    o[0] = __builtin_bit_cast(unsigned short, h);
+    o[512] = __builtin_bit_cast(unsigned short, m);
+    o[1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s) {
+    const int64_t n = (int64_t)(Kp / 16) * (Np / 32) * 512;
+    if (n <= 0) return MPNHIP_OK;
+    if (Kp % 16 != 0 || Np % 32 != 0) { set_error("pack_split: padded sizes must be multiples of 16 x 32"); return MPNHIP_ERR_ARG; }
+    hipLaunchKernelGGL(k_pack_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sk, sn, K, N, Kp, Np,
+                       reinterpret_cast<unsigned short*>(dst));
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s) {
     const int64_t n = (int64_t)n_pad * k_pad;
     if (n <= 0) return MPNHIP_OK;
@@ -922,13 +1074,23 @@ int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
-            if (exact)
-                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), s, a);
+            if (a.split && exact)
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, true, true>), dim3(blocks), dim3(256), s, a);
+            else if (a.split)
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, false, true>), dim3(blocks), dim3(256), s, a);
+            else if (exact)
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, true, false>), dim3(blocks), dim3(256), s, a);
             else
-                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_kernel<10, 2, 7, 4, false, false>), dim3(blocks), dim3(256), s, a);
             break;
-        case 64: MPN_LAUNCH_PROFILED((edge_chain_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), s, a); break;
-        case 32: MPN_LAUNCH_PROFILED((edge_chain_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), s, a); break;
+        case 64:
+            if (a.split) MPN_LAUNCH_PROFILED((edge_chain_kernel<5, 1, 4, 2, false, true>), dim3(blocks), dim3(256), s, a);
+            else MPN_LAUNCH_PROFILED((edge_chain_kernel<5, 1, 4, 2, false, false>), dim3(blocks), dim3(256), s, a);
+            break;
+        case 32:
+            if (a.split) MPN_LAUNCH_PROFILED((edge_chain_kernel<3, 1, 2, 1, false, true>), dim3(blocks), dim3(256), s, a);
+            else MPN_LAUNCH_PROFILED((edge_chain_kernel<3, 1, 2, 1, false, false>), dim3(blocks), dim3(256), s, a);
+            break;
         default: set_error("edge_chain: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
 #ifdef MPNHIP_CHAIN_TS

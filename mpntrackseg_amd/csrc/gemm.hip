@@ -54,15 +54,27 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v) {
     return v;
 }
 
+// x = h + m + l with every piece a bfloat16 (RNE): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m).  The residuals are
+// exact in fp32 and the pieces carry 8 + 8 + 8 significant bits, so the three-term sum reproduces a finite fp32 x exactly
+// (up to bf16 underflow of l).  5.5 VALU operations per element (v_cvt_pk_bf16_f32 converts two at a time).
+__device__ __forceinline__ void split3(float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    h = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    const float r0 = v.x - (float)h[0], r1 = v.y - (float)h[1], r2 = v.z - (float)h[2], r3 = v.w - (float)h[3];
+    m = bf16x4{(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+    l = bf16x4{(__bf16)(r0 - (float)m[0]), (__bf16)(r1 - (float)m[1]), (__bf16)(r2 - (float)m[2]), (__bf16)(r3 - (float)m[3])};
+}
+
 // waves per SIMD the register allocation must leave room for (accumulators: 16 TN registers)
 constexpr int min_waves(int tn) { return tn <= 2 ? 4 : (tn <= 4 ? 3 : 2); }
 
 // BF16: same loader / epilogue; the LDS images are row-major bf16 [m][k], [n][k] (k contiguous: the fp32 rows are
 // rounded and written without a transpose) and every MFMA operand is one ds_read_b128 of 8 consecutive k.
-template <int WM, int WN, int TN, int BLAY, bool BF16 = false>
+template <int WM, int WN, int TN, int BLAY, int PREC = 0>
 __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs args) {
     static_assert(WM * WN == 4, "4 waves");
-    static_assert(!BF16 || BLAY == B_KCONTIG, "bf16 operands: nn.Linear weights only");
+    constexpr bool BF16 = PREC == 1, SPLIT = PREC == 2, LOWP = PREC != 0;
+    constexpr int NIMG = SPLIT ? 3 : 1;                        // bf16 images per operand
+    static_assert(!LOWP || BLAY == B_KCONTIG, "bf16 operands: nn.Linear weights only");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int PA = BM + 1;                                 // pitch % 8 == 1 (transposing stores)
@@ -70,14 +82,14 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
     constexpr int A_F4 = BM / 32;                              // float4 loads per thread and K step
     constexpr int B_F4 = BN / 32;
     constexpr int PATCH = 32 * 36;                             // per-wave epilogue patch [32][36]
-    constexpr int TILE_FLOATS = BF16 ? (BM + BN) * PKB / 2 : BK * (PA + PB);
+    constexpr int TILE_FLOATS = LOWP ? NIMG * (BM + BN) * PKB / 2 : BK * (PA + PB);
     constexpr int SMEM_FLOATS = TILE_FLOATS > 4 * PATCH ? TILE_FLOATS : 4 * PATCH;
 
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * PA;
-    __bf16* const Ab = reinterpret_cast<__bf16*>(smem);   // BF16: [BM][PKB], then [BN][PKB]
-    __bf16* const Bb = Ab + BM * PKB;
+    __bf16* const Ab = reinterpret_cast<__bf16*>(smem);   // BF16 / SPLIT: NIMG x [BM][PKB], then NIMG x [BN][PKB]
+    __bf16* const Bb = Ab + NIMG * BM * PKB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,6 +184,27 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
 
     auto store_tile = [&](int kt) {
         const bool k_ok = kt * BK + ld_k4 < K;   // K % 4 == 0: a float4 is entirely in or out
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) {
+                bf16x4 h, m, l;
+                split3(keep4(k_ok, a_reg[j]), h, m, l);
+                __bf16* d = Ab + (ld_r + 32 * j) * PKB + ld_k4;
+                *reinterpret_cast<bf16x4*>(d) = h;
+                *reinterpret_cast<bf16x4*>(d + BM * PKB) = m;
+                *reinterpret_cast<bf16x4*>(d + 2 * BM * PKB) = l;
+            }
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) {
+                bf16x4 h, m, l;
+                split3(keep4(k_ok, b_reg[j]), h, m, l);
+                __bf16* d = Bb + (ld_r + 32 * j) * PKB + ld_k4;
+                *reinterpret_cast<bf16x4*>(d) = h;
+                *reinterpret_cast<bf16x4*>(d + BN * PKB) = m;
+                *reinterpret_cast<bf16x4*>(d + 2 * BN * PKB) = l;
+            }
+            return;
+        }
         if (BF16) {
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) {
@@ -227,6 +260,33 @@ __global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs 
         store_tile(kt);
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        if (SPLIT) {
+            // x = h + m + l exactly representable pieces (split3); the six products of weight >= 2^-16 relative to
+            // h_a h_b, smallest first, accumulate in fp32: the dropped ones (m l, l m, l l) are below 2^-24 |a b|
+            const __bf16* ap = Ab + (wm * 32 + li) * PKB + lh * 8;
+            const __bf16* bp = Bb + (wn * 32 * TN + li) * PKB + lh * 8;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 av[3], bv[3][TN];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    av[q] = *reinterpret_cast<const bf16x8*>(ap + q * BM * PKB + kb * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[q][j] = *reinterpret_cast<const bf16x8*>(bp + q * BN * PKB + 32 * j * PKB + kb * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0][j], acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         if (BF16) {
             // two 16-deep k blocks per K step; lane (i, h) supplies k = 8h .. 8h+7 of its row
             const __bf16* ap = Ab + (wm * 32 + li) * PKB + lh * 8;
@@ -391,8 +451,12 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * TN * WN;
     int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
     dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
-    if (bl == B_KCONTIG && g_precision == 1)
-        MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, true>), grid, dim3(NTHREADS), s, a);
+    int prec = g_precision;
+    if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);
+    if (bl == B_KCONTIG && prec == 2)
+        MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, 2>), grid, dim3(NTHREADS), s, a);
+    else if (bl == B_KCONTIG && prec == 1)
+        MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, 1>), grid, dim3(NTHREADS), s, a);
     else if (bl == B_KCONTIG)
         MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG>), grid, dim3(NTHREADS), s, a);
     else

@@ -193,10 +193,27 @@ static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights
     if (!cw.ok) return MPNHIP_OK;
     const int HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
     const int hc = m.classifier.out_dims[0];
+    const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
+    cw.split = chain_split(m);
+    if (cw.split) {
+        // the same logical images WT[k][n] = W[n][k0 + k] as below, as split images (3/2 the size, offsets scale alike)
+        MPN_TRY(pack_split(m.edge.weight[0] + 2 * d.kx, 1, m.edge.in_dim, d.ke, d.he, d.ke, HE, cw.w1T, s));
+        MPN_TRY(pack_split(m.edge.weight[1], 1, d.he, d.he, d.de, HE, DE, cw.w2T, s));
+        MPN_TRY(pack_split(m.classifier.weight[0], 1, d.de, d.de, hc, DE, 32, cw.wc1T, s));
+        for (int q = 0; q < 2; ++q) {
+            for (int n0 = 0; n0 < HN; n0 += 64) {
+                const int ncw = HN - n0 < 64 ? HN - n0 : 64;
+                const int rows = d.hn - n0 < 0 ? 0 : (d.hn - n0 < ncw ? d.hn - n0 : ncw);
+                MPN_TRY(pack_split(fl[q]->weight[0] + (int64_t)n0 * fl[q]->in_dim + d.kx, 1, fl[q]->in_dim, d.de, rows, DE, ncw,
+                                   cw.wf1T[q] + (int64_t)DE * n0 * 3 / 2, s));
+            }
+            MPN_TRY(pack_split(fl[q]->weight[1], 1, d.hn, d.hn, d.dn, HN, DN, cw.wf2T[q], s));
+        }
+        return MPNHIP_OK;
+    }
     MPN_TRY(transpose_padded(m.edge.weight[0], m.edge.in_dim, 2 * d.kx, d.he, d.ke, cw.w1T, HE, d.ke, s));
     MPN_TRY(transpose_padded(m.edge.weight[1], d.he, 0, d.de, d.he, cw.w2T, DE, HE, s));
     MPN_TRY(transpose_padded(m.classifier.weight[0], d.de, 0, hc, d.de, cw.wc1T, 32, DE, s));
-    const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
     for (int q = 0; q < 2; ++q) {
         // flow layer 0, e'-part: one image [DE][<= 64] per block of 64 output features (the kernel streams whole blocks)
         for (int n0 = 0; n0 < HN; n0 += 64) {
@@ -254,7 +271,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     if (chain) {
         // (2)-(4) fused: edge MLP, classifier and both flow MLPs in one kernel (edge_chain.hip)
         EdgeChainArgs a = {};
-        a.E = (int)E; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm;
+        a.E = (int)E; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm; a.split = cw->split ? 1 : 0;
         a.he = d.he; a.de = d.de; a.hn = d.hn; a.dn = d.dn; a.hc = m.classifier.out_dims[0];
         a.xa = io.ea; a.ldxa = io.ldea; a.k1a = io.eb ? io.kea : d.ke;
         a.xb = io.eb; a.ldxb = io.ldeb; a.k1b = io.eb ? d.ke - io.kea : 0;
@@ -266,7 +283,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
             a.Q0 = io.Q0;
             a.xa = io.eb; a.ldxa = io.ldeb; a.k1a = d.ke - io.kea;
             a.xb = nullptr; a.ldxb = 0; a.k1b = 0;
-            a.w1T = cw->w1T + (size_t)io.kea * pad32(d.he);
+            a.w1T = cw->w1T + (size_t)io.kea * pad32(d.he) * (cw->split ? 3 : 2) / 2;
         }
         a.wc1T = cw->wc1T; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
         a.wf1T_out = cw->wf1T[0]; a.wf1T_in = cw->wf1T[1]; a.wf2T_out = cw->wf2T[0]; a.wf2T_in = cw->wf2T[1];
@@ -412,6 +429,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
 
     if (m.weights_prepacked && !save) {
         p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace
+        p.cw.split = chain_split(m);
     } else {
         MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
         MPN_TRY(pack_chain_weights(m, d, p.cw, s));

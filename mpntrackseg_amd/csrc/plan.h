@@ -116,6 +116,7 @@ struct ChainWeights {
     float* wf1T[2];   // [P(de)][P(hn)]  (0: flow_out, 1: flow_in)
     float* wf2T[2];   // [P(hn)][P(dn)]
     bool ok;          // the model's shapes are covered by the fused kernel
+    bool split;       // the images are three-piece bf16 split images (edge_chain.hip), 3/2 the size, same logical layout
 };
 
 struct FwdPlan {
@@ -171,12 +172,14 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.bnode = a.f((size_t)d.pw);
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
-        p.cw.w1T = a.f((size_t)d.ke * HE);
-        p.cw.w2T = a.f(HE * DE);
-        p.cw.wc1T = a.f(DE * 32);
+        // (sized for the split images, 3/2 of the fp32 ones: ChainWeights.split)
+        const size_t KE = (size_t)(d.ke + 15) / 16 * 16;
+        p.cw.w1T = a.f(KE * HE * 3 / 2);
+        p.cw.w2T = a.f(HE * DE * 3 / 2);
+        p.cw.wc1T = a.f(DE * 32 * 3 / 2);
         for (int q = 0; q < 2; ++q) {
-            p.cw.wf1T[q] = a.f(DE * HN);
-            p.cw.wf2T[q] = a.f(HN * DN);
+            p.cw.wf1T[q] = a.f(DE * HN * 3 / 2);
+            p.cw.wf2T[q] = a.f(HN * DN * 3 / 2);
         }
         p.cw.ok = false;
     }
@@ -227,6 +230,13 @@ static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
     if (m.precision != MPNHIP_PREC_FP32) return false;  // the fused chain kernels are fp32-operand kernels
     return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
            edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
+}
+
+// split (three-piece bf16) weight images and six-product MFMAs in the fused chain kernels: tuning switch for now
+static inline bool chain_split(const mpnhip_model& m) {
+    (void)m;
+    const char* e = getenv("MPNHIP_CHAIN_SPLIT");
+    return e && e[0] == '1';
 }
 
 static inline void init_group(GemmGroup& g) { memset(&g, 0, sizeof(g)); }

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--shapes", nargs="*")
+    ap.add_argument("--check", action="store_true", help="also print the max error against a float64 product")
     a = ap.parse_args()
     shapes = CFG_B
     if a.shapes:
@@ -33,7 +34,12 @@ def main():
         capi.check(lib.mpnhip_time_linear(capi.ptr(x), capi.ptr(w), capi.ptr(b), capi.ptr(y), M, N, K, a.iters,
                                           ctypes.byref(us), capi.stream_ptr()), "time_linear")
         fl = 2.0 * M * N * K
-        print("%6d x %4d x %4d  %-24s %8.1f us  %6.1f TFLOP/s" % (M, N, K, what, us.value, fl / us.value / 1e6))
+        err = ""
+        if a.check:
+            ref = torch.relu(x[:4096].double() @ w.double().t())
+            err = "  max|err| %.3e (fp32 eps * max|y| = %.3e)" % ((y[:4096].double() - ref).abs().max().item(),
+                                                                 2.0 ** -24 * ref.abs().max().item())
+        print("%6d x %4d x %4d  %-24s %8.1f us  %6.1f TFLOP/s%s" % (M, N, K, what, us.value, fl / us.value / 1e6, err))
         tot += us.value
     print("sum %.1f us" % tot)
 
