@@ -211,10 +211,11 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
-        for (int q = 0; q < 2; ++q) { p.wf2p[q] = a.f(DN * HN); p.wfep[q] = a.f(HN * DE); }
-        p.wc1p = a.f(32 * DE);
-        p.w2p = a.f(DE * HE);
-        p.w1ep = a.f(HE * 2 * DE);
+        // (sized for the split images, 3/2 of the fp32 ones)
+        for (int q = 0; q < 2; ++q) { p.wf2p[q] = a.f(DN * HN * 3 / 2); p.wfep[q] = a.f(HN * DE * 3 / 2); }
+        p.wc1p = a.f(32 * DE * 3 / 2);
+        p.w2p = a.f(DE * HE * 3 / 2);
+        p.w1ep = a.f(HE * 2 * DE * 3 / 2);
     }
     p.gWnode = a.f((size_t)d.pw * d.kx);
     size_t sl = 0;
@@ -433,23 +434,39 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
     const bool use_chain = chain_shapes_ok(m, d) && E > 0 && L > 0 && !getenv("MPNHIP_NO_CHAIN_BWD");
+    const bool bwd_split = use_chain && chain_split(m);
     if (use_chain) {
         const int HE = pad32(he), DE = pad32(de), HN = pad32(hn), DN = pad32(dn);
         const int KEp = d.ef * DE;
         const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
-        for (int q = 0; q < 2; ++q) {
-            MPN_TRY(pack_padded(fl[q]->weight[1], hn, 0, dn, hn, p.wf2p[q], DN, HN, HN, 0, s));
-            MPN_TRY(pack_padded(fl[q]->weight[0], fl[q]->in_dim, kx, hn, de, p.wfep[q], HN, DE, DE, 0, s));
-        }
-        MPN_TRY(pack_padded(m.classifier.weight[0], de, 0, m.classifier.out_dims[0], de, p.wc1p, 32, DE, DE, 0, s));
-        MPN_TRY(pack_padded(m.edge.weight[1], he, 0, de, he, p.w2p, DE, HE, HE, 0, s));
-        // e-part columns of edge layer 0 as one image [HE][ncol6] per pass of <= 64 (padded) columns of [e0 | e_{s-1}]
-        // (the kernel streams whole rows of one pass image)
         const int ncol6 = KEp < 64 ? KEp : 64;
-        for (int hlf = 0; hlf < d.ef; ++hlf) {
-            const int col0 = hlf * DE;
-            MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de,
-                                p.w1ep + (int64_t)(col0 / 64) * HE * ncol6, HE, DE, ncol6, col0 % 64, s));
+        if (bwd_split) {
+            // the same logical images (rows = contraction index n, columns = k) as split images (edge_chain.hip, split8)
+            for (int q = 0; q < 2; ++q) {
+                MPN_TRY(pack_split(fl[q]->weight[1], hn, 1, dn, hn, DN, HN, p.wf2p[q], s));
+                MPN_TRY(pack_split(fl[q]->weight[0] + kx, fl[q]->in_dim, 1, hn, de, HN, DE, p.wfep[q], s));
+            }
+            MPN_TRY(pack_split(m.classifier.weight[0], de, 1, m.classifier.out_dims[0], de, 32, DE, p.wc1p, s));
+            MPN_TRY(pack_split(m.edge.weight[1], he, 1, de, he, DE, HE, p.w2p, s));
+            for (int hlf = 0; hlf < d.ef; ++hlf) {
+                const int col0 = hlf * DE;
+                MPN_TRY(pack_split(m.edge.weight[0] + 2 * kx + hlf * de, m.edge.in_dim, 1, he, de, HE, DE,
+                                   p.w1ep + (int64_t)(col0 / 64) * HE * ncol6 * 3 / 2, s, ncol6 / 32, (col0 % 64) / 32));
+            }
+        } else {
+            for (int q = 0; q < 2; ++q) {
+                MPN_TRY(pack_padded(fl[q]->weight[1], hn, 0, dn, hn, p.wf2p[q], DN, HN, HN, 0, s));
+                MPN_TRY(pack_padded(fl[q]->weight[0], fl[q]->in_dim, kx, hn, de, p.wfep[q], HN, DE, DE, 0, s));
+            }
+            MPN_TRY(pack_padded(m.classifier.weight[0], de, 0, m.classifier.out_dims[0], de, p.wc1p, 32, DE, DE, 0, s));
+            MPN_TRY(pack_padded(m.edge.weight[1], he, 0, de, he, p.w2p, DE, HE, HE, 0, s));
+            // e-part columns of edge layer 0 as one image [HE][ncol6] per pass of <= 64 (padded) columns of [e0 | e_{s-1}]
+            // (the kernel streams whole rows of one pass image)
+            for (int hlf = 0; hlf < d.ef; ++hlf) {
+                const int col0 = hlf * DE;
+                MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de,
+                                    p.w1ep + (int64_t)(col0 / 64) * HE * ncol6, HE, DE, ncol6, col0 % 64, s));
+            }
         }
     }
 
@@ -604,7 +621,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         if (use_chain) {
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
             EdgeChainBwdArgs a = {};
-            a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0;
+            a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0; a.split = bwd_split ? 1 : 0;
             a.he = he; a.de = de; a.hn = hn; a.dn = dn; a.hc = cls.out_dims[0];
             a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
             a.dAGG = p.dAGG; a.mask = reinterpret_cast<const unsigned*>(b.MK); a.ARG = b.ARG;

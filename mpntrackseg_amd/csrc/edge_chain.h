@@ -51,6 +51,7 @@ struct EdgeChainArgs {
 // products of the per-edge modules, with the saved activations as ReLU masks.
 struct EdgeChainBwdArgs {
     int E, N, agg, first_step, cat_two;
+    int split;             // 1: the weight images are split images (pack_split)
     int he, de, hn, dn, hc;  // real widths
     const int* header;
     const int* srow;
@@ -93,8 +94,10 @@ static inline size_t chain_mask_ints(int64_t E, int he, int de, int hn, int dn) 
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
 // Split image of the logical operand A[k][n] = src[k * sk + n * sn] (zero beyond K x N), padded to Kp x Np (multiples of
-// 16 / 32): Kp Np 6 bytes at dst, in the unit order edge_chain.hip documents.
-int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s);
+// 16 / 32): Kp Np 6 bytes at dst, in the unit order edge_chain.hip documents.  ntr_image / t0: the Np / 32 column tiles are
+// tiles t0 .. of an image with ntr_image tiles per k block (default: the whole image).
+int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s,
+               int ntr_image = 0, int t0 = 0);
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s);
 int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
                 int dst_c0, hipStream_t s);

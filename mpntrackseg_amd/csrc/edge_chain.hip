@@ -100,6 +100,21 @@ __device__ __forceinline__ void strow(float* row, int n, int dim, float4 v, bool
     if (ok && (EXACT || n < dim)) *reinterpret_cast<float4*>(row + n) = v;
 }
 
+// the same through a (scalar) base pointer and a 32-bit element offset: one address register per row instead of two
+template <bool EXACT>
+__device__ __forceinline__ float4 ldrow(const float* base, unsigned off, int n, int dim) {
+    // (base + zext(off)) + n: scalar base, 32-bit register offset, n in the instruction's immediate field
+    if (EXACT) return ldg4(base + (size_t)off + n);
+    const bool ok = n < dim;
+    float4 v = ldg4(base + (size_t)off + (ok ? n : 0));
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+template <bool EXACT>
+__device__ __forceinline__ void strow(float* base, unsigned off, int n, int dim, float4 v, bool ok) {
+    if (ok && (EXACT || n < dim)) *reinterpret_cast<float4*>(base + (size_t)off + n) = v;
+}
+
 __device__ __forceinline__ void relu16(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
@@ -195,10 +210,24 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const S
 // Split counterpart of chain_tile / chain_half: NKB k blocks (registers 8 c0 .. of `src`) against the units
 // [kb0 + c][t0 + t] of the chunk image at LDS address wsaddr (+ lane * 16 already added), NTR tiles per k block.
 // One step = one unit: the next unit's three reads go out before this unit's six MFMAs.
-template <int TOUT, int NKB>
+template <int TOUT, int NKB, bool PIPE = true>
 __device__ __forceinline__ void chain_units(const f32x16& src, int c0, f32x16* out, unsigned wsaddr, int ntr, int kb0, int t0) {
-    bf16x8 a[2][3];
     auto unit = [&](int st) { return wsaddr + (unsigned)((((kb0 + st / TOUT) * ntr + t0 + st % TOUT) * 3) << 10); };
+    if (!PIPE) {
+        // register-starved phases: one operand set, fetched just before its MFMAs (the SIMD's other wave covers the LDS latency)
+        Split8 b = split_regs(src, 8 * c0);
+#pragma unroll
+        for (int st = 0; st < NKB * TOUT; ++st) {
+            bf16x8 a[3];
+            lds_read3(unit(st), a);
+            if (NKB == 2 && st == TOUT) b = split_regs(src, 8);
+            lds_wait<0>(a);
+            mfma6(out[st % TOUT], a, b);
+            __builtin_amdgcn_sched_barrier(0);  // (keeps the next unit's fetch behind these MFMAs: one operand set live)
+        }
+        return;
+    }
+    bf16x8 a[2][3];
     lds_read3(unit(0), a[0]);
     Split8 b = split_regs(src, 8 * c0);
 #pragma unroll
@@ -285,6 +314,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     constexpr int NCH2 = (HE + KC2 - 1) / KC2;
     constexpr int NCH4 = (HN + NC4 - 1) / NC4;
     constexpr int NCH5 = HN / KC5;
+    constexpr bool P2PIPE = T1 < 10;                         // phase 2 of the widest variant has no registers for a second operand set
     constexpr int SCN = SP ? 3 : 2;                          // image size in halves of the fp32 image's (split images: 3/2)
     constexpr int N4_1 = KC1 * HE / 4 * SCN / 2;             // phase 1: 16 rows of W1T
     constexpr int N4_2_0 = cmin(KC2, HE) * DE / 4 * SCN / 2; // phase 2, first chunk
@@ -329,7 +359,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const int K1 = A.k1a + A.k1b;                 // columns of [e0 | e] (multiples of 16)
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
-    unsigned* const mkp = A.save_mask ? A.save_mask + ((int64_t)(blockIdx.x * 4 + wave) * NW) * 64 + lane : nullptr;
+    // (wave-uniform base + lane: no address registers; rows of P / Q0 / save_h1 are addressed as base + 32-bit offset)
+    unsigned* const mkb = A.save_mask ? A.save_mask + (int64_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave) * NW * 64 : nullptr;
+#define MKP(w) mkb[(w) * 64 + lane]
 
     const float* wf1 = grp == 1 ? A.wf1T_in : A.wf1T_out;   // NCH4 column-block images [DE][<=64], block i at DE * 64 * i
     const float* wf2 = grp == 1 ? A.wf2T_in : A.wf2T_out;
@@ -352,6 +384,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 
     // ---- phase 1: H1^T = W1e [e0|e]^T, C-in = Pr[row] (+ Pc[col] after the MFMAs) ---------------------------
     const int row = A.srow[edge], col = A.scol[edge];
+    const unsigned eh = (unsigned)edge * (unsigned)he;   // this edge's row of Q0 / save_h1
     f32x16 h1[T1];
     {
         const float* pr = A.P + (int64_t)row * A.pw;
@@ -360,22 +393,21 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(h1[t], g, ldrow<EXACT>(pr, 32 * t + 8 * g + 4 * lh, he));
         if (A.Q0) {  // + the step-invariant share of the layer (hoisted out of the step loop like P0)
-            const float* q0 = A.Q0 + (int64_t)edge * he;
 #pragma unroll
             for (int t = 0; t < T1; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) add4(h1[t], g, ldrow<EXACT>(q0, 32 * t + 8 * g + 4 * lh, he));
+                for (int g = 0; g < 4; ++g) add4(h1[t], g, ldrow<EXACT>(A.Q0, eh, 32 * t + 8 * g + 4 * lh, he));
         }
     }
     // Pc[col] joins H1 after the MFMAs, two tiles (8 row pieces) per gather round; round r is issued one chunk before
     // the phase-2 chunk that consumes tiles 2r, 2r+1 (round 0: in the last phase-1 chunk)
     float4 pcv[8];
-    const float* pc = A.P + (int64_t)col * A.pw + he;
-    float* sv = A.save_h1 ? A.save_h1 + (int64_t)edge * he : nullptr;
+    const unsigned pco = (unsigned)col * (unsigned)A.pw + (unsigned)he;
+    float* const sv = A.save_h1;
     auto pc_issue = [&](int r) {
 #pragma unroll
         for (int g = 0; g < 8; ++g)
-            if (2 * r + (g >> 2) < T1) pcv[g] = ldrow<EXACT>(pc, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
+            if (2 * r + (g >> 2) < T1) pcv[g] = ldrow<EXACT>(A.P, pco, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he);
     };
     auto pc_finish = [&](int r) {
 #pragma unroll
@@ -387,9 +419,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 8; ++g)
                 if (2 * r + (g >> 2) < T1)
-                    strow<EXACT>(sv, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[2 * r + (g >> 2)], g & 3), edge_ok);
+                    strow<EXACT>(sv, eh, 32 * (2 * r + (g >> 2)) + 8 * (g & 3) + 4 * lh, he, get4(h1[2 * r + (g >> 2)], g & 3), edge_ok);
         }
-        if (mkp) mkp[(W_H1 + r) * 64] = mask16(h1[2 * r]) | (2 * r + 1 < T1 ? mask16(h1[2 * r + 1]) << 16 : 0u);
+        if (mkb) MKP(W_H1 + r) = mask16(h1[2 * r]) | (2 * r + 1 < T1 ? mask16(h1[2 * r + 1]) << 16 : 0u);
     };
     {
         // lane (j, h) reads its edge's features 16 bytes at a time: k = 8u + 4h + (0..3)
@@ -475,10 +507,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     // every gather has a whole chunk of MFMAs to land and is drained by the barrier that ends the chunk.
     f32x16 en[T2];
     f32x16 hf[TF];
-    const float* pf = A.P + (int64_t)col * A.pw + 2 * he + (grp == 1 ? hn : 0);  // (self-loop blocks gather flow_out's and drop it)
+    const unsigned pfo = pco + (unsigned)(he + (grp == 1 ? hn : 0));  // (self-loop blocks gather flow_out's and drop it)
     auto pf_issue = [&](int t) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(pf, 32 * t + 8 * g + 4 * lh, hn));
+        for (int g = 0; g < 4; ++g) set4(hf[t], g, ldrow<EXACT>(A.P, pfo, 32 * t + 8 * g + 4 * lh, hn));
     };
 #pragma unroll
     for (int t = 0; t < T2; ++t)
@@ -503,8 +535,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         const float* ws = wbuf_at(c);
         if constexpr (SP) {
             const unsigned wa = lds_addr(ws) + lane * 16;
-            chain_units<T2, 2>(h1[2 * i], 0, en, wa, T2, 0, 0);
-            if (2 * i + 1 < T1) chain_units<T2, 2>(h1[2 * i + 1], 0, en, wa, T2, 2, 0);
+            chain_units<T2, 2, P2PIPE>(h1[2 * i], 0, en, wa, T2, 0, 0);
+            if (2 * i + 1 < T1) chain_units<T2, 2, P2PIPE>(h1[2 * i + 1], 0, en, wa, T2, 2, 0);
         } else {
             chain_tile<T2>(h1[2 * i], en, ws, DE, 0, 0, 4 * lh * DE + lj);
             if (2 * i + 1 < T1) chain_tile<T2>(h1[2 * i + 1], en, ws, DE, 32, 0, 4 * lh * DE + lj);
@@ -520,9 +552,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, de, get4(en[t], g), edge_ok);
         }
-        if (mkp) {
+        if (mkb) {
 #pragma unroll
-            for (int t = 0; t < T2; t += 2) mkp[(W_E + (t >> 1)) * 64] = mask16(en[t]) | (t + 1 < T2 ? mask16(en[t + 1]) << 16 : 0u);
+            for (int t = 0; t < T2; t += 2) MKP(W_E + (t >> 1)) = mask16(en[t]) | (t + 1 < T2 ? mask16(en[t + 1]) << 16 : 0u);
         }
     }
 
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
         __syncthreads();
         ++c;
         relu16(hcv);
-        if (mkp) mkp[W_HC * 64] = mask16(hcv);
+        if (mkb) MKP(W_HC) = mask16(hcv);
         if (A.save_hc) {
             float* o = A.save_hc + (int64_t)edge * hc;
 #pragma unroll
@@ -604,9 +636,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
                 for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, hn, get4(hf[t], g), edge_ok);
             }
         }
-        if (mkp) {
+        if (mkb) {
 #pragma unroll
-            for (int t = 0; t < TF; t += 2) mkp[(W_HF + (t >> 1)) * 64] = mask16(hf[t]) | (t + 1 < TF ? mask16(hf[t + 1]) << 16 : 0u);
+            for (int t = 0; t < TF; t += 2) MKP(W_HF + (t >> 1)) = mask16(hf[t]) | (t + 1 < TF ? mask16(hf[t + 1]) << 16 : 0u);
         }
     }
 
@@ -637,12 +669,13 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(o, 32 * t + 8 * g + 4 * lh, dn, get4(mm[t], g), edge_ok);
         }
-        if (mkp) {
+        if (mkb) {
 #pragma unroll
-            for (int t = 0; t < TD; t += 2) mkp[(W_M + (t >> 1)) * 64] = mask16(mm[t]) | (t + 1 < TD ? mask16(mm[t + 1]) << 16 : 0u);
+            for (int t = 0; t < TD; t += 2) MKP(W_M + (t >> 1)) = mask16(mm[t]) | (t + 1 < TD ? mask16(mm[t + 1]) << 16 : 0u);
         }
     }
     TS(8);
+#undef MKP
 }
 #undef wbuf_at
 
@@ -655,7 +688,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 //   B4  dZc = (dlog wc2) (.) [HC > 0];  dE' += Wc1^T dZc;  dZ2 = dE' (.) [e_s > 0]
 //   B5  dZ1 = (W2^T dZ2) (.) [H1 > 0]
 //   B6  d[e0 | e_{s-1}] = W1e^T dZ1  ->  dE0 += ..., dEprev = ...
-template <int T1, int T2, int TF, int TD, bool EXACT>
+template <int T1, int T2, int TF, int TD, bool EXACT, bool SP>
 __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(EdgeChainBwdArgs A) {
     constexpr int HE = 32 * T1, DE = 32 * T2, HN = 32 * TF, DN = 32 * TD, HC = 32;
     constexpr int NR2 = 16;   // B2 chunk: [16 n][HN]
@@ -664,12 +697,15 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     constexpr int NR6 = 64;   // B6 chunk: [<=64 n][64 k]
     // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6; float4 counts of the contiguous chunks ------------
     constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
-    constexpr int N4_2 = NR2 * HN / 4;                  // 16 rows of Wf2
-    constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4;      // first 64 rows of Wfe
-    constexpr int N4_4 = HC * DE / 4;                   // Wc1, whole
-    constexpr int N4_5 = NR5 * HE / 4;                  // 16 rows of W2
-    constexpr int N4_6MAX = cmin(NR6, HE) * 64 / 4;     // <= 64 rows of one W1e column-pass image [HE][ncol6]
-    constexpr int CHF = 1024 * chunk_q(cmax(cmax(N4_2, N4_3_0), cmax(cmax(N4_4, N4_5), N4_6MAX)));
+    constexpr int SCN = SP ? 3 : 2;                                // split images: 3/2 the size (edge_chain.hip, split8)
+    constexpr bool WIDEPIPE = T1 < 10;                             // B5 of the widest variant: no registers for a second operand set
+    constexpr int N4_2 = NR2 * HN / 4 * SCN / 2;                   // 16 rows of Wf2
+    constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4 * SCN / 2;       // first 64 rows of Wfe
+    constexpr int N4_4 = HC * DE / 4 * SCN / 2;                    // Wc1, whole
+    constexpr int N4_5 = NR5 * HE / 4 * SCN / 2;                   // 16 rows of W2
+    constexpr int N4_6MAX = cmin(NR6, HE) * 64 / 4 * SCN / 2;      // <= 64 rows of one W1e column-pass image [HE][ncol6]
+    constexpr int N4_MAX = cmax(cmax(N4_2, N4_3_0), cmax(cmax(N4_4, N4_5), N4_6MAX));
+    constexpr int CHF = SP ? 4 * N4_MAX : 1024 * chunk_q(N4_MAX);
     static_assert(CHF <= CH_FLOATS, "chunk too large");
     // mask words per lane (edge_chain.h: chain_mask_words)
     constexpr int W_H1 = 0, W_E = W_H1 + (T1 + 1) / 2, W_HC = W_E + (T2 + 1) / 2, W_HF = W_HC + 1, W_M = W_HF + (TF + 1) / 2,
@@ -708,9 +744,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     TS_INIT();
     TS(0);
     if (flow) {
-        chunk_fetch<chunk_q(N4_2)>(wf2, N4_2, tid, wbuf_at(0));
+        chunk_fetch<chunk_q(N4_2), SP>(wf2, N4_2, tid, wbuf_at(0));
     } else {
-        chunk_fetch<chunk_q(N4_4)>(A.wc1, N4_4, tid, wbuf_at(0));
+        chunk_fetch<chunk_q(N4_4), SP>(A.wc1, N4_4, tid, wbuf_at(0));
     }
     if (tid < 32) swc2[tid] = tid < hc ? A.wc2[tid] : 0.f;
 
@@ -788,11 +824,12 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 #pragma unroll
         for (int i = 0; i < NCH2; ++i) {
             const bool more = i + 1 < NCH2;  // folds: i is unrolled
-            const float* nsrc = more ? wf2 + (i + 1) * NR2 * HN : wfe;
+            const float* nsrc = more ? wf2 + (i + 1) * (NR2 * HN * SCN / 2) : wfe;
             const int nn4 = more ? N4_2 : N4_3_0;
-            chunk_fetch<chunk_q(cmax(N4_2, N4_3_0))>(nsrc, nn4, tid, wbuf_at(c + 1));
+            chunk_fetch<chunk_q(cmax(N4_2, N4_3_0)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
             // chunk rows = 16 contraction indices n = 16 i .. 16 i + 15 = registers 8 (i & 1) .. + 7 of source tile i / 2
-            chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf_at(c), HN, 4 * lh * HN + lj);
+            if constexpr (SP) chain_units<TF, 1, WIDEPIPE>(dzm[i >> 1], i & 1, dzf, lds_addr(wbuf_at(c)) + lane * 16, TF, 0, 0);
+            else chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf_at(c), HN, 4 * lh * HN + lj);
             __syncthreads();
             ++c;
         }
@@ -812,12 +849,17 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         for (int i = 0; i < NCH3; ++i) {
             const bool more = i + 1 < NCH3;
             const int rows_n = more ? (HN - (i + 1) * NR3 < NR3 ? HN - (i + 1) * NR3 : NR3) : 0;
-            const float* nsrc = more ? wfe + (i + 1) * NR3 * DE : A.wc1;
-            const int nn4 = more ? rows_n * DE / 4 : N4_4;
-            chunk_fetch<chunk_q(cmax(N4_3_0, N4_4))>(nsrc, nn4, tid, wbuf_at(c + 1));
+            const float* nsrc = more ? wfe + (i + 1) * (NR3 * DE * SCN / 2) : A.wc1;
+            const int nn4 = more ? rows_n * DE / 4 * SCN / 2 : N4_4;
+            chunk_fetch<chunk_q(cmax(N4_3_0, N4_4)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
             const float* ws = wbuf_at(c);
-            chain_tile<T2>(dzf[2 * i], dE, ws, DE, 0, 0, 4 * lh * DE + lj);
-            if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], dE, ws, DE, 32, 0, 4 * lh * DE + lj);
+            if constexpr (SP) {
+                chain_units<T2, 2>(dzf[2 * i], 0, dE, lds_addr(ws) + lane * 16, T2, 0, 0);
+                if (2 * i + 1 < TF) chain_units<T2, 2>(dzf[2 * i + 1], 0, dE, lds_addr(ws) + lane * 16, T2, 2, 0);
+            } else {
+                chain_tile<T2>(dzf[2 * i], dE, ws, DE, 0, 0, 4 * lh * DE + lj);
+                if (2 * i + 1 < TF) chain_tile<T2>(dzf[2 * i + 1], dE, ws, DE, 32, 0, 4 * lh * DE + lj);
+            }
             __syncthreads();
             ++c;
         }
@@ -838,8 +880,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 8 * g + 4 * lh, hc, get4(dzc, g), edge_ok);
         }
-        chunk_fetch<chunk_q(N4_5)>(A.w2, N4_5, tid, wbuf_at(c + 1));
-        chain_tile<T2>(dzc, dE, wbuf_at(c), DE, 0, 0, 4 * lh * DE + lj);
+        chunk_fetch<chunk_q(N4_5), SP>(A.w2, N4_5, tid, wbuf_at(c + 1));
+        if constexpr (SP) chain_units<T2, 2>(dzc, 0, dE, lds_addr(wbuf_at(c)) + lane * 16, T2, 0, 0);
+        else chain_tile<T2>(dzc, dE, wbuf_at(c), DE, 0, 0, 4 * lh * DE + lj);
         __syncthreads();
         ++c;
     }
@@ -865,13 +908,17 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
         const bool more = i + 1 < NCH5;
-        const float* nsrc = more ? A.w2 + (i + 1) * NR5 * HE : A.w1e;
-        const int nn4 = more ? N4_5 : rows6_0 * ncol6 / 4;
-        chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX))>(nsrc, nn4, tid, wbuf_at(c + 1));
+        const float* nsrc = more ? A.w2 + (i + 1) * (NR5 * HE * SCN / 2) : A.w1e;
+        const int nn4 = more ? N4_5 : rows6_0 * ncol6 / 4 * SCN / 2;
+        chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
         // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
         constexpr int TA = (T1 + 1) / 2, TB = T1 - TA;
-        chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf_at(c), HE, 4 * lh * HE + lj);
-        if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf_at(c), HE, 4 * lh * HE + lj + 32 * TA);
+        if constexpr (SP) {
+            chain_units<T1, 1, WIDEPIPE>(dE[i >> 1], i & 1, dz1, lds_addr(wbuf_at(c)) + lane * 16, T1, 0, 0);
+        } else {
+            chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf_at(c), HE, 4 * lh * HE + lj);
+            if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf_at(c), HE, 4 * lh * HE + lj + 32 * TA);
+        }
         __syncthreads();
         ++c;
     }
@@ -922,11 +969,20 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             const int in = more ? i + 1 : (more_pass ? 0 : i);
             const int pn = more ? pass : (more_pass ? pass + 1 : pass);
             const int rows_n = HE - in * NR6 < NR6 ? HE - in * NR6 : NR6;
-            const float* nsrc = A.w1e + ((int64_t)pn * HE + in * NR6) * ncol6;
-            const int nn4 = rows_n * ncol6 / 4;
-            chunk_fetch<chunk_q(N4_6MAX)>(nsrc, nn4, tid, wbuf_at(c + 1));
+            const float* nsrc = A.w1e + ((int64_t)pn * HE + in * NR6) * ncol6 * SCN / 2;
+            const int nn4 = rows_n * ncol6 / 4 * SCN / 2;
+            chunk_fetch<chunk_q(N4_6MAX), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
             const float* ws = wbuf_at(c);
-            if (ncol6 == 64) {
+            if constexpr (SP) {
+                const unsigned wa = lds_addr(ws) + lane * 16;
+                if (ncol6 == 64) {
+                    chain_units<2, 2>(dz1[2 * i], 0, dc, wa, 2, 0, 0);
+                    if (2 * i + 1 < T1) chain_units<2, 2>(dz1[2 * i + 1], 0, dc, wa, 2, 2, 0);
+                } else {
+                    chain_units<1, 2>(dz1[2 * i], 0, dc, wa, 1, 0, 0);
+                    if (2 * i + 1 < T1) chain_units<1, 2>(dz1[2 * i + 1], 0, dc, wa, 1, 2, 0);
+                }
+            } else if (ncol6 == 64) {
                 chain_tile<2>(dz1[2 * i], dc, ws, 64, 0, 0, 4 * lh * 64 + lj);
                 if (2 * i + 1 < T1) chain_tile<2>(dz1[2 * i + 1], dc, ws, 64, 32, 0, 4 * lh * 64 + lj);
             } else {
@@ -973,7 +1029,7 @@ __global__ void k_transpose_padded(const float* __restrict__ W, int64_t ldw, int
 
 // Split image (see the comment at split8): thread = one element of one unit; writes its three pieces.
 __global__ void k_pack_split(const float* __restrict__ src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np,
-                             unsigned short* __restrict__ dst) {
+                             unsigned short* __restrict__ dst, int ntr_image, int t0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int ntr = Np / 32;
     if (idx >= (int64_t)(Kp / 16) * ntr * 512) return;
@@ -986,18 +1042,19 @@ __global__ void k_pack_split(const float* __restrict__ src, int64_t sk, int64_t 
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)m);
-    unsigned short* o = dst + unit * 3 * 512 + lane * 8 + i;
+    unsigned short* o = dst + ((int64_t)kb * ntr_image + t0 + t) * 3 * 512 + lane * 8 + i;
     o[0] = __builtin_bit_cast(unsigned short, h);
     o[512] = __builtin_bit_cast(unsigned short, m);
     o[1024] = __builtin_bit_cast(unsigned short, l);
 }
 
-int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s) {
+int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s, int ntr_image, int t0) {
+    if (ntr_image <= 0) ntr_image = Np / 32;
     const int64_t n = (int64_t)(Kp / 16) * (Np / 32) * 512;
     if (n <= 0) return MPNHIP_OK;
     if (Kp % 16 != 0 || Np % 32 != 0) { set_error("pack_split: padded sizes must be multiples of 16 x 32"); return MPNHIP_ERR_ARG; }
     hipLaunchKernelGGL(k_pack_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sk, sn, K, N, Kp, Np,
-                       reinterpret_cast<unsigned short*>(dst));
+                       reinterpret_cast<unsigned short*>(dst), ntr_image, t0);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
@@ -1110,13 +1167,23 @@ int launch_edge_chain_bwd(const EdgeChainBwdArgs& a_in, hipStream_t s) {
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc == 32;
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
-            if (exact)
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true>), dim3(blocks), dim3(256), 0, s, a);
+            if (a.split && exact)
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true, true>), dim3(blocks), dim3(256), 0, s, a);
+            else if (a.split)
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false, true>), dim3(blocks), dim3(256), 0, s, a);
+            else if (exact)
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true, false>), dim3(blocks), dim3(256), 0, s, a);
             else
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false, false>), dim3(blocks), dim3(256), 0, s, a);
             break;
-        case 64: hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 64:
+            if (a.split) hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false, false>), dim3(blocks), dim3(256), 0, s, a);
+            break;
+        case 32:
+            if (a.split) hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false, false>), dim3(blocks), dim3(256), 0, s, a);
+            break;
         default: set_error("edge_chain_bwd: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
 #ifdef MPNHIP_CHAIN_TS
