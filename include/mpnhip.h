@@ -33,6 +33,13 @@ extern "C" {
  * configuration (SURVEY.md section 8d cfg-E); forward only (mpnhip_backward refuses it). */
 #define MPNHIP_PREC_FP32 0
 #define MPNHIP_PREC_BF16 1
+/* FP32_SPLIT: fp32 results from bf16 matrix instructions.  In the fused per-edge chain kernels (forward and backward) every
+ * fp32 operand is taken as the exact sum of three bfloat16 pieces (x = h + m + l, each the RNE rounding of the remainder)
+ * and a product is accumulated in fp32 from the six piece products whose weight is at least 2^-16 of the leading one; the
+ * three dropped products are below 2^-24 |a b|, i.e. below fp32 rounding.  Nothing is rounded to bf16: the error against
+ * float64 is that of the FP32 mode (tests/test_gpu_split.py measures both), at 3/8 of the fp32 MFMA's cycles.  The
+ * unfused products (node-side GEMMs, encoders, weight gradients) stay fp32 MFMAs.  Forward and backward. */
+#define MPNHIP_PREC_FP32_SPLIT 2
 
 #define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
 #define MPNHIP_AGG_MEAN 1 /* torch_scatter.scatter_mean (models/mpn.py:267) */

@@ -21,6 +21,10 @@ class MpnhipError(RuntimeError):
     pass
 
 
+# mpnhip_model.precision (include/mpnhip.h)
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp32_split': 2}
+
+
 class Mlp(C.Structure):
     _fields_ = [
         ("n_layers", C.c_int),

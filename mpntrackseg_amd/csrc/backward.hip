@@ -384,8 +384,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     const int64_t N = n_nodes, E = n_edges;
     MPN_CHECK_ARG(N >= 0 && E >= 0, "backward: negative sizes");
     MPN_CHECK_ARG((x || N == 0) && (edge_attr || E == 0) && (grad_logits || E == 0), "backward: null tensor");
-    if (m.precision != MPNHIP_PREC_FP32) {
-        set_error("backward: bf16-operand products are an inference mode; train with MPNHIP_PREC_FP32");
+    if (m.precision == MPNHIP_PREC_BF16) {
+        set_error("backward: bf16-operand products are an inference mode; train with MPNHIP_PREC_FP32 or MPNHIP_PREC_FP32_SPLIT");
         return MPNHIP_ERR_UNSUPPORTED;
     }
     {

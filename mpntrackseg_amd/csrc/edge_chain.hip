@@ -758,14 +758,16 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 #pragma unroll
         for (int w = 0; w < NW; ++w) mk[w] = mp[w * 64];
     }
-    f32x16 dE[T2];   // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators
-    {
+    f32x16 dE[T2];   // gradient w.r.t. e_s arriving from the later step: C-in of the dE' accumulators (B3 / B4)
+    auto load_dE = [&]() {
         const float* p = A.dE_io + (int64_t)edge * de;
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(dE[t], g, ldrow<EXACT>(p, 32 * t + 8 * g + 4 * lh, de));
-    }
+    };
+    // flow blocks fetch it in B2's last chunk (into the registers the consumed dZM tiles free: B2 is the register peak)
+    if (!flow) load_dE();
     const float dl = A.dlog[A.perm[edge]];
     f32x16 dzm[TD];
     if (flow) {
@@ -827,8 +829,9 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             const float* nsrc = more ? wf2 + (i + 1) * (NR2 * HN * SCN / 2) : wfe;
             const int nn4 = more ? N4_2 : N4_3_0;
             chunk_fetch<chunk_q(cmax(N4_2, N4_3_0)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
+            if (i == NCH2 - 1) load_dE();
             // chunk rows = 16 contraction indices n = 16 i .. 16 i + 15 = registers 8 (i & 1) .. + 7 of source tile i / 2
-            if constexpr (SP) chain_units<TF, 1, WIDEPIPE>(dzm[i >> 1], i & 1, dzf, lds_addr(wbuf_at(c)) + lane * 16, TF, 0, 0);
+            if constexpr (SP) chain_units<TF, 1>(dzm[i >> 1], i & 1, dzf, lds_addr(wbuf_at(c)) + lane * 16, TF, 0, 0);
             else chain_half<TF>(dzm[i >> 1], (i & 1) * 8, dzf, wbuf_at(c), HN, 4 * lh * HN + lj);
             __syncthreads();
             ++c;
@@ -975,9 +978,13 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             const float* ws = wbuf_at(c);
             if constexpr (SP) {
                 const unsigned wa = lds_addr(ws) + lane * 16;
+                // (the split of a dZ1 tile does not depend on the pass: without this the compiler computes all of them
+                // ahead of the pass loop and spills them)
+                asm volatile("" : "+v"(dz1[2 * i]));
+                if (2 * i + 1 < T1) asm volatile("" : "+v"(dz1[2 * i + 1 < T1 ? 2 * i + 1 : 0]));
                 if (ncol6 == 64) {
-                    chain_units<2, 2>(dz1[2 * i], 0, dc, wa, 2, 0, 0);
-                    if (2 * i + 1 < T1) chain_units<2, 2>(dz1[2 * i + 1], 0, dc, wa, 2, 2, 0);
+                    chain_units<2, 2, WIDEPIPE>(dz1[2 * i], 0, dc, wa, 2, 0, 0);
+                    if (2 * i + 1 < T1) chain_units<2, 2, WIDEPIPE>(dz1[2 * i + 1], 0, dc, wa, 2, 2, 0);
                 } else {
                     chain_units<1, 2>(dz1[2 * i], 0, dc, wa, 1, 0, 0);
                     if (2 * i + 1 < T1) chain_units<1, 2>(dz1[2 * i + 1], 0, dc, wa, 1, 2, 0);

@@ -452,7 +452,7 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
     dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
     int prec = g_precision;
-    if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);
+    if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);  // tuning override (tools/gemm_bench.py)
     if (bl == B_KCONTIG && prec == 2)
         MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, 2>), grid, dim3(NTHREADS), s, a);
     else if (bl == B_KCONTIG && prec == 1)

@@ -227,16 +227,16 @@ static inline void hidden_ptrs(const mpnhip_mlp& m, float* const two[2], int64_t
 // the fused edge-chain kernels (edge_chain.hip) cover this model's per-edge modules
 static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
     if (getenv("MPNHIP_NO_CHAIN")) return false;  // tuning / A-B switch
-    if (m.precision != MPNHIP_PREC_FP32) return false;  // the fused chain kernels are fp32-operand kernels
+    if (m.precision == MPNHIP_PREC_BF16) return false;  // the fused chain kernels compute fp32 results (FP32 / FP32_SPLIT)
     return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
            edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
 }
 
-// split (three-piece bf16) weight images and six-product MFMAs in the fused chain kernels: tuning switch for now
+// split (three-piece bf16) weight images and six-product MFMAs in the fused chain kernels: mpnhip_model.precision ==
+// MPNHIP_PREC_FP32_SPLIT (MPNHIP_CHAIN_SPLIT=0/1 in the environment overrides it: A-B switch for measurements)
 static inline bool chain_split(const mpnhip_model& m) {
-    (void)m;
-    const char* e = getenv("MPNHIP_CHAIN_SPLIT");
-    return e && e[0] == '1';
+    if (const char* e = getenv("MPNHIP_CHAIN_SPLIT")) return e[0] == '1';
+    return m.precision == MPNHIP_PREC_FP32_SPLIT;
 }
 
 static inline void init_group(GemmGroup& g) { memset(&g, 0, sizeof(g)); }

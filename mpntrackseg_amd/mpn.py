@@ -370,12 +370,13 @@ class MOTMPNet(nn.Module):
         m.reattach_nodes = int(bool(self.reattach_initial_nodes))
         m.reattach_edges = int(bool(self.reattach_initial_edges))
         m.num_enc_steps = int(self.num_enc_steps)
-        # operand precision of the Linear products: 'fp32' (the reference's arithmetic) or 'bf16' (inference only:
-        # operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs on MFMA" configuration)
+        # operand precision of the Linear products (include/mpnhip.h MPNHIP_PREC_*): 'fp32' (fp32 MFMAs), 'fp32_split'
+        # (fp32 results from three-piece bf16 operands in the fused chain kernels: same accuracy, fewer MFMA cycles) or
+        # 'bf16' (inference only: operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs" mode)
         prec = getattr(self, 'gemm_precision', 'fp32')
-        if prec not in ('fp32', 'bf16'):
-            raise capi.MpnhipError("gemm_precision must be 'fp32' or 'bf16', not %r" % (prec,))
-        m.precision = 1 if prec == 'bf16' else 0
+        if prec not in capi.PRECISIONS:
+            raise capi.MpnhipError("gemm_precision must be one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
+        m.precision = capi.PRECISIONS[prec]
         m.enc_node = self.encoder.node_model.c_struct(keep, grads)
         m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
         m.classifier = self.classifier.edge_model.c_struct(keep, grads)

@@ -53,6 +53,12 @@ def test_struct_layout_matches_c():
     assert capi.Model.weights_prepacked.offset == capi.Model.precision.offset + 4
 
 
+def test_precision_codes_match_header():
+    src = open(os.path.join(REPO, "include", "mpnhip.h")).read()
+    codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define MPNHIP_PREC_([A-Z0-9_]+) (\d+)", src)}
+    assert codes == capi.PRECISIONS
+
+
 def test_new_entry_points_argument_checks_without_gpu():
     """Size queries and the argument checks of the f-3 / f-4 / optimizer entry points run on the host: no device work is
     reached for empty inputs, null pointers or undersized workspaces (error codes as include/mpnhip.h states)."""
