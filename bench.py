@@ -309,7 +309,7 @@ def rooflines(prof, c, args, N, E, chain):
         # fused per-edge chain (edge MLP e-part + classifier + flow MLP e-part): MACs per edge, DESIGN.md section 4
         # the re-attached e0's share of the first layer is computed once per forward (Q0, one GEMM) when de >= 32: the
         # kernel then contracts de, not 2 de, columns there -- EXECUTED flops are what the MFMA fraction is quoted on
-        k1 = de if (de >= 32 and c["L"] > 1) else 2 * de
+        k1 = de if (de >= 32 and c["L"] > 1 and args.precision != "fp32_split") else 2 * de   # (no Q0 hoist in the split mode)
         macs = k1 * he + he * de + de * hc + hc + de * hn + hn * dn
         flops = 2.0 * E * macs
         ach = flops / (gemm_us * 1e-6) / 1e12

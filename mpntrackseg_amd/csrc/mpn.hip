@@ -458,8 +458,10 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     // the same for the edge side of the fused chain: Q0 = e0 W1[:, e0 columns]^T, [E, he] (64 MB at cfg-B), saves a
     // quarter of the chain's first-layer MFMAs in every step
     // (measured: pays from de = 32 up; at the reference's de = 16 the extra C-in loads cost more than the one chunk saved)
-    const bool hoist_e = p.cw.ok && d.ef == 2 && d.L > 1 && E > 0 && d.de >= 32 && (d.ke - d.de) % 16 == 0 && d.de % 16 == 0 &&
-                         !getenv("MPNHIP_NO_Q0");
+    // (FP32_SPLIT: the chain kernel is bound by its row traffic, not by MFMA cycles -- re-reading 4 he bytes per edge and step
+    // costs more than the k blocks it saves: measured 1.59 -> 1.55 ms per cfg-B forward without the hoist)
+    const bool hoist_e = p.cw.ok && !p.cw.split && d.ef == 2 && d.L > 1 && E > 0 && d.de >= 32 && (d.ke - d.de) % 16 == 0 &&
+                         d.de % 16 == 0 && !getenv("MPNHIP_NO_Q0");
     if (hoist_e) {
         GemmArgs a = {};
         a.ngroups = 1; a.N = d.he; a.K = d.de; a.ksplit = d.de; a.m_upper = E;
