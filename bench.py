@@ -282,11 +282,11 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel_key, cfg_name):
+def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
     tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
-    path = os.path.join(REPO, "profiles", "r01", "pmc_summary.json")
-    if cfg_name != "B":
+    path = os.path.join(REPO, "profiles", "r01", "pmc_summary.json" if precision == "fp32" else "pmc_summary_split.json")
+    if cfg_name != "B" or precision == "bf16":
         return None
     try:
         return json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
@@ -324,7 +324,7 @@ def rooflines(prof, c, args, N, E, chain):
                                                           "six v_mfma_f32_32x32x16_bf16 products per fp32 MAC (three-piece split operands)"
                                                           if split else "fp32 v_mfma_f32_32x32x2_f32", E, macs),
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "traffic": pmc_traffic("edge_chain", args.config), "avg_us": gemm_us,
+                           "traffic": pmc_traffic("edge_chain", args.config, args.precision), "avg_us": gemm_us,
                            "empty_event_pair_us": empty_us, "launches": gemm_n, "algorithmic_flops": flops,
                            # what the reference executes for the same per-edge modules (gathered
                            # [x_row | x_col | e] and [x_col | e'] inputs multiplied per edge), for comparability
@@ -346,7 +346,7 @@ def rooflines(prof, c, args, N, E, chain):
         ach = bytes_agg / (agg_us * 1e-6) / 1e9
         res["roofline_aggregation"] = {"bound": "hbm", "kernel": "k_aggregate (both directions, %d messages x %d-d, %s)" % (E, dn, args.agg),
                                        "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                                       "traffic": pmc_traffic("k_aggregate", args.config), "avg_us": agg_us,
+                                       "traffic": pmc_traffic("k_aggregate", args.config, args.precision), "avg_us": agg_us,
                                        "empty_event_pair_us": empty_us, "launches": agg_n,
                                        "algorithmic_bytes": bytes_agg}
     return res
