@@ -38,7 +38,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // Operand precision of the MFMA products of the calling thread's current forward (set by mpnhip_forward from
 // mpnhip_model.precision): 0 = fp32 operands (v_mfma_f32_32x32x2_f32), 1 = operands rounded to bf16 (RNE) when they
-// are staged into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- BASELINE.json's "bf16 MLP GEMMs on MFMA" mode.
+// are staged into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- BASELINE.json's "bf16 MLP GEMMs on MFMA" mode;
+// 2 = MPNHIP_PREC_FP32_SPLIT: fp32 operands split into three bf16 pieces as they are staged, six products per multiply.
 static thread_local int g_precision = 0;
 void set_gemm_precision(int p) { g_precision = p; }
 int gemm_precision() { return g_precision; }
@@ -452,6 +453,10 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     int64_t nby = (a.m_upper + BM - 1) / BM + (a.ngroups > 1 ? 1 : 0);
     dim3 grid((a.N + BN - 1) / BN, (unsigned)nby, 1);
     int prec = g_precision;
+    // FP32_SPLIT (three-piece bf16 operands, six products: split3): pays where the product is large enough to be MFMA-bound --
+    // measured on MI355X (tools/gemm_bench.py --check): 5000 x 1088 x 256 38.9 -> 31.6 us, 5000 x 512 x 2048 141 -> 122 us,
+    // 50000 x 320 x 128 65.6 -> 48.5 us; narrow outputs (N = 128) and short K lose to the fp32 MFMA kernel's smaller LDS image
+    if (prec == 2 && !(a.K >= 128 && a.N >= 256)) prec = 0;
     if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);  // tuning override (tools/gemm_bench.py)
     if (bl == B_KCONTIG && prec == 2)
         MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, 2>), grid, dim3(NTHREADS), s, a);

@@ -426,7 +426,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         int old;
         explicit PrecisionScope(int p) : old(gemm_precision()) { set_gemm_precision(p); }
         ~PrecisionScope() { set_gemm_precision(old); }
-    } precision_scope(m.precision == MPNHIP_PREC_BF16 ? 1 : 0);  // (FP32_SPLIT concerns the fused chain kernels only)
+    } precision_scope(m.precision);  // (FP32_SPLIT: the fused chain kernels, and the larger K-contiguous GEMMs -- gemm.hip)
 
     if (m.weights_prepacked && !save) {
         p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace

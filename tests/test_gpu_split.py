@@ -11,7 +11,7 @@ import torch
 
 from mpntrackseg_amd import capi, synth
 from oracle import mpn_oracle as O
-from test_gpu_backward import check_against_oracle, make_model as make_train_model, native_grads, nerr
+from test_gpu_backward import check_against_oracle, close_enough, make_model as make_train_model, native_grads, nerr
 from test_gpu_parity import make_model, rel_err, run_hot
 
 pytestmark = pytest.mark.gpu
@@ -116,9 +116,12 @@ def test_split_training_step_gradients_reproducible():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     for k in runs[0][3]:
         assert np.array_equal(runs[0][3][k], runs[1][3][k]), k
-    # and against the fp32 mode: same gradients up to rounding
+    # and against the fp32 mode: the same gradients.  Two fp32-class implementations differ where a pre-activation lies within
+    # rounding of zero (48 M ReLU inputs here: a handful do, cf. the seed note above) -- there the gradient of a few rows
+    # takes the other branch, so the comparison is the robust one of tests/test_gpu_backward.py (relative L2 + loose max)
     model.gemm_precision = "fp32"
     lg, gx, gea, pg = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r)
-    assert nerr(runs[0][0], lg) < 1e-4 and nerr(runs[0][1], gx) < 2e-4
+    assert nerr(runs[0][0], lg) < 1e-4
+    assert close_enough(runs[0][1], gx, 2e-4, True) and close_enough(runs[0][2], gea, 2e-4, True)
     for k in pg:
-        assert nerr(runs[0][3][k], pg[k]) < 2e-4, k
+        assert close_enough(runs[0][3][k], pg[k], 2e-4, True), k
