@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_f32(const float* w, float* y, int re
 #pragma unroll
         for (int t = 0; t < TIN; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(o[t % TOUT][r] * 0.25f + h[t][r] * 0.5f, -1.f);
+            for (int r = 0; r < 16; ++r) h[t][r] = fminf(fmaxf(o[t % TOUT][r] * 0.25f + h[t][r] * 0.5f + 0.01f * ((r + t) % 5), -1.f), 1.f);
     }
     float s = 0.f;
     for (int t = 0; t < TIN; ++t)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_split(const bf16x8* w, float* y, int
 #pragma unroll
         for (int t = 0; t < TIN; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(o[t % TOUT][r] * 0.25f + h[t][r] * 0.5f, -1.f);
+            for (int r = 0; r < 16; ++r) h[t][r] = fminf(fmaxf(o[t % TOUT][r] * 0.25f + h[t][r] * 0.5f + 0.01f * ((r + t) % 5), -1.f), 1.f);
     }
     float s = 0.f;
     for (int t = 0; t < TIN; ++t)
