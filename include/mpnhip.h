@@ -38,7 +38,10 @@ extern "C" {
  * and a product is accumulated in fp32 from the six piece products whose weight is at least 2^-16 of the leading one; the
  * three dropped products are below 2^-24 |a b|, i.e. below fp32 rounding.  Nothing is rounded to bf16: the error against
  * float64 is that of the FP32 mode (tests/test_gpu_split.py measures both), at 3/8 of the fp32 MFMA's cycles.  The
- * unfused products (node-side GEMMs, encoders, weight gradients) stay fp32 MFMAs.  Forward and backward. */
+ * larger K-contiguous GEMMs (node projections, encoders) use the same six products; the remaining products (small GEMMs,
+ * weight gradients) stay fp32 MFMAs.  Forward and backward.  Operands must be finite and below 3.3e38 in magnitude: an
+ * infinite operand gives NaN (inf - inf in the split) where the FP32 mode gives +-inf; pieces below the bf16 normal range
+ * (|x| < 1e-33) may be flushed. */
 #define MPNHIP_PREC_FP32_SPLIT 2
 
 #define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
