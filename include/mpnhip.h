@@ -240,6 +240,16 @@ int mpnhip_edge_features(const int64_t* edge_ixs, int64_t n_edges, int n_nodes, 
 int mpnhip_pairwise_distance(const float* emb, int64_t ld, int dim, const int64_t* edge_ixs, int64_t n_edges, float eps,
                              float* dist, void* stream);
 
+/* load_precomputed_embeddings (utils/rgb.py:150-188) once the per-frame files are in device memory: stored [n_stored, ld]
+ * fp32 rows whose element 0 carries the detection id (1D files: column 0; 3D files [n, 1 + C, H, W]: element [0, 0, 0], i.e.
+ * ld = (1 + C) H W).  keep [n_stored] = 1 iff that id occurs in det_ids_sorted [n_det] (int32 ascending): the np.isin
+ * filter of rgb.py:179 / :185.  The kept rows without their id column / channel are then one mpnhip_gather_rows. */
+int mpnhip_embedding_keep(const float* stored, int64_t ld, int64_t n_stored, const int32_t* det_ids_sorted, int64_t n_det,
+                          unsigned char* keep, void* stream);
+/* the order assertion of rgb.py:180 / :186: mismatch[0] (device int32) = number of j < n with id(stored[rows[j]]) != det_ids[j] */
+int mpnhip_embedding_check(const float* stored, int64_t ld, const int32_t* rows, int64_t n, const int32_t* det_ids,
+                           int32_t* mismatch, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window inference: MPNTracker._predict_edges_and_masks /
  * _evaluate_graph_in_batches (tracker/mpn_tracker.py:96-210) around mpnhip_forward.

@@ -80,6 +80,8 @@ SIGNATURES = {
     "mpnhip_time_valid_conn_fill": (_I, [_P, _I, _L, _P, _L, _P, _P]),
     "mpnhip_edge_features": (_I, [_P, _L, _I, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     "mpnhip_pairwise_distance": (_I, [_P, _L, _I, _P, _L, C.c_float, _P, _P]),
+    "mpnhip_embedding_keep": (_I, [_P, _L, _L, _P, _L, _P, _P]),
+    "mpnhip_embedding_check": (_I, [_P, _L, _P, _L, _P, _P, _P]),
     "mpnhip_knn_mask_workspace_bytes": (_Z, [_L, _I]),
     "mpnhip_knn_mask": (_I, [_P, _P, _I, _L, _I, _I, _I, _P, _P, _Z, _P]),
     "mpnhip_window_flags": (_I, [_P, _L, _L, _L, _P, _P]),

@@ -105,6 +105,28 @@ static size_t scan_temp(int n) {
 }
 
 }  // namespace
+// ---- load_precomputed_embeddings (utils/rgb.py:150-188): id membership and the order check ---------------------------
+// keep[i] = the detection id stored in element 0 of row i occurs in det_ids_sorted (binary search; np.isin of rgb.py:179,185)
+__global__ void k_embedding_keep(const float* __restrict__ stored, int64_t ld, int64_t n_stored, const int* __restrict__ ids_sorted,
+                                 int64_t n_det, unsigned char* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_stored) return;
+    const int id = (int)stored[i * ld];   // (.int() of the reference: truncation)
+    int64_t lo = 0, hi = n_det;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ids_sorted[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    keep[i] = (lo < n_det && ids_sorted[lo] == id) ? 1 : 0;
+}
+// mismatch[0] += number of j whose kept row's id differs from det_ids[j] (the assertion of rgb.py:180,186)
+__global__ void k_embedding_check(const float* __restrict__ stored, int64_t ld, const int* __restrict__ rows, int64_t n,
+                                  const int* __restrict__ det_ids, int* __restrict__ mismatch) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if ((int)stored[(int64_t)rows[j] * ld] != det_ids[j]) atomicAdd(mismatch, 1);
+}
+
 }  // namespace mpnhip
 
 using namespace mpnhip;
@@ -174,6 +196,31 @@ extern "C" int mpnhip_pairwise_distance(const float* emb, int64_t ld, int dim, c
     MPN_CHECK_ARG(emb && edge_ixs && dist, "pairwise_distance: null pointer");
     hipLaunchKernelGGL(k_pairwise_dist, dim3((unsigned)((n_edges + 3) / 4)), dim3(256), 0, stream, emb, ld, dim, edge_ixs, n_edges,
                        eps, dist);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_embedding_keep(const float* stored, int64_t ld, int64_t n_stored, const int32_t* det_ids_sorted, int64_t n_det,
+                                     unsigned char* keep, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(n_stored >= 0 && n_det >= 0 && ld >= 1, "embedding_keep: bad sizes");
+    if (n_stored == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(stored && keep && (det_ids_sorted || n_det == 0), "embedding_keep: null pointer");
+    hipLaunchKernelGGL(k_embedding_keep, dim3((unsigned)((n_stored + 255) / 256)), dim3(256), 0, stream, stored, ld, n_stored,
+                       det_ids_sorted, n_det, keep);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_embedding_check(const float* stored, int64_t ld, const int32_t* rows, int64_t n, const int32_t* det_ids,
+                                      int32_t* mismatch, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(n >= 0 && ld >= 1, "embedding_check: bad sizes");
+    MPN_CHECK_ARG(mismatch, "embedding_check: null pointer");
+    MPN_HIP(hipMemsetAsync(mismatch, 0, sizeof(int32_t), stream));
+    if (n == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(stored && rows && det_ids, "embedding_check: null pointer");
+    hipLaunchKernelGGL(k_embedding_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, stored, ld, rows, n, det_ids, mismatch);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

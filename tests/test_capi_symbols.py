@@ -81,3 +81,8 @@ def test_new_entry_points_argument_checks_without_gpu():
     assert l.mpnhip_adam_step(None, None, None, None, 5, ctypes.c_float(1e-3), ctypes.c_float(0.9), ctypes.c_float(0.999),
                               ctypes.c_float(1e-8), ctypes.c_float(0.0), 0, None) != 0
     assert l.mpnhip_window_accumulate(None, None, 3, None, 2, 0, None, None, None) != 0   # more kept than window edges
+    # embedding-file selection (f-4): empty inputs succeed, null pointers are refused
+    assert l.mpnhip_embedding_keep(None, 17, 0, None, 0, None, None) == 0
+    assert l.mpnhip_embedding_keep(None, 17, 5, None, 0, None, None) != 0
+    assert b"embedding_keep" in l.mpnhip_last_error()
+    assert l.mpnhip_embedding_check(None, 17, None, 0, None, None, None) != 0   # the mismatch counter is always required

@@ -144,3 +144,18 @@ def test_graph_file_round_trip(tmp_path):
     np.savez(str(tmp_path / "junk.npz"), a=np.zeros(3))
     with pytest.raises(ValueError):
         graphfile.load_graph(str(tmp_path / "junk.npz"))
+
+
+def test_frame_embedding_files_have_the_reference_layout(tmp_path):
+    """write_frame_embeddings: one <frame>.pt per frame, detection id in column 0 ('1D') / broadcast into channel 0 ('3D'),
+    as seq_processor.py stores them (what load_precomputed_embeddings, utils/rgb.py:150-188, expects).  Host-only."""
+    import torch
+    from mpntrackseg_amd import embeddings as E
+    frames = np.array([4, 4, 9])
+    ids = np.array([10, 11, 12])
+    E.write_frame_embeddings(str(tmp_path), "reid", frames, ids, np.arange(12, dtype=np.float32).reshape(3, 4))
+    E.write_frame_embeddings(str(tmp_path), "node", frames, ids, np.ones((3, 2, 2, 2), np.float32))
+    a = torch.load(str(tmp_path / "processed_data" / "reid" / "4.pt"))
+    assert tuple(a.shape) == (2, 5) and a[:, 0].tolist() == [10.0, 11.0] and a[1, 1:].tolist() == [4.0, 5.0, 6.0, 7.0]
+    b = torch.load(str(tmp_path / "processed_data" / "node" / "9.pt"))
+    assert tuple(b.shape) == (1, 3, 2, 2) and bool((b[:, 0] == 12).all()) and bool((b[:, 1:] == 1).all())

@@ -170,3 +170,16 @@ def test_g7_graph_utils_oracle_matches_reference(golden):
                 assert np.array_equal(m.numpy(), z[f"{tag}:knn_k{k}_r{rec}_pairs"])
                 m2 = T.get_knn_mask(torch.cat((d, d)), ei2, len(det["frame"]), k, bool(rec), symmetric_edges=True)
                 assert np.array_equal(m2.numpy(), z[f"{tag}:knn_k{k}_r{rec}_sym"])
+
+
+def test_g8_embedding_loader_oracle_matches_reference(golden):
+    """oracle/embeddings_oracle.py against the reference's load_precomputed_embeddings (tests/golden/g8_embedding_files.npz:
+    per-frame files with detections the query does not contain, one frame none of whose detections survives)."""
+    from oracle import embeddings_oracle as EO
+    z = golden("g8_embedding_files.npz")
+    for tag in ("1d", "3d"):
+        out = EO.load_precomputed_embeddings(z["stored_" + tag], z["stored_frame"], z["det_frame"], z["det_id"])
+        assert out.shape == z["out_" + tag].shape and np.array_equal(out, z["out_" + tag])
+    # the reference's assertion fires when the query is not in stored order
+    with pytest.raises(AssertionError):
+        EO.load_precomputed_embeddings(z["stored_1d"], z["stored_frame"], z["det_frame"][::-1], z["det_id"][::-1])

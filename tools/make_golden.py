@@ -375,9 +375,57 @@ def gen_g7():
     print("g7_graph_utils.npz", {k: v.shape for k, v in out.items() if k.startswith("max:")})
 
 
+def gen_g8():
+    """load_precomputed_embeddings (utils/rgb.py:150-188): per-frame ``.pt`` files whose column / channel 0 carries the
+    detection id.  utils/rgb.py imports skimage / torchvision / pycocotools / matplotlib at module level for its OTHER
+    functions (image cropping, mask decoding, plotting); none is installed here and none is touched by the function under
+    test, so empty placeholder modules are registered for the import only."""
+    import tempfile
+    import types
+    import pandas as pd
+    for name, attrs in (("skimage", ()), ("skimage.io", ("imread",)), ("torchvision", ()),
+                        ("torchvision.transforms", ("Compose", "Resize", "ToTensor", "Normalize")),
+                        ("pycocotools", ()), ("pycocotools.mask", ()), ("matplotlib", ()), ("matplotlib.pyplot", ())):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, None)
+            sys.modules[name] = m
+    from mot_neural_solver.utils import rgb as R
+    rng = np.random.RandomState(8)
+    frames = [3, 4, 6, 7, 9, 10]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        next_id, stored1, stored3, fr_of, keep_ids, keep_frames = 0, [], [], [], [], []
+        os.makedirs(os.path.join(tmp, "processed_data", "emb1d"))
+        os.makedirs(os.path.join(tmp, "processed_data", "emb3d"))
+        for f in frames:
+            n = int(rng.randint(2, 7))
+            ids = np.arange(next_id, next_id + n)
+            next_id += n
+            e1 = np.concatenate([ids[:, None].astype(np.float32), rng.randn(n, 16).astype(np.float32)], axis=1)
+            e3 = rng.randn(n, 5, 3, 2).astype(np.float32)
+            e3[:, 0] = ids[:, None, None]
+            torch.save(torch.from_numpy(e1), os.path.join(tmp, "processed_data", "emb1d", f"{f}.pt"))
+            torch.save(torch.from_numpy(e3), os.path.join(tmp, "processed_data", "emb3d", f"{f}.pt"))
+            stored1.append(e1); stored3.append(e3); fr_of += [f] * n
+            kept = ids[rng.rand(n) < 0.7]           # the detections that survived the reference's filtering steps
+            keep_ids += kept.tolist(); keep_frames += [f] * len(kept)
+        # a frame none of whose detections survives is not opened at all (frames_to_retrieve = det_df.frame.unique())
+        det_df = pd.DataFrame({"frame": keep_frames, "detection_id": keep_ids})
+        info = {"seq_path": tmp}
+        o1 = R.load_precomputed_embeddings(det_df, info, "emb1d", use_cuda=False, embedding_dim='1D')
+        o3 = R.load_precomputed_embeddings(det_df, info, "emb3d", use_cuda=False, embedding_dim='3D')
+    out.update(stored_1d=np.concatenate(stored1), stored_3d=np.concatenate(stored3), stored_frame=np.asarray(fr_of, np.int64),
+               det_frame=np.asarray(keep_frames, np.int64), det_id=np.asarray(keep_ids, np.int64),
+               out_1d=o1.numpy(), out_3d=o3.numpy())
+    np.savez_compressed(os.path.join(GOLD, "g8_embedding_files.npz"), **out)
+    print("g8_embedding_files.npz", {k: v.shape for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g2,g3")
+    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     os.makedirs(GOLD, exist_ok=True)
@@ -389,6 +437,7 @@ def main():
     if "g5" in only: gen_g5(mpn)
     if "g6" in only: gen_g6(mpn)
     if "g7" in only: gen_g7()
+    if "g8" in only: gen_g8()
     if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
     if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
 
