@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
         constexpr int TA = (T1 + 1) / 2, TB = T1 - TA;
         if constexpr (SP) {
-            chain_units<T1, 1, WIDEPIPE>(dE[i >> 1], i & 1, dz1, lds_addr(wbuf_at(c)) + lane * 16, T1, 0, 0);
+            chain_units<T1, 1>(dE[i >> 1], i & 1, dz1, lds_addr(wbuf_at(c)) + lane * 16, T1, 0, 0);
         } else {
             chain_half<TA>(dE[i >> 1], (i & 1) * 8, dz1, wbuf_at(c), HE, 4 * lh * HE + lj);
             if (TB > 0) chain_half<(TB > 0 ? TB : 1)>(dE[i >> 1], (i & 1) * 8, dz1 + TA, wbuf_at(c), HE, 4 * lh * HE + lj + 32 * TA);
@@ -983,8 +983,8 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
                 asm volatile("" : "+v"(dz1[2 * i]));
                 if (2 * i + 1 < T1) asm volatile("" : "+v"(dz1[2 * i + 1 < T1 ? 2 * i + 1 : 0]));
                 if (ncol6 == 64) {
-                    chain_units<2, 2, WIDEPIPE>(dz1[2 * i], 0, dc, wa, 2, 0, 0);
-                    if (2 * i + 1 < T1) chain_units<2, 2, WIDEPIPE>(dz1[2 * i + 1], 0, dc, wa, 2, 2, 0);
+                    chain_units<2, 2>(dz1[2 * i], 0, dc, wa, 2, 0, 0);
+                    if (2 * i + 1 < T1) chain_units<2, 2>(dz1[2 * i + 1], 0, dc, wa, 2, 2, 0);
                 } else {
                     chain_units<1, 2>(dz1[2 * i], 0, dc, wa, 1, 0, 0);
                     if (2 * i + 1 < T1) chain_units<1, 2>(dz1[2 * i + 1], 0, dc, wa, 1, 2, 0);
