@@ -698,7 +698,6 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     // ---- chunk schedule: [B2 | B3] (flow groups only) B4 B5 B6; float4 counts of the contiguous chunks ------------
     constexpr int NCH2 = DN / NR2, NCH3 = (HN + NR3 - 1) / NR3, NCH5 = DE / NR5, NCH6 = (HE + NR6 - 1) / NR6;
     constexpr int SCN = SP ? 3 : 2;                                // split images: 3/2 the size (edge_chain.hip, split8)
-    constexpr bool WIDEPIPE = T1 < 10;                             // B5 of the widest variant: no registers for a second operand set
     constexpr int N4_2 = NR2 * HN / 4 * SCN / 2;                   // 16 rows of Wf2
     constexpr int N4_3_0 = cmin(NR3, HN) * DE / 4 * SCN / 2;       // first 64 rows of Wfe
     constexpr int N4_4 = HC * DE / 4 * SCN / 2;                    // Wc1, whole
