@@ -6,6 +6,7 @@ namespace mpnhip {
 
 struct EdgeChainArgs {
     int E;                 // edges (sorted order)
+    int N;                 // nodes (rows of P): only checked against the kernel's 32-bit row offsets
     int split;             // 1: weight images are three-piece bf16 split images (pack_split), products from six bf16 MFMAs
     int he, de, hn, dn, hc;  // real widths; the kernel pads them to multiples of 32 (zero-padded weight images)
     const int* header;     // graph header: [1] = E_out, [2] = E_in

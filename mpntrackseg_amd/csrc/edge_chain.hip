@@ -1130,6 +1130,11 @@ bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k
 int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
     if (a_in.E <= 0) return MPNHIP_OK;
     EdgeChainArgs a = a_in;
+    // rows of P / Q0 / save_h1 are addressed as base + unsigned 32-bit element offset
+    if ((int64_t)a.E * a.he >= ((int64_t)1 << 32) || (int64_t)a.N * a.pw >= ((int64_t)1 << 32)) {
+        set_error("edge_chain: graph too large for 32-bit row offsets (E * he or N * pw >= 2^32)");
+        return MPNHIP_ERR_UNSUPPORTED;
+    }
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
 #ifdef MPNHIP_CHAIN_TS
     a.ts = g_stamp_fwd.prepare(blocks, s);

@@ -70,8 +70,17 @@ constexpr int min_waves(int tn) { return tn <= 2 ? 4 : (tn <= 4 ? 3 : 2); }
 
 // BF16: same loader / epilogue; the LDS images are row-major bf16 [m][k], [n][k] (k contiguous: the fp32 rows are
 // rounded and written without a transpose) and every MFMA operand is one ds_read_b128 of 8 consecutive k.
+// ... and what the LDS images allow: the split variant's three-piece images are 6 (BM + BN) PKB bytes per block
+constexpr int min_waves_lds(int wm, int wn, int tn, int prec) {
+    const int by_regs = min_waves(tn);
+    if (prec != 2) return by_regs;
+    const int lds = 3 * (32 * wm + 32 * tn * wn) * PKB * 2;
+    const int by_lds = 163840 / lds < 1 ? 1 : 163840 / lds;
+    return by_lds < by_regs ? by_lds : by_regs;
+}
+
 template <int WM, int WN, int TN, int BLAY, int PREC = 0>
-__global__ __launch_bounds__(NTHREADS, min_waves(TN)) void gemm_kernel(GemmArgs args) {
+__global__ __launch_bounds__(NTHREADS, min_waves_lds(WM, WN, TN, PREC)) void gemm_kernel(GemmArgs args) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr bool BF16 = PREC == 1, SPLIT = PREC == 2, LOWP = PREC != 0;
     constexpr int NIMG = SPLIT ? 3 : 1;                        // bf16 images per operand

@@ -271,7 +271,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     if (chain) {
         // (2)-(4) fused: edge MLP, classifier and both flow MLPs in one kernel (edge_chain.hip)
         EdgeChainArgs a = {};
-        a.E = (int)E; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm; a.split = cw->split ? 1 : 0;
+        a.E = (int)E; a.N = (int)N; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm; a.split = cw->split ? 1 : 0;
         a.he = d.he; a.de = d.de; a.hn = d.hn; a.dn = d.dn; a.hc = m.classifier.out_dims[0];
         a.xa = io.ea; a.ldxa = io.ldea; a.k1a = io.eb ? io.kea : d.ke;
         a.xb = io.eb; a.ldxb = io.ldeb; a.k1b = io.eb ? d.ke - io.kea : 0;
