@@ -489,6 +489,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         return MPNHIP_OK;
     };
 
+    // The re-attached x0 does not change from step to step: its share of dX (and of the packed projection weight's gradient)
+    // comes from the SUM of the steps' dP, once, after the loop
+    const bool hoist_x = d.nf == 2 && L > 1 && N > 0 && pw % 4 == 0 && dn % 4 == 0 && !getenv("MPNHIP_NO_DX0_HOIST");
     // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per
     // weight (batch index = step - 1).  Issued on `st` with the slab buffer `slab`.
     auto mp_weight_grads = [&](int b0, int nb, hipStream_t st, float* slab) -> int {
@@ -537,6 +540,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             }
         }
         {   // per-node projections (packed), accumulated into gWnode
+            if (hoist_x) {
+                // columns [dn, 2 dn) (the current features) here; the x0 columns are one product with the summed dP after the loop
+                float* gw[2] = {p.gWnode + dn, nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {p.dP + zb * N * pw, pw, (int64_t)N * pw}, nullptr, {f.x_hist + xs * zb, dn, (int64_t)xs},
+                                    {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr, N, nb, st));
+                return MPNHIP_OK;
+            }
             float* gw[2] = {p.gWnode, nullptr};
             const bool two = d.nf == 2;
             Operand h1 = two ? Operand{x0, dn, 0} : Operand{f.x_hist + xs * zb, dn, (int64_t)xs};
@@ -594,7 +604,6 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     };
     int next_group = 0;
     bool forked = false;
-    const bool hoist_x = d.nf == 2 && L > 1 && N > 0 && pw % 4 == 0 && dn % 4 == 0 && !getenv("MPNHIP_NO_DX0_HOIST");
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
@@ -708,6 +717,11 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         MPN_LAUNCH_CHECK();
         const float* Wa[2] = {f.Wnode, nullptr};
         MPN_TRY(act_grad(1, p.dPsum, pw, nullptr, Wa, kx, pw, dn, p.dX0, dn, nullptr, nullptr, 0, 1, nullptr, N, s));
+        // ... and the x0 columns [0, dn) of the packed projection weight's gradient: (sum of dP)^T x0 (disjoint from the columns the
+        // side stream accumulates; main-stream slab buffer)
+        float* gw[2] = {p.gWnode, nullptr};
+        MPN_TRY(weight_grad(p, p.slab, 1, {p.dPsum, pw, 0}, nullptr, {x0, dn, 0}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr,
+                            N, 1, s));
     }
     auto unpack_node_grads = [&]() -> int {
         // the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] back into the layers' grads (their biases were handled above)
