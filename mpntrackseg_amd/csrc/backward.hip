@@ -18,15 +18,20 @@
 namespace mpnhip {
 
 // ------------------------------------------------------------------------------------ small kernels
-// out = g (.) [act > 0]   (ReLU backward), float4
-__global__ void k_relu_mask(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out, int64_t n) {
+// out = (g (+ g2)) (.) [act > 0]   (ReLU backward), float4; g2: optional second addend (the other K half of a split product)
+__global__ void k_relu_mask(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ act,
+                            float* __restrict__ out, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         float4 a = *reinterpret_cast<const float4*>(act + i), v = *reinterpret_cast<const float4*>(g + i);
+        if (g2) {
+            const float4 w = *reinterpret_cast<const float4*>(g2 + i);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
         v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
         *reinterpret_cast<float4*>(out + i) = v;
     } else {
-        for (; i < n; ++i) out[i] = act[i] > 0.f ? g[i] : 0.f;
+        for (; i < n; ++i) out[i] = act[i] > 0.f ? g[i] + (g2 ? g2[i] : 0.f) : 0.f;
     }
 }
 
@@ -116,9 +121,9 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     dst[i] = src[(int64_t)idx[r] * cols + c];
 }
 
-static int relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s) {
+static int relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s, const float* g2 = nullptr) {
     if (n <= 0) return MPNHIP_OK;
-    hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, g, act, out, n);
+    hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, g, g2, act, out, n);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
@@ -150,6 +155,7 @@ static int side_stream_ready() {
 // batched split-row product over all L steps (12x fewer launches and slab reductions than per step).
 struct BwdPlan {
     float* dX[2];                       // [N, dn] ping-pong: gradient w.r.t. x_s
+    float* dXh;                         // [N, dn] second K half of the per-node projection's activation gradient (split product)
     float* dX0;                         // [N, dn] gradient w.r.t. the encoder's node output
     float* dE0;                         // [E, de]
     float* dAGG;                        // [N, 2dn]
@@ -193,6 +199,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     BwdPlan p = {};
     const size_t L = d.L > 0 ? d.L : 1;
     for (int i = 0; i < 2; ++i) p.dX[i] = a.f((size_t)N * d.dn);
+    p.dXh = a.f((size_t)N * d.dn);
     p.dX0 = a.f((size_t)N * d.dn);
     p.dPsum = a.f((size_t)N * d.pw);
     p.dE0 = a.f((size_t)E * d.de);
@@ -604,6 +611,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     };
     int next_group = 0;
     bool forked = false;
+    bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
@@ -622,7 +630,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         float* dEc = dzed[ne - 1];  // gradient w.r.t. e_s (seeded by the later step / the caller)
 
         // ---- A. node update  x_s = relu(AGG W^T + b)  (mpn.py:97-99) ---------------------------
-        MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s));
+        MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s, dx_split ? p.dXh : nullptr));
+        dx_split = false;
         {
             const float* Wq[2] = {m.node.weight[0], nullptr};
             MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
@@ -685,7 +694,22 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         // ---- F. per-node projections  P = [x0 | x_{s-1}] Wnode^T -----------------------------------
         {
             float* dXp = p.dX[cx ^ 1];
-            if (hoist_x) {
+            if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000) {
+                // [N, pw] x [pw, dn] is 157 tiles of 64 x 64 at cfg-B -- not enough blocks for 256 CUs and 34 K steps each: the two K
+                // halves run as the two groups of ONE grouped launch into dXp / dXh; the next step's ReLU-mask kernel adds them
+                GemmArgs a = {};
+                a.ngroups = 2; a.N = dn; a.K = pw / 2; a.ksplit = pw / 2; a.m_upper = 2 * N; a.small_tiles = 1;
+                for (int q = 0; q < 2; ++q) {
+                    GemmGroup& G = a.g[q];
+                    init_group(G);
+                    G.A = dP + q * (pw / 2); G.lda = pw;
+                    G.B = f.Wnode + dn + (size_t)q * (pw / 2) * kx; G.ldb = kx;
+                    G.C = q == 0 ? dXp : p.dXh; G.ldc = dn;
+                    G.m_static = N;
+                }
+                MPN_TRY(launch_gemm(a, A_KCONTIG, B_NCONTIG, s));
+                dx_split = true;
+            } else if (hoist_x) {
                 // only the x_{s-1} columns here (at step 1 x_0 IS x0); the re-attached x0's columns take the SUM of the steps'
                 // dP after the loop: one product instead of L
                 const float* Wa[2] = {f.Wnode + dn, nullptr};

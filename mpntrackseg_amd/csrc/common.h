@@ -83,6 +83,7 @@ struct GemmArgs {
     int accumulate;        // C += result (after relu, before the mask)
     int64_t m_upper;       // host-side upper bound of the total row count (sizes the grid)
     int epi_vec;           // set by launch_gemm: epilogue operands allow 16-byte vector access
+    int small_tiles;       // 1: take the 64 x 64 configuration whatever m_upper says (two K halves as two groups: m_upper = 2 M)
 };
 
 int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);

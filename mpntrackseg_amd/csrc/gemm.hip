@@ -518,7 +518,7 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
     const int N = a.N;
     const int64_t M = a.m_upper;
     const int nt = (N + 31) / 32;  // 32-wide column tiles needed
-    if (M >= 8192) {
+    if (M >= 8192 && !a.small_tiles) {
         // waves stacked along M (block 128 x 32 TN): pick the strip width that wastes the fewest tiles,
         // widest first (A is then re-read from L2 the fewest times)
         int best = 1, best_cost = 1 << 30;
