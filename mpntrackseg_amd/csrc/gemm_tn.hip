@@ -324,7 +324,10 @@ void tn_plan(TnArgs& a) {
     if (a.nbatch < 1) a.nbatch = 1;
     const int tbn = a.k_in <= 64 ? 64 : 128;
     int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn) * a.nbatch;
-    static const int blocks_wanted = [] { const char* e = getenv("MPNHIP_TN_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 1536; }();  // tuning override
+    // measured on MI355X (cfg-B / C / D training steps): 1024 blocks for the long products (>= 100k rows over the batch: the
+    // edge-level ones), 1536 for the short ones (node level, small graphs), which need the extra row chunks to fill the chip
+    static const int blocks_env = [] { const char* e = getenv("MPNHIP_TN_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 0; }();  // tuning override
+    const int blocks_wanted = blocks_env ? blocks_env : (a.m_upper * a.nbatch >= 100000 ? 1024 : 1536);
     int target = blocks_wanted / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
     if (target > 128) target = 128;
