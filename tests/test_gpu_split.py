@@ -125,3 +125,43 @@ def test_split_training_step_gradients_reproducible():
     assert close_enough(runs[0][1], gx, 2e-4, True) and close_enough(runs[0][2], gea, 2e-4, True)
     for k in pg:
         assert close_enough(runs[0][3][k], pg[k], 2e-4, True), k
+
+
+@pytest.mark.parametrize("case", ["one_edge_pair", "ragged_33", "only_out", "only_in", "self_loops_only", "isolated_nodes"])
+def test_split_ragged_and_degenerate_graphs(case):
+    """Tile edge cases of the split chain kernels at d = 128 (forward + every gradient against the oracle): fewer edges than a
+    wave tile, tile counts that are not multiples of the block, a graph with one direction only (the other group's blocks
+    are empty), self loops only (no flow MLP work at all), nodes without edges (empty segments)."""
+    n = 40
+    g = synth.make_graph(n, 66, T=5, seed=31, node_in_dim=48)
+    ei, ea = g["edge_index"], g["edge_attr"]
+    if case == "one_edge_pair":
+        sel = np.array([0, 33])
+    elif case == "ragged_33":
+        sel = np.arange(33)            # 33 out-edges -> two wave tiles, the second with one edge
+    elif case == "only_out":
+        sel = np.nonzero(ei[0] < ei[1])[0]
+    elif case == "only_in":
+        sel = np.nonzero(ei[0] > ei[1])[0]
+    elif case == "self_loops_only":
+        sel = np.arange(6)
+    else:
+        sel = np.nonzero((ei[0] < 20) & (ei[1] < 20))[0]   # nodes 20.. have no edges
+    ei, ea = ei[:, sel].copy(), ea[sel].copy()
+    if case == "self_loops_only":
+        ei[1] = ei[0]
+    gg = {"x": g["x"], "edge_index": ei, "edge_attr": ea}
+    params = synth.model_params(128, 3, "mean", node_in_dim=48)
+    W = synth.make_weights(params, seed=17)
+    import test_gpu_backward as tb
+    orig = tb.make_model
+
+    def split_model(p, w):
+        m = orig(p, w)
+        m.gemm_precision = "fp32_split"
+        return m
+    tb.make_model = split_model
+    try:
+        check_against_oracle(params, W, gg)
+    finally:
+        tb.make_model = orig
