@@ -239,6 +239,9 @@ struct StepIO {
     const float* P0;                      // optional: xa's share of the projections (+ biases), precomputed [N, pw];
                                           // then only xb is multiplied here (the weights are shared by all steps)
     const float* Q0;                      // optional (fused chain): ea's share of the edge MLP's first layer, [E, he]
+    int p_ready;                          // the previous step's fused node kernel already wrote this step's projections into b.P
+    int fuse_node;                        // 1: aggregate + node update (+ the NEXT step's projections unless `last`) in one launch
+    int last;                             //    (node_step32: inference at the reference's width, see node_step_fusable)
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -248,7 +251,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     const int64_t N = g.N, E = g.E;
     const int he = d.he, hn = d.hn;
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
-    {
+    if (!io.p_ready) {
         GemmArgs a = {};
         a.ngroups = 1; a.N = d.pw; a.relu = 0; a.m_upper = N;
         GemmGroup& G = a.g[0];
@@ -351,6 +354,11 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         MPN_TRY(mlp_tail(m.flow_out, &m.flow_in, &g, b.HF, b.M, d.dn, nullptr, E, s));
     }
     // (5) aggregation (node_agg_fn, mpn.py:89,96) and node update (mpn.py:97-99)
+    if (io.fuse_node) {
+        MPN_TRY(node_step32(g, b.M, m.agg, m.node.weight[0], m.node.bias[0], io.x_new, Wnode + io.kxa, d.kx, io.P0,
+                            io.last ? nullptr : b.P, d.pw, s));
+        return MPNHIP_OK;
+    }
     prof_begin(PROF_AGG, s);
     MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
     prof_end(PROF_AGG, s);
@@ -470,6 +478,11 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         G.A = e0; G.lda = d.de; G.B = m.edge.weight[0] + 2 * d.kx; G.ldb = m.edge.in_dim; G.C = p.Q0; G.ldc = d.he; G.m_static = E;
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
+    // inference at the reference's node width: the three node-side kernels of a step in one launch (segment.hip, node_step32);
+    // needs the hoisted P0 form of the projections, 16-byte aligned weights and the shared inference step buffers
+    const bool fuse_node = !save && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && m.precision != MPNHIP_PREC_BF16 &&
+                           ((((uintptr_t)m.node.weight[0]) | ((uintptr_t)p.P0) | ((uintptr_t)p.Wnode)) & 15) == 0 &&
+                           !getenv("MPNHIP_NO_NODE_FUSION");
     int prev = 0;
     for (int step = 0; step < d.L; ++step) {
         int cur = save ? step + 1 : 1 + (step & 1);
@@ -486,6 +499,9 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.logits = logits + (size_t)step * E;
         io.P0 = hoist ? p.P0 : nullptr;
         io.Q0 = hoist_e ? p.Q0 : nullptr;
+        io.fuse_node = fuse_node ? 1 : 0;
+        io.p_ready = fuse_node && step > 0 ? 1 : 0;
+        io.last = step + 1 == d.L ? 1 : 0;
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
         prev = cur;
     }

@@ -288,6 +288,117 @@ static int launch_seg(SegArgs a, hipStream_t stream) {
     return MPNHIP_OK;
 }
 
+// ---- fused node side of one inference step at the reference's width (dn = 32) ------------------------------------------
+// aggregate (node_agg_fn, mpn.py:89,96) -> node update x' = relu(W [agg_in | agg_out] + b) (mpn.py:97-99) -> the NEXT step's
+// per-node projections P = P0 + x' Wx^T, in ONE launch.  At these sizes (a few hundred nodes, 32-d features) the three
+// separate kernels are each at the ~4.5 us floor of a dependent launch; the work itself is a few microseconds.
+// Block = 2 nodes: one wave per (node, direction) segment (8 column lanes x 8 row lanes, four 16-byte row loads in flight per
+// lane, fixed shuffle tree across the row lanes), then the two small products with plain fp32 FMAs (W rows from L2).
+struct NodeStepArgs {
+    const float* msg;        // [E, 32] messages in sorted edge order
+    const int* seg_ptr;      // CSR over keys dir * N + row
+    int N, agg;
+    const float* Wu;         // node update Linear [32, 64] (nn.Linear layout), bias bu [32]
+    const float* bu;
+    float* x_new;            // [N, 32]
+    const float* Wx;         // projection weights of the CURRENT features: row p at Wx + p * ldwx, 32 columns
+    int64_t ldwx;
+    const float* P0;         // [N, pw] step-invariant share (+ biases)
+    float* P;                // [N, pw] out, or nullptr (last step)
+    int pw;
+};
+
+__global__ __launch_bounds__(256) void k_node_step32(NodeStepArgs a) {
+    __shared__ __attribute__((aligned(16))) float agg_s[2][64];
+    __shared__ __attribute__((aligned(16))) float x_s[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+    const int node_l = seg >> 1, dir = seg & 1;
+    const int node = blockIdx.x * 2 + node_l;
+    const bool node_ok = node < a.N;
+    // ---- aggregation: this wave's segment -----------------------------------------------------------------------
+    {
+        const int c4 = lane & 7, rl = lane >> 3;
+        const int key = dir * a.N + (node_ok ? node : 0);
+        const int beg = node_ok ? a.seg_ptr[key] : 0, end = node_ok ? a.seg_ptr[key + 1] : 0;
+        const bool is_max = a.agg == MPNHIP_AGG_MAX;
+        float4 acc = is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* base = a.msg + c4 * 4;
+        for (int j = beg + rl; j < end; j += 32) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + 8 * u < end ? j + 8 * u : end - 1;   // clamped: unconditional loads
+                v[u] = *reinterpret_cast<const float4*>(base + (int64_t)jj * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + 8 * u < end) {
+                    if (is_max) { acc.x = fmaxf(acc.x, v[u].x); acc.y = fmaxf(acc.y, v[u].y); acc.z = fmaxf(acc.z, v[u].z); acc.w = fmaxf(acc.w, v[u].w); }
+                    else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+        }
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {   // the 8 row lanes of a column: fixed tree
+            const float ox = __shfl_xor(acc.x, m, 64), oy = __shfl_xor(acc.y, m, 64), oz = __shfl_xor(acc.z, m, 64), ow = __shfl_xor(acc.w, m, 64);
+            if (is_max) { acc.x = fmaxf(acc.x, ox); acc.y = fmaxf(acc.y, oy); acc.z = fmaxf(acc.z, oz); acc.w = fmaxf(acc.w, ow); }
+            else { acc.x += ox; acc.y += oy; acc.z += oz; acc.w += ow; }
+        }
+        const int cnt = end - beg;
+        if (a.agg == MPNHIP_AGG_MEAN) { const float d = (float)(cnt > 0 ? cnt : 1); acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+        else if (is_max && cnt == 0) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // torch.cat((flow_in, flow_out)) (mpn.py:97): direction 0 (row < col, flow_out) is the right half
+        if (rl == 0) *reinterpret_cast<float4*>(&agg_s[node_l][(dir == 0 ? 32 : 0) + c4 * 4]) = acc;
+    }
+    __syncthreads();
+    // ---- node update: 64 outputs (2 nodes x 32), four threads per output over K = 64 ---------------------------------
+    {
+        const int o = tid >> 2, kq = tid & 3;
+        const int nl = o >> 5, c = o & 31;
+        const float* w = a.Wu + c * 64 + kq * 16;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + i);
+            const float4 av = *reinterpret_cast<const float4*>(&agg_s[nl][kq * 16 + i]);
+            s = fmaf(av.x, wv.x, s); s = fmaf(av.y, wv.y, s); s = fmaf(av.z, wv.z, s); s = fmaf(av.w, wv.w, s);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (kq == 0) {
+            const float xv = fmaxf(s + a.bu[c], 0.f);
+            x_s[nl][c] = xv;
+            if (blockIdx.x * 2 + nl < a.N) a.x_new[(int64_t)(blockIdx.x * 2 + nl) * 32 + c] = xv;
+        }
+    }
+    if (!a.P) return;   // (uniform)
+    __syncthreads();
+    // ---- the next step's projections of these two nodes: P = P0 + x' Wx^T -------------------------------------------------
+    for (int p = tid; p < a.pw; p += 256) {
+        const float* w = a.Wx + (int64_t)p * a.ldwx;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + i);
+            const float4 x0 = *reinterpret_cast<const float4*>(&x_s[0][i]);
+            const float4 x1 = *reinterpret_cast<const float4*>(&x_s[1][i]);
+            s0 = fmaf(x0.x, wv.x, s0); s0 = fmaf(x0.y, wv.y, s0); s0 = fmaf(x0.z, wv.z, s0); s0 = fmaf(x0.w, wv.w, s0);
+            s1 = fmaf(x1.x, wv.x, s1); s1 = fmaf(x1.y, wv.y, s1); s1 = fmaf(x1.z, wv.z, s1); s1 = fmaf(x1.w, wv.w, s1);
+        }
+        const int n0 = blockIdx.x * 2;
+        if (n0 < a.N) a.P[(int64_t)n0 * a.pw + p] = a.P0[(int64_t)n0 * a.pw + p] + s0;
+        if (n0 + 1 < a.N) a.P[(int64_t)(n0 + 1) * a.pw + p] = a.P0[(int64_t)(n0 + 1) * a.pw + p] + s1;
+    }
+}
+
+int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, const float* bu, float* x_new, const float* Wx,
+                int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream) {
+    if (g.N <= 0) return MPNHIP_OK;
+    NodeStepArgs a = {msg, g.seg_ptr, g.N, agg, Wu, bu, x_new, Wx, ldwx, P0, P, pw};
+    hipLaunchKernelGGL(k_node_step32, dim3((unsigned)((g.N + 1) / 2)), dim3(256), 0, stream, a);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
 int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out, int* argmax, hipStream_t stream) {
     SegArgs a = {};
     a.src = src;
