@@ -150,9 +150,10 @@ size_t graph_layout(int N, int64_t E, GraphView* view, void* base);
 // out[n][0:dim] = AGG over in-segment(n), out[n][dim:2dim] = AGG over out-segment(n)
 // (torch.cat((flow_in, flow_out)), mpn.py:97); src rows in sorted edge order.
 int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out, int* argmax, hipStream_t stream);
-// inference, dn = 32: aggregate -> node update -> next step's projections (P = P0 + x' Wx^T; P = nullptr: none) in one launch
-int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, const float* bu, float* x_new, const float* Wx,
-                int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream);
+// dn = 32: aggregate -> node update -> next step's projections (P = P0 + x' Wx^T; P = nullptr: none) in one launch; agg_out:
+// the aggregated messages [N, 64] for the backward pass (training) or nullptr
+int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, const float* bu, float* x_new, float* agg_out,
+                const float* Wx, int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream);
 // generic: out[s][:] = AGG_{j in [ptr[s], ptr[s+1])} src[list ? list[j] : j][:]; out leading dim ldo
 int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, int agg,
                        float* out, int64_t ldo, int* argmax, int accumulate, hipStream_t stream);

@@ -241,7 +241,8 @@ struct StepIO {
     const float* Q0;                      // optional (fused chain): ea's share of the edge MLP's first layer, [E, he]
     int p_ready;                          // the previous step's fused node kernel already wrote this step's projections into b.P
     int fuse_node;                        // 1: aggregate + node update (+ the NEXT step's projections unless `last`) in one launch
-    int last;                             //    (node_step32: inference at the reference's width, see node_step_fusable)
+    int last;                             //    (node_step32: the reference's node width)
+    float* P_next;                        //    where the next step's projections go (its step buffers; inference: the shared ones)
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -355,8 +356,8 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     }
     // (5) aggregation (node_agg_fn, mpn.py:89,96) and node update (mpn.py:97-99)
     if (io.fuse_node) {
-        MPN_TRY(node_step32(g, b.M, m.agg, m.node.weight[0], m.node.bias[0], io.x_new, Wnode + io.kxa, d.kx, io.P0,
-                            io.last ? nullptr : b.P, d.pw, s));
+        MPN_TRY(node_step32(g, b.M, m.agg, m.node.weight[0], m.node.bias[0], io.x_new, save_acts ? b.AGG : nullptr, Wnode + io.kxa, d.kx,
+                            io.P0, io.last ? nullptr : io.P_next, d.pw, s));
         return MPNHIP_OK;
     }
     prof_begin(PROF_AGG, s);
@@ -478,9 +479,11 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         G.A = e0; G.lda = d.de; G.B = m.edge.weight[0] + 2 * d.kx; G.ldb = m.edge.in_dim; G.C = p.Q0; G.ldc = d.he; G.m_static = E;
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
-    // inference at the reference's node width: the three node-side kernels of a step in one launch (segment.hip, node_step32);
-    // needs the hoisted P0 form of the projections, 16-byte aligned weights and the shared inference step buffers
-    const bool fuse_node = !save && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && m.precision != MPNHIP_PREC_BF16 &&
+    // the reference's node width: the three node-side kernels of a step in one launch (segment.hip, node_step32); needs the
+    // hoisted P0 form of the projections and 16-byte aligned weights; training with max aggregation keeps the separate
+    // kernels (the fused one does not record the arg max)
+    // (every 2-node block re-reads the 43 KB of node-side weights from L2: beyond a few thousand nodes the GEMMs win again)
+    const bool fuse_node = (!save || m.agg != MPNHIP_AGG_MAX) && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && N <= 4096 && m.precision != MPNHIP_PREC_BF16 &&
                            ((((uintptr_t)m.node.weight[0]) | ((uintptr_t)p.P0) | ((uintptr_t)p.Wnode)) & 15) == 0 &&
                            !getenv("MPNHIP_NO_NODE_FUSION");
     int prev = 0;
@@ -502,6 +505,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.fuse_node = fuse_node ? 1 : 0;
         io.p_ready = fuse_node && step > 0 ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
+        io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
         prev = cur;
     }

@@ -301,6 +301,7 @@ struct NodeStepArgs {
     const float* Wu;         // node update Linear [32, 64] (nn.Linear layout), bias bu [32]
     const float* bu;
     float* x_new;            // [N, 32]
+    float* agg_out;          // [N, 64] aggregated messages kept for the backward pass (training), or nullptr
     const float* Wx;         // projection weights of the CURRENT features: row p at Wx + p * ldwx, 32 columns
     int64_t ldwx;
     const float* P0;         // [N, pw] step-invariant share (+ biases)
@@ -350,6 +351,11 @@ __global__ __launch_bounds__(256) void k_node_step32(NodeStepArgs a) {
         if (rl == 0) *reinterpret_cast<float4*>(&agg_s[node_l][(dir == 0 ? 32 : 0) + c4 * 4]) = acc;
     }
     __syncthreads();
+    if (a.agg_out && tid < 32) {   // (training) [flow_in | flow_out] of the two nodes, 16 bytes per thread
+        const int nl = tid >> 4, q = tid & 15;
+        if (blockIdx.x * 2 + nl < a.N)
+            *reinterpret_cast<float4*>(a.agg_out + (int64_t)(blockIdx.x * 2 + nl) * 64 + q * 4) = *reinterpret_cast<const float4*>(&agg_s[nl][q * 4]);
+    }
     // ---- node update: 64 outputs (2 nodes x 32), four threads per output over K = 64 ---------------------------------
     {
         const int o = tid >> 2, kq = tid & 3;
@@ -390,10 +396,10 @@ __global__ __launch_bounds__(256) void k_node_step32(NodeStepArgs a) {
     }
 }
 
-int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, const float* bu, float* x_new, const float* Wx,
-                int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream) {
+int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, const float* bu, float* x_new, float* agg_out,
+                const float* Wx, int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream) {
     if (g.N <= 0) return MPNHIP_OK;
-    NodeStepArgs a = {msg, g.seg_ptr, g.N, agg, Wu, bu, x_new, Wx, ldwx, P0, P, pw};
+    NodeStepArgs a = {msg, g.seg_ptr, g.N, agg, Wu, bu, x_new, agg_out, Wx, ldwx, P0, P, pw};
     hipLaunchKernelGGL(k_node_step32, dim3((unsigned)((g.N + 1) / 2)), dim3(256), 0, stream, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;

@@ -50,20 +50,23 @@ class FlatBucket:
 
     def __init__(self, params):
         self.params = list(params)
-        n = sum(p.numel() for p in self.params)
+        # every parameter starts on a 16-byte boundary of the flat buffers (padding stays zero: zero gradient, zero update), so
+        # that the kernels' 16-byte operand paths apply to the views exactly as to separately allocated tensors
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views = {}
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, offs):
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views[id(p)] = v
             pv = self.flat_params[off:off + p.numel()].view_as(p)
             pv.copy_(p.data)
             p.data = pv
             p.grad = v
-            off += p.numel()
 
     def zero_(self):
         self.flat.zero_()

@@ -26,7 +26,10 @@ def test_flat_bucket_views_alias_param_grads():
     lin = [torch.nn.Linear(5, 3), torch.nn.Linear(3, 1)]
     params = [p for l in lin for p in l.parameters()]
     b = FlatBucket(params)
-    assert b.flat.numel() == sum(p.numel() for p in params)
+    # every parameter starts on a 16-byte boundary of the flat buffers (sizes rounded up to 4 floats; the padding stays zero)
+    assert b.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in params)
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in params)
+    assert all(p.data_ptr() >= b.flat_params.data_ptr() for p in params)
     b.views[id(params[0])].fill_(2.0)
     assert params[0].grad is not None and float(params[0].grad.sum()) == 2.0 * params[0].numel()
     assert float(b.flat.sum()) == 2.0 * params[0].numel()
