@@ -650,11 +650,18 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             a.wc1 = p.wc1p; a.wc2 = cls.weight[1]; a.w2 = p.w2p; a.w1e = p.w1ep;
             MPN_TRY(launch_edge_chain_bwd(a, s));
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
-            MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s, E));
-            // (by row: the sorted order IS (direction, row), so a node's rows are three contiguous runs of the CSR -- no list)
-            if (E >= 48 * N) MPN_TRY(segment_reduce_csr2(dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E));
-            else MPN_TRY(segment_reduce_csr2(dzed[0], he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E, 3, (int)N));
-            MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s, E));
+            if (E >= 48 * N) {
+                // dense graphs (long segments): the three reductions as ONE launch of the block-per-segment kernel
+                const SegReduce2 c3[3] = {{dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn},
+                                          {dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0},
+                                          {dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he}};
+                MPN_TRY(segment_reduce_csr2_x3(c3, E, s));
+            } else {
+                MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s, E));
+                // (by row: the sorted order IS (direction, row), so a node's rows are three contiguous runs of the CSR -- no list)
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E, 3, (int)N));
+                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s, E));
+            }
         } else if (E > 0) {
             // ---- B. aggregation backward + ReLU of the last flow layer ---------------------------
             {

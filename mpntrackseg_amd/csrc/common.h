@@ -162,6 +162,11 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
                         int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows = 0, int runs = 1,
                         int run_stride = 0);
+// one segment_reduce_csr2 call as data; segment_reduce_csr2_x3: three of them, in one launch where the block kernel applies
+struct SegReduce2 {
+    const float* src; int64_t lds; const int* list; const int* ptr; int nseg; int dim; float* out; int64_t ldo; int nmod; int off0; int off1;
+};
+int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream);
 
 // in-stream event timing of two designated kernels (see mpnhip_profile_enable)
 enum { PROF_GEMM = 0, PROF_AGG = 1 };

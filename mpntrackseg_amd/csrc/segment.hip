@@ -178,10 +178,7 @@ __global__ __launch_bounds__(256) void k_aggregate(SegArgs a) {
 // lanes cover the columns (16 bytes each), 256 / sub row lanes stride over the segment's rows, and the row lanes'
 // partial results are combined in a fixed tree through LDS -- deterministic, but not the sequential order of the
 // short-segment kernels.  dim % 4 == 0, dim <= 4 * 64.
-__global__ __launch_bounds__(256) void k_segment_reduce_block(SegArgs a) {
-    __shared__ float4 redv[256];
-    __shared__ int4 redi[256];
-    const int s = blockIdx.x;
+__device__ __forceinline__ void seg_block_body(const SegArgs& a, const int s, float4* redv, int4* redi) {
     const int sub = a.sub, rl_n = 256 / sub;
     const int cl = threadIdx.x % sub, rl = threadIdx.x / sub;
     const int beg = a.ptr[s], end = a.ptr[s + 1];
@@ -249,8 +246,36 @@ __global__ __launch_bounds__(256) void k_segment_reduce_block(SegArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_segment_reduce_block(SegArgs a) {
+    __shared__ float4 redv[256];
+    __shared__ int4 redi[256];
+    seg_block_body(a, blockIdx.x, redv, redi);
+}
+
+// three independent reductions in one launch (the backward's scatter-adds of a step on dense graphs: each alone is a few
+// hundred blocks and ~10 us, mostly launch floor and tail); the branch is block-uniform and every call site reads its own
+// kernel argument (selecting a struct by index would copy it to scratch)
+__global__ __launch_bounds__(256) void k_segment_reduce_block3(SegArgs a0, SegArgs a1, SegArgs a2) {
+    __shared__ float4 redv[256];
+    __shared__ int4 redi[256];
+    const int b = blockIdx.x;
+    if (b < a0.nseg) seg_block_body(a0, b, redv, redi);
+    else if (b < a0.nseg + a1.nseg) seg_block_body(a1, b - a0.nseg, redv, redi);
+    else seg_block_body(a2, b - a0.nseg - a1.nseg, redv, redi);
+}
+
 // average segment length above which the block-per-segment kernel is used
 constexpr int64_t LONG_SEGMENT = 48;
+
+static bool block_eligible(SegArgs& a, int64_t total_rows) {
+    const bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
+                     (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.out & 15) == 0) && (!a.argmax || ((uintptr_t)a.argmax & 15) == 0);
+    if (!vec || a.dim > 256 || a.nseg <= 0 || total_rows < LONG_SEGMENT * a.nseg) return false;
+    int sub = 1;
+    while (sub < a.dim / 4) sub <<= 1;
+    a.sub = sub;
+    return true;
+}
 
 static bool try_launch_block(SegArgs& a, int64_t total_rows, hipStream_t stream) {
     const bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
@@ -477,6 +502,27 @@ int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const in
         return MPNHIP_OK;
     }
     return launch_seg(a, stream);
+}
+
+static SegArgs seg_args2(const SegReduce2& c) {
+    SegArgs a = {};
+    a.src = c.src; a.lds = c.lds; a.list = c.list; a.ptr = c.ptr; a.nseg = c.nseg; a.dim = c.dim; a.agg = MPNHIP_AGG_SUM;
+    a.out = c.out; a.ldo = c.ldo; a.nmod = c.nmod > 0 ? c.nmod : 1; a.off0 = c.off0; a.off1 = c.off1;
+    return a;
+}
+
+// three segment_reduce_csr2 calls; ONE launch when all three take the block-per-segment kernel (dense graphs)
+int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream) {
+    SegArgs a[3] = {seg_args2(c[0]), seg_args2(c[1]), seg_args2(c[2])};
+    if (block_eligible(a[0], total_rows) && block_eligible(a[1], total_rows) && block_eligible(a[2], total_rows)) {
+        hipLaunchKernelGGL(k_segment_reduce_block3, dim3(a[0].nseg + a[1].nseg + a[2].nseg), dim3(256), 0, stream, a[0], a[1], a[2]);
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
+    for (int i = 0; i < 3; ++i)
+        MPN_TRY(segment_reduce_csr2(c[i].src, c[i].lds, c[i].list, c[i].ptr, c[i].nseg, c[i].dim, c[i].out, c[i].ldo, c[i].nmod, c[i].off0,
+                                    c[i].off1, stream, total_rows));
+    return MPNHIP_OK;
 }
 
 // ---- stand-alone node_agg_fn with an arbitrary (unsorted) int64 index ---------------------------
