@@ -612,6 +612,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     int next_group = 0;
     bool forked = false;
     bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
+    bool node_a_done = false;   // dZn / dAGG of the coming step were already produced by node_step32_bwd
+    const bool fuse_node_bwd = dn == 32 && N <= 4096 && pw <= 1088 && !getenv("MPNHIP_NO_NODE_FUSION");
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step
@@ -630,12 +632,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         float* dEc = dzed[ne - 1];  // gradient w.r.t. e_s (seeded by the later step / the caller)
 
         // ---- A. node update  x_s = relu(AGG W^T + b)  (mpn.py:97-99) ---------------------------
-        MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s, dx_split ? p.dXh : nullptr));
-        dx_split = false;
-        {
+        if (!node_a_done) {
+            MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s, dx_split ? p.dXh : nullptr));
             const float* Wq[2] = {m.node.weight[0], nullptr};
             MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
         }
+        dx_split = false;
+        node_a_done = false;
         if (use_chain) {
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
             EdgeChainBwdArgs a = {};
@@ -701,7 +704,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         // ---- F. per-node projections  P = [x0 | x_{s-1}] Wnode^T -----------------------------------
         {
             float* dXp = p.dX[cx ^ 1];
-            if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000) {
+            if (hoist_x && step > 1 && fuse_node_bwd) {
+                // the reference's node width: this product, the previous step's ReLU mask and its node-update activation gradient
+                // in one launch (segment.hip, node_step32_bwd); the next iteration starts at the chain kernel
+                MPN_TRY(node_step32_bwd(dP, (int)N, pw, f.Wnode + dn, kx, f.x_hist + xs * (step - 1), m.node.weight[0],
+                                        p.dZn + (size_t)(b_ - 1) * xs, p.dAGG, s));
+                node_a_done = true;
+            } else if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000) {
                 // [N, pw] x [pw, dn] is 157 tiles of 64 x 64 at cfg-B -- not enough blocks for 256 CUs and 34 K steps each: the two K
                 // halves run as the two groups of ONE grouped launch into dXp / dXh; the next step's ReLU-mask kernel adds them
                 GemmArgs a = {};

@@ -162,6 +162,9 @@ int segment_reduce_csr(const float* src, int64_t lds, const int* list, const int
 int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const int* ptr, int nseg, int dim, float* out,
                         int64_t ldo, int nmod, int off0, int off1, hipStream_t stream, int64_t total_rows = 0, int runs = 1,
                         int run_stride = 0);
+// dn = 32 backward: dX = dP Wx, dZn = dX (.) [x_prev > 0], dAGG = dZn Wu in one launch (segment.hip)
+int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldwx, const float* x_prev, const float* Wu, float* dZn,
+                    float* dAGG, hipStream_t stream);
 // one segment_reduce_csr2 call as data; segment_reduce_csr2_x3: three of them, in one launch where the block kernel applies
 struct SegReduce2 {
     const float* src; int64_t lds; const int* list; const int* ptr; int nseg; int dim; float* out; int64_t ldo; int nmod; int off0; int off1;

@@ -430,6 +430,70 @@ int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, 
     return MPNHIP_OK;
 }
 
+// Backward counterpart at the same width: the activation gradient of step s's projections, the ReLU mask of the node update of
+// step s - 1 and that update's activation gradient, for two nodes per block (fp32 FMAs, weight rows from L2):
+//   dX = dP Wx  ([pw] x [pw, 32]);   dZn = dX (.) [x_{s-1} > 0];   dAGG = dZn Wu  ([32] x [32, 64])
+// -- three dependent launches (a grouped GEMM, k_relu_mask, a GEMM) in one.
+struct NodeStepBwdArgs {
+    const float* dP;         // [N, pw] gradient of this step's projections
+    int N, pw;
+    const float* Wx;         // rows p of the packed projection weights, current-feature columns: Wx + p * ldwx, 32 columns
+    int64_t ldwx;
+    const float* x_prev;     // [N, 32] output of the previous step's node update (its ReLU mask)
+    const float* Wu;         // node update Linear [32, 64]
+    float* dZn;              // [N, 32] out: gradient at the previous step's node-update pre-activation
+    float* dAGG;             // [N, 64] out
+};
+
+__global__ __launch_bounds__(256) void k_node_step32_bwd(NodeStepBwdArgs a) {
+    __shared__ float dp_s[2][1088 + 4];    // the two nodes' dP rows (pw <= 1088)
+    __shared__ float part[4][64];
+    __shared__ float dz_s[2][32];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 2;
+    for (int i = tid; i < 2 * a.pw; i += 256) {
+        const int nl = i >= a.pw ? 1 : 0, pidx = i - nl * a.pw;
+        dp_s[nl][pidx] = n0 + nl < a.N ? a.dP[(int64_t)(n0 + nl) * a.pw + pidx] : 0.f;
+    }
+    __syncthreads();
+    {   // dX: 64 outputs, the contraction over pw split over four thread groups (fixed order when they meet)
+        const int o = tid & 63, kq = tid >> 6;
+        const int nl = o >> 5, c = o & 31;
+        const int per = (a.pw + 3) / 4, p0 = kq * per, p1 = p0 + per < a.pw ? p0 + per : a.pw;
+        float s = 0.f;
+        for (int pp = p0; pp < p1; ++pp) s = fmaf(dp_s[nl][pp], a.Wx[(int64_t)pp * a.ldwx + c], s);
+        part[kq][o] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int nl = tid >> 5, c = tid & 31;
+        const float dx = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        const bool ok = n0 + nl < a.N;
+        const float xv = ok ? a.x_prev[(int64_t)(n0 + nl) * 32 + c] : 0.f;
+        const float dz = xv > 0.f ? dx : 0.f;
+        dz_s[nl][c] = dz;
+        if (ok) a.dZn[(int64_t)(n0 + nl) * 32 + c] = dz;
+    }
+    __syncthreads();
+    if (tid < 128) {   // dAGG: 2 nodes x 64 outputs, 32 FMAs each
+        const int nl = tid >> 6, j = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) s = fmaf(dz_s[nl][c], a.Wu[c * 64 + j], s);
+        if (n0 + nl < a.N) a.dAGG[(int64_t)(n0 + nl) * 64 + j] = s;
+    }
+}
+
+int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldwx, const float* x_prev, const float* Wu, float* dZn,
+                    float* dAGG, hipStream_t stream) {
+    if (N <= 0) return MPNHIP_OK;
+    if (pw > 1088) { set_error("node_step32_bwd: projection width too large"); return MPNHIP_ERR_UNSUPPORTED; }
+    NodeStepBwdArgs a = {dP, N, pw, Wx, ldwx, x_prev, Wu, dZn, dAGG};
+    hipLaunchKernelGGL(k_node_step32_bwd, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, stream, a);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
 int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out, int* argmax, hipStream_t stream) {
     SegArgs a = {};
     a.src = src;
