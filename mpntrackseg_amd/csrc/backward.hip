@@ -570,7 +570,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready() == MPNHIP_OK;
     // Group sizes (in steps, first-finished group first).  The side stream is serial, so the last group should be the
     // smallest: it starts only when the loop is over and what it has not finished when the encoder's backward ends is
-    // exposed.  Default for L = 12: 5 + 4 + 3; in general three groups with sizes ~ (5 : 4 : 3), two below six steps.
+    // exposed.  Default for L = 12: 5 + 4 + 3; in general three groups with sizes ~ (5 : 4 : 3), two below six steps or when
+    // the products are small.
     int gsize[8] = {0};
     int ngroups = 1;
     if (want_fork) {
@@ -590,7 +591,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         for (int i = 0; i < parsed; ++i) ok = ok && gsize[i] > 0;
         if (ok) {
             ngroups = parsed;
-        } else if (L >= 6) {
+        } else if (L >= 6 && (double)E * dn * dn >= 3e8) {
+            // (enough work per group to pay for a third round of ~30 launches: cfg-B 8e8; the reference's 32-d widths, 8e7 at
+            // cfg-C, do better with two groups -- measured 2.59 -> 2.48 ms)
             ngroups = 3;
             gsize[0] = (int)((5 * L + 6) / 12);
             gsize[2] = (int)(L / 4);
