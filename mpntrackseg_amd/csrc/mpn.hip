@@ -367,6 +367,72 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     return MPNHIP_OK;
 }
 
+// ---- the reference's edge encoder (6 -> 18 -> 18 -> 16, ReLU after every layer; tracking_cfg.yaml:136-139) in one launch ----
+// Three Linear layers this narrow are three launches of the any-shape GEMM kernel (one thread per OUTPUT element, ~25 us each at
+// 78k edges): here one thread carries one edge through all three layers (720 FMAs), the weights sit in LDS and are read as
+// broadcasts, the hidden activations stay in registers (written out only when the backward pass needs them).
+template <int IN, int H1, int H2, int OUT>
+__global__ __launch_bounds__(256) void k_edge_encoder(const float* __restrict__ x, const int* __restrict__ idx, int64_t rows,
+                                                      const float* __restrict__ w0, const float* __restrict__ b0,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ h1_out, float* __restrict__ h2_out, float* __restrict__ y) {
+    __shared__ float sw0[H1 * IN], sb0[H1], sw1[H2 * H1], sb1[H2], sw2[OUT * H2], sb2[OUT];
+    for (int i = threadIdx.x; i < H1 * IN; i += 256) sw0[i] = w0[i];
+    for (int i = threadIdx.x; i < H2 * H1; i += 256) sw1[i] = w1[i];
+    for (int i = threadIdx.x; i < OUT * H2; i += 256) sw2[i] = w2[i];
+    if (threadIdx.x < H1) sb0[threadIdx.x] = b0[threadIdx.x];
+    if (threadIdx.x < H2) sb1[threadIdx.x] = b1[threadIdx.x];
+    if (threadIdx.x < OUT) sb2[threadIdx.x] = b2[threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (int64_t)(idx ? idx[r] : r) * IN;
+    float a[IN], h1[H1], h2[H2];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) a[k] = xr[k];
+#pragma unroll
+    for (int o = 0; o < H1; ++o) {
+        float s = sb0[o];
+#pragma unroll
+        for (int k = 0; k < IN; ++k) s = fmaf(a[k], sw0[o * IN + k], s);
+        h1[o] = fmaxf(s, 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < H2; ++o) {
+        float s = sb1[o];
+#pragma unroll
+        for (int k = 0; k < H1; ++k) s = fmaf(h1[k], sw1[o * H1 + k], s);
+        h2[o] = fmaxf(s, 0.f);
+    }
+    if (h1_out) {
+#pragma unroll
+        for (int o = 0; o < H1; ++o) h1_out[r * H1 + o] = h1[o];
+#pragma unroll
+        for (int o = 0; o < H2; ++o) h2_out[r * H2 + o] = h2[o];
+    }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        float s = sb2[o];
+#pragma unroll
+        for (int k = 0; k < H2; ++k) s = fmaf(h2[k], sw2[o * H2 + k], s);
+        y[r * OUT + o] = fmaxf(s, 0.f);
+    }
+}
+
+// true (and launched) when `m` is exactly that encoder; hidden[0..1] = where the backward wants the activations, or nullptr
+static bool edge_encoder_fused(const mpnhip_mlp& m, const float* x, const int* idx, float* const* hidden, bool keep_hidden, float* y,
+                               int64_t rows, hipStream_t s, int* status) {
+    *status = MPNHIP_OK;
+    if (getenv("MPNHIP_NO_ENCODER_FUSION")) return false;
+    if (m.n_layers != 3 || m.in_dim != 6 || m.out_dims[0] != 18 || m.out_dims[1] != 18 || m.out_dims[2] != 16 || rows <= 0) return false;
+    hipLaunchKernelGGL((k_edge_encoder<6, 18, 18, 16>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, idx, rows, m.weight[0],
+                       m.bias[0], m.weight[1], m.bias[1], m.weight[2], m.bias[2], keep_hidden ? hidden[0] : nullptr,
+                       keep_hidden ? hidden[1] : nullptr, y);
+    if (hipGetLastError() != hipSuccess) { set_error("edge encoder: launch failed"); *status = MPNHIP_ERR_HIP; }
+    return true;
+}
+
 // full MLP (all layers) with ping-pong or per-layer hidden buffers; a_idx permutes the input rows
 static int mlp_forward(const mpnhip_mlp& m, const float* x, int64_t ldx, const int* a_idx, float* const* hidden, float* y,
                        int64_t rows, hipStream_t s) {
@@ -452,7 +518,13 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     hidden_ptrs(m.enc_node, p.enc_n, N, save != 0, hid);
     MPN_TRY(mlp_forward(m.enc_node, x, m.enc_node.in_dim, nullptr, hid, x0, N, s));
     hidden_ptrs(m.enc_edge, p.enc_e, E, save != 0, hid);
-    MPN_TRY(mlp_forward(m.enc_edge, edge_attr, m.enc_edge.in_dim, g.perm, hid, e0, E, s));
+    {
+        int st = MPNHIP_OK;
+        // (bf16-operand mode: every Linear product rounds its operands -- the GEMM path does that, the fused kernel is fp32)
+        if (m.precision == MPNHIP_PREC_BF16 || !edge_encoder_fused(m.enc_edge, edge_attr, g.perm, hid, save != 0, e0, E, s, &st))
+            MPN_TRY(mlp_forward(m.enc_edge, edge_attr, m.enc_edge.in_dim, g.perm, hid, e0, E, s));
+        else if (st != MPNHIP_OK) return st;
+    }
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
     const bool hoist = d.nf == 2 && d.L > 1;
