@@ -167,6 +167,7 @@ struct BwdPlan {
     float* dZed[MPNHIP_MAX_LAYERS];     // edge MLP layer i:   [L][E, out_i]  (last layer: the masked dE_s)
     float* dZcl[MPNHIP_MAX_LAYERS];     // classifier layer i: [L][E, out_i]  (i < n-1; the last one is grad_logits)
     float* T[2];                        // encoder chain scratch [max(E,N), max encoder width]
+    int t_width;                        // that width (floats per row)
     // zero-padded copies of the per-edge weights for the fused backward chain (native [n][k] orientation)
     float* wf2p[2]; float* wfep[2]; float* wc1p; float* w2p; float* w1ep;
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
@@ -216,6 +217,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     int64_t rows = E > N ? E : N;
     int mw = enc_maxw(m, d);
     for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
+    p.t_width = (int)mw;
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
         // (sized for the split images, 3/2 of the fp32 ones)
@@ -350,6 +352,43 @@ static int mlp_weight_grads(const BwdPlan& p, float* slab_base, const mpnhip_mlp
 }
 
 // encoder-style chain with ping-pong scratch (one batch): returns dZ of layer 0 in *dz
+// ---- the reference's edge encoder (6 -> 18 -> 18 -> 16) backwards: the three activation gradients of an edge in one thread ------
+//   dz2 = dE0 (.) [e0 > 0];   dz1 = (dz2 W2) (.) [H2 > 0];   dz0 = (dz1 W1) (.) [H1 > 0]
+// (instead of a ReLU-mask kernel and two launches of the any-shape GEMM kernel; the weight-gradient products read dz2 / dz1 / dz0)
+template <int H1W, int H2W, int OUTW>
+__global__ __launch_bounds__(256) void k_edge_encoder_bwd(const float* __restrict__ dE0, const float* __restrict__ e0,
+                                                          const float* __restrict__ h2, const float* __restrict__ h1,
+                                                          const float* __restrict__ w2, const float* __restrict__ w1, int64_t rows,
+                                                          float* __restrict__ dz2, float* __restrict__ dz1, float* __restrict__ dz0) {
+    __shared__ float sw2[OUTW * H2W], sw1[H2W * H1W];
+    for (int i = threadIdx.x; i < OUTW * H2W; i += 256) sw2[i] = w2[i];
+    for (int i = threadIdx.x; i < H2W * H1W; i += 256) sw1[i] = w1[i];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float g2[OUTW], g1[H2W];
+#pragma unroll
+    for (int o = 0; o < OUTW; ++o) {
+        g2[o] = e0[r * OUTW + o] > 0.f ? dE0[r * OUTW + o] : 0.f;
+        dz2[r * OUTW + o] = g2[o];
+    }
+#pragma unroll
+    for (int k = 0; k < H2W; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < OUTW; ++o) s = fmaf(g2[o], sw2[o * H2W + k], s);
+        g1[k] = h2[r * H2W + k] > 0.f ? s : 0.f;
+        dz1[r * H2W + k] = g1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < H1W; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < H2W; ++o) s = fmaf(g1[o], sw1[o * H1W + k], s);
+        dz0[r * H1W + k] = h1[r * H1W + k] > 0.f ? s : 0.f;
+    }
+}
+
 static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, float* const* hidden, const float** dz, int* cur_buf,
                              int64_t rows, hipStream_t s) {
     for (int i = m0.n_layers - 1; i >= 1; --i) {
@@ -854,7 +893,29 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         const mpnhip_mlp& ee = m.enc_edge;
         const float* dz = p.dE0;
         int cur = 0;
-        if (E > 0) {
+        const bool ref_encoder = ee.n_layers == 3 && ee.in_dim == 6 && ee.out_dims[0] == 18 && ee.out_dims[1] == 18 && ee.out_dims[2] == 16 &&
+                                 p.t_width >= 52 && !getenv("MPNHIP_NO_ENCODER_FUSION");
+        if (E > 0 && ref_encoder) {
+            // the reference's edge encoder: all three activation gradients in one launch (dz2 | dz1 | dz0 side by side in T[0]),
+            // then the weight-gradient products as before
+            float* dz2 = p.T[0];
+            float* dz1 = dz2 + (size_t)E * 16;
+            float* dz0 = dz1 + (size_t)E * 18;
+            hipLaunchKernelGGL((k_edge_encoder_bwd<18, 18, 16>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, p.dE0, e0, hid[1], hid[0],
+                               ee.weight[2], ee.weight[1], E, dz2, dz1, dz0);
+            MPN_LAUNCH_CHECK();
+            {
+                float* gw[2] = {ee.grad_weight[2], nullptr};
+                float* gb[2] = {ee.grad_bias[2], nullptr};
+                MPN_TRY(weight_grad(p, p.slab, 1, {dz2, 16, 0}, nullptr, {hid[1], 18, 0}, {nullptr, 0, 0}, 18, nullptr, 16, 18, gw, 18, gb, nullptr, E, 1, s));
+            }
+            {
+                float* gw[2] = {ee.grad_weight[1], nullptr};
+                float* gb[2] = {ee.grad_bias[1], nullptr};
+                MPN_TRY(weight_grad(p, p.slab, 1, {dz1, 18, 0}, nullptr, {hid[0], 18, 0}, {nullptr, 0, 0}, 18, nullptr, 18, 18, gw, 18, gb, nullptr, E, 1, s));
+            }
+            dz = dz0;
+        } else if (E > 0) {
             if (ee.out_dims[ee.n_layers - 1] != 1) {
                 MPN_TRY(relu_mask(p.dE0, e0, p.T[0], (int64_t)es, s));
                 dz = p.T[0];
@@ -862,6 +923,8 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
                 cur = 1;
             }
             MPN_TRY(mlp_tail_backward(p, ee, hid, &dz, &cur, E, s));
+        }
+        if (E > 0) {
             float* gw[2] = {ee.grad_weight[0], nullptr};
             float* gb[2] = {ee.grad_bias[0], nullptr};
             // layer 0 read edge_attr through the sort permutation
