@@ -202,6 +202,68 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = tot;
 }
 
+// Narrow outputs (n_out <= 32, k_in <= 32: the reference's 18-wide edge encoder, the [1 x hc] classifier output layer): the
+// any-shape kernel above is latency-bound there (one dependent gather chain per row and lane).  Here a block stages 64 rows of
+// dZ and H (through the row indices, if any) in LDS and every thread owns up to five output elements (o, c) -- c == k_in is
+// the bias column, fed by a column of ones -- reading dZ as a broadcast and H conflict-free.  Same chunking and slab format.
+constexpr int TS_ROWS = 64;
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(TnArgs args) {
+    __shared__ float zs[TS_ROWS][33];
+    __shared__ float hs[TS_ROWS][34];
+    const int n_out = args.n_out, k_in = args.k_in, kc = k_in + 1;
+    const int nout_total = n_out * kc;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    const int batch = blockIdx.y / args.nsplit;
+    const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
+    int r1 = r0 + args.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;
+    const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride);
+    const float* H = TN_G(H) + (int64_t)batch * TN_G(h_bstride);
+    const int* zi = TN_G(dz_idx);
+    const int* hi = TN_G(h_idx);
+    const int64_t ldz = TN_G(ldz), ldh = TN_G(ldh);
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int oo[5], cc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = threadIdx.x + 256 * q;
+        oo[q] = t < nout_total ? t / kc : 0;
+        cc[q] = t < nout_total ? t % kc : 0;
+    }
+    for (int m0 = r0; m0 < r1; m0 += TS_ROWS) {
+        const int nr = r1 - m0 < TS_ROWS ? r1 - m0 : TS_ROWS;
+        for (int i = threadIdx.x; i < TS_ROWS * n_out; i += 256) {
+            const int r = i / n_out, o = i - r * n_out;
+            const int64_t row = r < nr ? (zi ? zi[m0 + r] : m0 + r) : 0;
+            zs[r][o] = r < nr ? dZ[row * ldz + o] : 0.f;
+        }
+        for (int i = threadIdx.x; i < TS_ROWS * kc; i += 256) {
+            const int r = i / kc, c = i - r * kc;
+            const int64_t row = r < nr ? (hi ? hi[m0 + r] : m0 + r) : 0;
+            hs[r][c] = c == k_in ? 1.f : (r < nr ? H[row * ldh + c] : 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (threadIdx.x + 256 * q < nout_total) {
+                float s = acc[q];
+#pragma unroll 8
+                for (int r = 0; r < TS_ROWS; ++r) s = fmaf(zs[r][oo[q]], hs[r][cc[q]], s);
+                acc[q] = s;
+            }
+        }
+        __syncthreads();
+    }
+    float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * (k_in + 4);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (threadIdx.x + 256 * q < nout_total) slab[(size_t)oo[q] * (k_in + 4) + cc[q]] = acc[q];
+}
+
 // grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]  over the non-empty chunks.
 // Block = 32 x 16-byte columns of the padded slab image x 8 slab groups: a wave reads 512 contiguous bytes of one
 // slab, four slabs in flight per lane; the eight groups' partial sums meet in LDS in a fixed order (deterministic).
@@ -361,6 +423,8 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
             hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
         else
             hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
+    } else if (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL")) {
+        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(1, a.nsplit * a.nbatch, a.ngroups), dim3(256), 0, s, a);
     } else {
         const int64_t nout_total = (int64_t)a.n_out * (a.k_in + 1);
         hipLaunchKernelGGL(gemm_tn_generic_kernel, dim3((unsigned)((nout_total + 31) / 32), a.nsplit * a.nbatch, a.ngroups),
