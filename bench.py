@@ -262,7 +262,7 @@ def main():
             # the same step with the fused chain kernels in MPNHIP_PREC_FP32_SPLIT (fp32 results from three-piece bf16 operands,
             # DESIGN.md section 4b): reported BESIDE the headline, which stays on fp32 MFMAs
             model.gemm_precision = "fp32_split"
-            for _ in range(min(args.warmup, 5)):
+            for _ in range(max(args.warmup, 5)):   # (first launches of the split kernel variants load their code objects)
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
