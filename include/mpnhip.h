@@ -88,6 +88,42 @@ const char* mpnhip_version(void);
 /* Host string describing the last error raised on the calling thread ("" if none). */
 const char* mpnhip_last_error(void);
 
+/* Test instrumentation: host-side counters of the kernel variants launched by this process (which code path a call took:
+ * fused chain or GEMMs, block-per-segment or short-segment reductions, ...).  Copies min(capacity, count) values into
+ * counts (may be NULL), zeroes them when reset != 0, returns the number of counters; mpnhip_debug_counter_name(i) names
+ * counter i ("" past the end).  No reference counterpart: the parity tests use it to prove that the kernel they mean to
+ * check is the one that ran. */
+int mpnhip_debug_counters(int64_t* counts, int capacity, int reset);
+const char* mpnhip_debug_counter_name(int index);
+
+/* Test instrumentation: one activation that mpnhip_forward(save_for_backward = 1) left in its workspace, copied to `out`
+ * [rows, width] fp32 in ORIGINAL node / edge order (the workspace keeps per-edge tensors in sorted order).  The parity tests
+ * read the forward's ReLU / arg-max DECISIONS from these (value > 0) and differentiate the oracle on the same branch of the
+ * piecewise-linear function, so that a gradient comparison is not at the mercy of a pre-activation that sits within fp32
+ * noise of zero (tests/test_gpu_pinned.py).  out == NULL: only rows / width are reported.
+ *   what                         step        layer   contents (reference line)
+ *   MPNHIP_SAVED_ENC_NODE / EDGE -           i       encoder hidden layer i, post-ReLU (mpn.py:355)
+ *   MPNHIP_SAVED_X / _E          0..L        -       latent node / edge features after `step` steps (0 = encoder output)
+ *   MPNHIP_SAVED_EDGE_HIDDEN     1..L        i       EdgeModel MLP hidden layer i (mpn.py:69)
+ *   MPNHIP_SAVED_CLS_HIDDEN      1..L        i       classifier hidden layer i (mpn.py:114)
+ *   MPNHIP_SAVED_FLOW_HIDDEN     1..L        i       flow_out / flow_in MLP hidden layer i of each edge's direction (mpn.py:88,95)
+ *   MPNHIP_SAVED_MSG             1..L        -       the messages the aggregation reads (mpn.py:89,96)
+ *   MPNHIP_SAVED_AGG             1..L        -       [flow_in | flow_out] (mpn.py:97)
+ *   MPNHIP_SAVED_ARGMAX          1..L        -       max aggregation: original edge id chosen per (node, column), -1 = none */
+#define MPNHIP_SAVED_ENC_NODE 0
+#define MPNHIP_SAVED_ENC_EDGE 1
+#define MPNHIP_SAVED_X 2
+#define MPNHIP_SAVED_E 3
+#define MPNHIP_SAVED_EDGE_HIDDEN 4
+#define MPNHIP_SAVED_CLS_HIDDEN 5
+#define MPNHIP_SAVED_FLOW_HIDDEN 6
+#define MPNHIP_SAVED_MSG 7
+#define MPNHIP_SAVED_AGG 8
+#define MPNHIP_SAVED_ARGMAX 9
+int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges, const void* fwd_workspace,
+                       size_t fwd_workspace_bytes, int what, int step, int layer, float* out, int64_t* rows, int* width,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Graph preparation -- replaces the six boolean-mask indexings per step of
  * TimeAwareNodeModel.forward (models/mpn.py:85-87,91-93) and the implicit index structures behind

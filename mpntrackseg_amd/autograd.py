@@ -50,29 +50,42 @@ def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, 
 class _HotPath(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, g, x, edge_attr, *params):
-        x = capi.f32c(x.detach())
-        ea = capi.f32c(edge_attr.detach())
+        xd = capi.f32c(x.detach())
+        ead = capi.f32c(edge_attr.detach())
         L = max(int(model.num_enc_steps), 1)
-        logits = torch.empty((L, ea.shape[0]), dtype=torch.float32, device=x.device)
-        ctx.fwd_ws = native_forward_saved(model, g, x, ea, logits)
-        ctx.model, ctx.g, ctx.x, ctx.ea = model, g, x, ea
-        ctx.params = params
+        logits = torch.empty((L, ead.shape[0]), dtype=torch.float32, device=xd.device)
+        ctx.fwd_ws = native_forward_saved(model, g, xd, ead, logits)
+        ctx.model, ctx.g = model, g
+        # through save_for_backward: autograd's version check then catches an in-place change of x / edge_attr / a weight
+        # between forward and backward (the saved activations would no longer belong to them)
+        ctx.save_for_backward(xd, ead, *params)
+        ctx.params = params   # the Parameter objects themselves: the native model description is keyed by their id()
         return logits
 
     @staticmethod
     def backward(ctx, grad_logits):
-        grads = {id(p): torch.zeros_like(p) for p in ctx.params}
-        gx, gea = native_backward(ctx.model, ctx.g, ctx.x, ctx.ea, grad_logits, ctx.fwd_ws, grads,
+        if ctx.fwd_ws is None:
+            raise capi.MpnhipError("the hot path's saved activations were already consumed by a backward pass: a second "
+                                   "backward through the same forward (retain_graph=True, checkpointing) is not supported -- "
+                                   "run the forward again")
+        saved = ctx.saved_tensors   # (raises if one of them was modified in place since the forward)
+        x, ea, params = saved[0], saved[1], ctx.params
+        grads = {id(p): torch.zeros_like(p) for p in params}
+        gx, gea = native_backward(ctx.model, ctx.g, x, ea, grad_logits, ctx.fwd_ws, grads,
                                   need_gx=ctx.needs_input_grad[2], need_gea=ctx.needs_input_grad[3])
         ctx.fwd_ws = None
-        return (None, None, gx, gea) + tuple(grads[id(p)] if p.requires_grad else None for p in ctx.params)
+        return (None, None, gx, gea) + tuple(grads[id(p)] if p.requires_grad else None for p in params)
 
 
-def mpn_hot_path_autograd(model, x, edge_index, edge_attr, holder=None):
-    from .mpn import _prepared
+def mpn_hot_path_autograd(model, x, edge_index, edge_attr, holder=None, validate=True):
+    from .mpn import _prepared, check_hot_path_inputs
     capi.require_device(x, edge_index, edge_attr)
     g = _prepared(edge_index, x.shape[0], holder)
     params = model.hot_path_parameters()
     for p in params:
         capi.require_device(p)
-    return _HotPath.apply(model, g, x, edge_attr, *params)
+    check_hot_path_inputs(model.c_model([]), g, x, edge_attr)
+    out = _HotPath.apply(model, g, x, edge_attr, *params)
+    if validate:
+        g.raise_if_invalid()
+    return out

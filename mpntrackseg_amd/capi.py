@@ -6,6 +6,7 @@ path runs in the hand-written HIP kernels behind these entry points.  There is N
 if the library cannot be loaded, or a tensor is not on a HIP device, the call raises.
 """
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -52,6 +53,9 @@ _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
     "mpnhip_version": (C.c_char_p, []),
     "mpnhip_last_error": (C.c_char_p, []),
+    "mpnhip_debug_counters": (_I, [C.POINTER(C.c_int64), _I, _I]),
+    "mpnhip_debug_counter_name": (C.c_char_p, [_I]),
+    "mpnhip_debug_saved": (_I, [C.POINTER(Model), _P, _I, _L, _P, _Z, _I, _I, _I, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int), _P]),
     "mpnhip_graph_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep_workspace_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep": (_I, [_P, _I, _L, _P, _Z, _P, _Z, _P]),
@@ -121,6 +125,34 @@ def load():
     return _lib
 
 
+def path_counters(reset=False):
+    """{kernel-variant name: launches since the last reset} (``mpnhip_debug_counters``): which code paths the calls took."""
+    lib = load()
+    n = lib.mpnhip_debug_counters(None, 0, 0)
+    arr = (C.c_int64 * n)()
+    lib.mpnhip_debug_counters(arr, n, 1 if reset else 0)
+    return {lib.mpnhip_debug_counter_name(i).decode(): int(arr[i]) for i in range(n)}
+
+
+SAVED = {"enc_node": 0, "enc_edge": 1, "x": 2, "e": 3, "edge_hidden": 4, "cls_hidden": 5, "flow_hidden": 6, "msg": 7, "agg": 8,
+         "argmax": 9}
+
+
+def saved_activation(model, graph, fwd_ws, what, step=0, layer=0):
+    """One activation a training forward (``autograd.native_forward_saved``) left in ``fwd_ws``, in original node / edge order
+    (``mpnhip_debug_saved``); test instrumentation."""
+    lib = load()
+    m = model.c_model([])
+    rows, width = C.c_int64(0), C.c_int(0)
+    with torch.cuda.device(graph.device):
+        check(lib.mpnhip_debug_saved(m, ptr(graph.buf), graph.N, graph.E, ptr(fwd_ws), fwd_ws.numel(), SAVED[what], int(step), int(layer),
+                                     None, C.byref(rows), C.byref(width), stream_ptr()), "mpnhip_debug_saved")
+        out = torch.empty((rows.value, width.value), dtype=torch.float32, device=graph.device)
+        check(lib.mpnhip_debug_saved(m, ptr(graph.buf), graph.N, graph.E, ptr(fwd_ws), fwd_ws.numel(), SAVED[what], int(step), int(layer),
+                                     ptr(out), C.byref(rows), C.byref(width), stream_ptr()), "mpnhip_debug_saved")
+    return out
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().mpnhip_last_error().decode("utf-8", "replace")
@@ -144,6 +176,20 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_tensor_device(fn):
+    """Decorator: run ``fn`` with the HIP device of its first device-tensor argument current, so that ``stream_ptr()`` and
+    ``workspace()`` inside refer to THAT device's current stream (one process may hold several GPUs; launching on the
+    current device's stream with another device's pointers is an invalid access)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapper
+
+
 def f32c(t):
     """contiguous float32 view/copy of a tensor (no-op for the expected layout)"""
     if t.dtype != torch.float32:
@@ -160,8 +206,12 @@ _model_uid = [0]  # source of MOTMPNet._mpnhip_uid tokens
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only per-(device, tag) scratch buffer from torch's caching allocator."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer from torch's caching allocator, one per (device, tag, current stream of that device): two
+    streams of one device never share scratch memory, so calls issued on different streams cannot race on it."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (str(device), tag, int(torch.cuda.current_stream(device).cuda_stream))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -187,6 +237,44 @@ def fill_mlp(dst, linears, with_grads=False, keep=None):
     return dst
 
 
+class _StatusRing:
+    """Pinned host slots for the asynchronous read-back of graph-prep error flags (a pinned allocation per graph would cost
+    more than the prep).  A slot that was recycled before its graph looked at it falls back to the synchronous status()."""
+
+    SLOTS = 512
+
+    def __init__(self):
+        self.host = None
+        self.owner = [None] * self.SLOTS
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def post(self, graph):
+        if self.host is None:
+            self.host = torch.empty((self.SLOTS, 4), dtype=torch.int32, pin_memory=True)
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        self.owner[i] = id(graph)
+        with torch.cuda.device(graph.device):
+            self.host[i].copy_(graph.buf[:16].view(torch.int32), non_blocking=True)
+            ev = self.events[i]
+            if ev is None:
+                ev = self.events[i] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        return i
+
+    def read(self, i, graph):
+        if self.owner[i] != id(graph):
+            return None
+        self.events[i].synchronize()
+        if self.owner[i] != id(graph):
+            return None
+        return int(self.host[i, 0])
+
+
+_status_ring = _StatusRing()
+
+
 class PreparedGraph:
     """Device-side sort of an edge_index (see ``mpnhip_graph_prep``)."""
 
@@ -210,10 +298,32 @@ class PreparedGraph:
             fn = lib.mpnhip_graph_prep if full else lib.mpnhip_graph_prep_forward
             check(fn(ptr(ei), self.N, self.E, ptr(self.buf), self.buf.numel(), ptr(ws), ws.numel(), stream_ptr()),
                   "mpnhip_graph_prep")
+        # the error flag travels to the host asynchronously (pinned slot + event on the launch stream); the first consumer
+        # that cares reads it with raise_if_invalid() AFTER it has enqueued its own work -- by then the prep is long done
+        self._status_slot = None
+        self._validated = False
         if validate:
             st = self.status()
+            self._validated = True
             if st[0] != 0:
                 raise MpnhipError("edge_index has entries outside [0, N)")
+        else:
+            self._status_slot = _status_ring.post(self)
+
+    def raise_if_invalid(self):
+        """The reference raises IndexError from its ``x[row]`` / ``x[col]`` gathers when edge_index leaves [0, N) (mpn.py:69);
+        graph prep clamps such entries and sets a flag.  Reads the flag once per prepared graph (waits for the prep kernels
+        only, never for work enqueued after them)."""
+        if self._validated:
+            return
+        flag = _status_ring.read(self._status_slot, self) if self._status_slot is not None else None
+        if flag is None:
+            flag = self.status()[0]
+        self._validated = True
+        self._status_slot = None
+        if flag != 0:
+            raise IndexError("index out of range in edge_index: entries must lie in [0, %d) (reference mpn.py:69 gathers "
+                             "x[row], x[col])" % self.N)
 
     def status(self):
         arr = (C.c_int32 * 4)()

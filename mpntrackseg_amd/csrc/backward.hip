@@ -10,6 +10,7 @@
 //
 // Every per-step activation was saved by the forward (288 GB of HBM: nothing is recomputed).
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "edge_chain.h"
@@ -134,20 +135,42 @@ static int relu_mask(const float* g, const float* act, float* out, int64_t n, hi
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
-    int device = -1;
 };
-static SideStream g_side;
+// one per device, created on first use; g_side_mu serialises the ENQUEUE phase of concurrent mpnhip_backward calls (threads /
+// caller streams of one process): each call's event record -> wait pairs are then issued as a unit, and a wait refers to the
+// record made just before it.  (Device work of different caller streams still overlaps; their slab buffers are per call.)
+constexpr int MAX_DEVICES = 64;
+static SideStream g_side_dev[MAX_DEVICES];
+static std::mutex g_side_mu;
 
-static int side_stream_ready() {
+static int side_stream_ready(SideStream** out) {
     int dev = -1;
     MPN_HIP(hipGetDevice(&dev));
-    if (g_side.stream && g_side.device == dev) return MPNHIP_OK;
-    MPN_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-    MPN_HIP(hipEventCreateWithFlags(&g_side.ready, hipEventDisableTiming));
-    MPN_HIP(hipEventCreateWithFlags(&g_side.done, hipEventDisableTiming));
-    g_side.device = dev;
+    MPN_CHECK_ARG(dev >= 0 && dev < MAX_DEVICES, "backward: device ordinal %d", dev);
+    SideStream& ss = g_side_dev[dev];
+    if (!ss.stream) {
+        MPN_HIP(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+        MPN_HIP(hipEventCreateWithFlags(&ss.ready, hipEventDisableTiming));
+        MPN_HIP(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
+    }
+    *out = &ss;
     return MPNHIP_OK;
 }
+
+// Once work has been forked to the side stream the caller's stream must wait for it on EVERY exit path -- also when a later
+// launch fails and the function returns early: the side stream still reads the forward / backward workspaces and adds into
+// the gradient buffers, all of which the caller is free to release as soon as this call returns.
+struct SideJoin {
+    SideStream* ss = nullptr;
+    hipStream_t caller = nullptr;
+    bool forked = false, joined = false;
+    ~SideJoin() {
+        if (forked && !joined && ss) {
+            if (hipEventRecord(ss->done, ss->stream) != hipSuccess || hipStreamWaitEvent(caller, ss->done, 0) != hipSuccess)
+                (void)hipStreamSynchronize(ss->stream);   // last resort: block the host rather than leave the work unordered
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------ plan
 // Pre-activation gradients (dZ) of EVERY step are kept ([L][rows][width] blocks): the activation-gradient
@@ -606,7 +629,13 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     // its batched products run on a side stream UNDER the remaining steps' chain kernels (which leave 120 of the 256
     // CUs idle for the last third of their run at cfg-B); only the last group runs after the loop.  Groups are issued
     // to ONE side stream in order, so they can share its slab buffer and their "+=" into the gradients stay ordered.
-    const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready() == MPNHIP_OK;
+    SideStream* side = nullptr;
+    const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready(&side) == MPNHIP_OK;
+    std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
+    if (want_fork) side_lock.lock();
+    SideJoin join;
+    join.ss = side;
+    join.caller = s;
     // Group sizes (in steps, first-finished group first).  The side stream is serial, so the last group should be the
     // smallest: it starts only when the loop is over and what it has not finished when the encoder's backward ends is
     // exposed.  Default for L = 12: 5 + 4 + 3; in general three groups with sizes ~ (5 : 4 : 3), two below six steps or when
@@ -652,7 +681,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         return g < 0 ? (int)L : lo;
     };
     int next_group = 0;
-    bool forked = false;
+    bool& forked = join.forked;
     bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
     bool node_a_done = false;   // dZn / dAGG of the coming step were already produced by node_step32_bwd
     const bool fuse_node_bwd = dn == 32 && N <= 4096 && pw <= 1088 && !getenv("MPNHIP_NO_NODE_FUSION");
@@ -785,11 +814,11 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         }
         cx ^= 1;
         if (next_group < ngroups - 1 && b_ == glo(next_group)) {
-            MPN_HIP(hipEventRecord(g_side.ready, s));
-            MPN_HIP(hipStreamWaitEvent(g_side.stream, g_side.ready, 0));
-            MPN_TRY(mp_weight_grads(glo(next_group), glo(next_group - 1) - glo(next_group), g_side.stream, p.slab_side));
-            ++next_group;
+            MPN_HIP(hipEventRecord(side->ready, s));
+            MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
             forked = true;
+            MPN_TRY(mp_weight_grads(glo(next_group), glo(next_group - 1) - glo(next_group), side->stream, p.slab_side));
+            ++next_group;
         }
     }
 
@@ -825,10 +854,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         // runs under the encoder's backward below, which touches none of its buffers; the join is at the very end.
         const int last_n = glo(ngroups - 2 < 0 ? -1 : ngroups - 2);
         if (forked) {
-            MPN_HIP(hipEventRecord(g_side.ready, s));
-            MPN_HIP(hipStreamWaitEvent(g_side.stream, g_side.ready, 0));
-            MPN_TRY(mp_weight_grads(0, last_n, g_side.stream, p.slab_side));
-            MPN_HIP(hipEventRecord(g_side.done, g_side.stream));
+            MPN_HIP(hipEventRecord(side->ready, s));
+            MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
+            MPN_TRY(mp_weight_grads(0, last_n, side->stream, p.slab_side));
         } else {
             MPN_TRY(mp_weight_grads(0, last_n, s, p.slab));
             MPN_TRY(unpack_node_grads());
@@ -901,6 +929,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             float* dz2 = p.T[0];
             float* dz1 = dz2 + (size_t)E * 16;
             float* dz0 = dz1 + (size_t)E * 18;
+            count_path(PC_EDGE_ENCODER_BWD);
             hipLaunchKernelGGL((k_edge_encoder_bwd<18, 18, 16>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, p.dE0, e0, hid[1], hid[0],
                                ee.weight[2], ee.weight[1], E, dz2, dz1, dz0);
             MPN_LAUNCH_CHECK();
@@ -938,7 +967,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         }
     }
     if (L > 0 && forked) {  // join: every "+=" of the side stream's groups is in; then the unpacking, on the caller's stream
-        MPN_HIP(hipStreamWaitEvent(s, g_side.done, 0));
+        MPN_HIP(hipEventRecord(side->done, side->stream));
+        MPN_HIP(hipStreamWaitEvent(s, side->done, 0));
+        join.joined = true;
         MPN_TRY(unpack_node_grads());
     }
     return MPNHIP_OK;

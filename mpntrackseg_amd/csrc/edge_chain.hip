@@ -1136,6 +1136,7 @@ int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
         return MPNHIP_ERR_UNSUPPORTED;
     }
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+    count_path(a.split ? PC_CHAIN_FWD_SPLIT : PC_CHAIN_FWD);
 #ifdef MPNHIP_CHAIN_TS
     a.ts = g_stamp_fwd.prepare(blocks, s);
 #endif
@@ -1172,6 +1173,7 @@ int launch_edge_chain_bwd(const EdgeChainBwdArgs& a_in, hipStream_t s) {
     if (a_in.E <= 0) return MPNHIP_OK;
     EdgeChainBwdArgs a = a_in;
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+    count_path(a.split ? PC_CHAIN_BWD_SPLIT : PC_CHAIN_BWD);
 #ifdef MPNHIP_CHAIN_TS
     a.ts = g_stamp_bwd.prepare(blocks, s);
 #endif

@@ -467,6 +467,7 @@ static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     // 50000 x 320 x 128 65.6 -> 48.5 us; narrow outputs (N = 128) and short K lose to the fp32 MFMA kernel's smaller LDS image
     if (prec == 2 && !(a.K >= 128 && a.N >= 256)) prec = 0;
     if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);  // tuning override (tools/gemm_bench.py)
+    count_path(bl == B_KCONTIG && prec == 2 ? PC_GEMM_SPLIT : (bl == B_KCONTIG && prec == 1 ? PC_GEMM_BF16 : PC_GEMM_FP32));
     if (bl == B_KCONTIG && prec == 2)
         MPN_LAUNCH_PROFILED((gemm_kernel<WM, WN, TN, B_KCONTIG, 2>), grid, dim3(NTHREADS), s, a);
     else if (bl == B_KCONTIG && prec == 1)

@@ -416,6 +416,7 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
                g.h2_bstride % 4 == 0;
     }
     tn_plan(a);
+    count_path(fast ? PC_TN_MFMA : (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL") ? PC_TN_SMALL : PC_TN_GENERIC));
     if (fast) {
         const int tbn = a.k_in <= 64 ? 64 : 128;
         int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn);

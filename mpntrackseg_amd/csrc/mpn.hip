@@ -9,6 +9,7 @@
 // weight block [W1r; W1c; Wfo_x; Wfi_x] (biases folded in) and added per edge in the epilogue of the
 // per-edge GEMMs; torch.cat([x0, x]) / torch.cat([e0, e]) (mpn.py:369-373) are never materialised --
 // the GEMM's A operand is read from two K segments.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,16 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------ path counters (common.h)
+static std::atomic<long long> g_path_counts[PC_COUNT];
+static const char* const g_path_names[PC_COUNT] = {
+    "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
+    "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack"};
+void count_path(int id) {
+    if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
 
 // ------------------------------------------------------------------------------------ event profiling
@@ -426,6 +437,7 @@ static bool edge_encoder_fused(const mpnhip_mlp& m, const float* x, const int* i
     *status = MPNHIP_OK;
     if (getenv("MPNHIP_NO_ENCODER_FUSION")) return false;
     if (m.n_layers != 3 || m.in_dim != 6 || m.out_dims[0] != 18 || m.out_dims[1] != 18 || m.out_dims[2] != 16 || rows <= 0) return false;
+    count_path(PC_EDGE_ENCODER);
     hipLaunchKernelGGL((k_edge_encoder<6, 18, 18, 16>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, idx, rows, m.weight[0],
                        m.bias[0], m.weight[1], m.bias[1], m.weight[2], m.bias[2], keep_hidden ? hidden[0] : nullptr,
                        keep_hidden ? hidden[1] : nullptr, y);
@@ -468,6 +480,15 @@ using namespace mpnhip;
 extern "C" const char* mpnhip_version(void) { return "mpnhip 0.1 (gfx950)"; }
 extern "C" const char* mpnhip_last_error(void) { return g_err; }
 
+extern "C" int mpnhip_debug_counters(int64_t* counts, int capacity, int reset) {
+    for (int i = 0; i < PC_COUNT; ++i) {
+        if (counts && i < capacity) counts[i] = (int64_t)g_path_counts[i].load(std::memory_order_relaxed);
+        if (reset) g_path_counts[i].store(0, std::memory_order_relaxed);
+    }
+    return PC_COUNT;
+}
+extern "C" const char* mpnhip_debug_counter_name(int index) { return index >= 0 && index < PC_COUNT ? g_path_names[index] : ""; }
+
 extern "C" size_t mpnhip_forward_workspace_bytes(const mpnhip_model* model, int n_nodes, int64_t n_edges, int save) {
     Dims d;
     if (!model || check_full(*model, &d, false) != MPNHIP_OK) return 0;
@@ -507,6 +528,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace
         p.cw.split = chain_split(m);
     } else {
+        count_path(PC_WEIGHT_PACK);
         MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
         MPN_TRY(pack_chain_weights(m, d, p.cw, s));
     }
@@ -695,6 +717,83 @@ extern "C" int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, vo
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        x, rows, hw, y, sub);
     MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ test instrumentation
+// argmax entries are positions in SORTED edge order (or -1): as floats holding the ORIGINAL edge id
+__global__ void k_arg_to_original(const int* __restrict__ arg, const int* __restrict__ perm, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = arg[i];
+    out[i] = j >= 0 ? (float)perm[j] : -1.f;
+}
+
+extern "C" int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
+                                  const void* fwd_workspace, size_t fwd_workspace_bytes, int what, int step, int layer, float* out,
+                                  int64_t* rows_out, int* width_out, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(model && graph_buf && fwd_workspace, "debug_saved: null argument");
+    const mpnhip_model& m = *model;
+    Dims d;
+    MPN_TRY(check_full(m, &d));
+    const int64_t N = n_nodes, E = n_edges;
+    FwdPlan p;
+    const size_t need = plan_forward(m, d, N, E, 1, const_cast<void*>(fwd_workspace), &p);
+    if (fwd_workspace_bytes < need) {
+        set_error("debug_saved: workspace %zu < %zu (must be a save_for_backward buffer)", fwd_workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    GraphView g;
+    graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
+    const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
+    const float* src = nullptr;
+    int64_t rows = 0;
+    int width = 0;
+    bool per_edge = false;
+    auto enc_layer = [&](const mpnhip_mlp& e, float* base, int64_t r) -> const float* {
+        if (layer < 0 || layer + 1 >= e.n_layers) return nullptr;
+        size_t off = 0;
+        for (int i = 0; i < layer; ++i) off += (size_t)r * e.out_dims[i];
+        width = e.out_dims[layer];
+        return base + off;
+    };
+    const bool step_ok = step >= 1 && step <= d.L;
+    const StepBufs b = step_ok ? step_at(p, step - 1) : p.step0;
+    switch (what) {
+        case MPNHIP_SAVED_ENC_NODE: src = enc_layer(m.enc_node, p.enc_n[0], N); rows = N; break;
+        case MPNHIP_SAVED_ENC_EDGE: src = enc_layer(m.enc_edge, p.enc_e[0], E); rows = E; per_edge = true; break;
+        case MPNHIP_SAVED_X: if (step >= 0 && step <= d.L) { src = p.x_hist + xs * step; rows = N; width = d.dn; } break;
+        case MPNHIP_SAVED_E: if (step >= 0 && step <= d.L) { src = p.e_hist + es * step; rows = E; width = d.de; per_edge = true; } break;
+        case MPNHIP_SAVED_EDGE_HIDDEN:
+            if (step_ok && layer >= 0 && layer + 1 < m.edge.n_layers) { src = b.HE[layer]; rows = E; width = m.edge.out_dims[layer]; per_edge = true; }
+            break;
+        case MPNHIP_SAVED_CLS_HIDDEN:
+            if (step_ok && layer >= 0 && layer + 1 < m.classifier.n_layers) { src = b.HC[layer]; rows = E; width = m.classifier.out_dims[layer]; per_edge = true; }
+            break;
+        case MPNHIP_SAVED_FLOW_HIDDEN:
+            if (step_ok && layer >= 0 && layer + 1 < m.flow_in.n_layers) { src = b.HF[layer]; rows = E; width = m.flow_in.out_dims[layer]; per_edge = true; }
+            break;
+        case MPNHIP_SAVED_MSG: if (step_ok) { src = b.M; rows = E; width = d.dn; per_edge = true; } break;
+        case MPNHIP_SAVED_AGG: if (step_ok) { src = b.AGG; rows = N; width = 2 * d.dn; } break;
+        case MPNHIP_SAVED_ARGMAX: if (step_ok && b.ARG) { src = reinterpret_cast<const float*>(b.ARG); rows = N; width = 2 * d.dn; } break;
+        default: break;
+    }
+    if (!src) {
+        set_error("debug_saved: nothing saved for what = %d, step = %d, layer = %d", what, step, layer);
+        return MPNHIP_ERR_ARG;
+    }
+    if (rows_out) *rows_out = rows;
+    if (width_out) *width_out = width;
+    if (!out || rows * width == 0) return MPNHIP_OK;
+    if (what == MPNHIP_SAVED_ARGMAX) {
+        const int64_t n = rows * width;
+        hipLaunchKernelGGL(k_arg_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const int*>(src), g.perm, out, n);
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
+    if (per_edge) return scatter_rows(src, g.perm, out, rows, width, s);   // sorted -> original edge order
+    MPN_HIP(hipMemcpyAsync(out, src, (size_t)rows * width * sizeof(float), hipMemcpyDeviceToDevice, s));
     return MPNHIP_OK;
 }
 

@@ -284,6 +284,7 @@ static bool try_launch_block(SegArgs& a, int64_t total_rows, hipStream_t stream)
     int sub = 1;
     while (sub < a.dim / 4) sub <<= 1;
     a.sub = sub;
+    count_path(PC_SEG_BLOCK);
     MPN_LAUNCH_PROFILED(k_segment_reduce_block, dim3(a.nseg), dim3(256), stream, a);
     return true;
 }
@@ -307,6 +308,7 @@ static int launch_seg(SegArgs a, hipStream_t stream) {
     a.sub = sub;
     int64_t threads = (int64_t)a.nseg * sub * a.nblk;
     unsigned blocks = (unsigned)((threads + 255) / 256);
+    count_path(PC_SEG_SHORT);
     if (vec) hipLaunchKernelGGL(k_segment_reduce<4>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(k_segment_reduce<1>, dim3(blocks), dim3(256), 0, stream, a);
     MPN_LAUNCH_CHECK();
@@ -425,6 +427,7 @@ int node_step32(const GraphView& g, const float* msg, int agg, const float* Wu, 
                 const float* Wx, int64_t ldwx, const float* P0, float* P, int pw, hipStream_t stream) {
     if (g.N <= 0) return MPNHIP_OK;
     NodeStepArgs a = {msg, g.seg_ptr, g.N, agg, Wu, bu, x_new, agg_out, Wx, ldwx, P0, P, pw};
+    count_path(PC_NODE_STEP32);
     hipLaunchKernelGGL(k_node_step32, dim3((unsigned)((g.N + 1) / 2)), dim3(256), 0, stream, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
@@ -489,6 +492,7 @@ int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldw
     if (N <= 0) return MPNHIP_OK;
     if (pw > 1088) { set_error("node_step32_bwd: projection width too large"); return MPNHIP_ERR_UNSUPPORTED; }
     NodeStepBwdArgs a = {dP, N, pw, Wx, ldwx, x_prev, Wu, dZn, dAGG};
+    count_path(PC_NODE_STEP32_BWD);
     hipLaunchKernelGGL(k_node_step32_bwd, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, stream, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
@@ -510,6 +514,7 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
     a.off0 = dim;  // flow_out goes to the right half: torch.cat((flow_in, flow_out)) (mpn.py:97)
     a.off1 = 0;
     if (try_launch_block(a, g.E, stream)) {
+        count_path(PC_AGGREGATE_BLOCK);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
     }
@@ -518,6 +523,7 @@ int aggregate(const GraphView& g, const float* src, int dim, int agg, float* out
         while (sub < dim / 4 && sub < 64) sub <<= 1;
         a.sub = sub;
         const int64_t threads = (int64_t)a.nseg * sub;
+        count_path(PC_AGGREGATE);
         MPN_LAUNCH_PROFILED(k_aggregate, dim3((unsigned)((threads + 255) / 256)), dim3(256), stream, a);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
@@ -579,6 +585,7 @@ static SegArgs seg_args2(const SegReduce2& c) {
 int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream) {
     SegArgs a[3] = {seg_args2(c[0]), seg_args2(c[1]), seg_args2(c[2])};
     if (block_eligible(a[0], total_rows) && block_eligible(a[1], total_rows) && block_eligible(a[2], total_rows)) {
+        count_path(PC_SEG_BLOCK3);
         hipLaunchKernelGGL(k_segment_reduce_block3, dim3(a[0].nseg + a[1].nseg + a[2].nseg), dim3(256), 0, stream, a[0], a[1], a[2]);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;

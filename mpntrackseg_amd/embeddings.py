@@ -29,7 +29,7 @@ def load_precomputed_embeddings(det_df, seq_info_dict, embeddings_dir, use_cuda=
     if not use_cuda:
         raise MpnhipError("load_precomputed_embeddings: this build selects the embeddings on the device (use_cuda=True)")
     lib = capi.load()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device())   # (no tensor argument: the caller's current device, like the reference's .cuda())
     path = osp.join(seq_info_dict['seq_path'], 'processed_data', embeddings_dir)
     frames = sorted(np.unique(_col(det_df, 'frame')).tolist())
     stored = torch.cat([torch.load(osp.join(path, f"{int(f)}.pt")) for f in frames], dim=0).float().contiguous()

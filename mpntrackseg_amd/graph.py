@@ -27,6 +27,7 @@ def _col(det_df, name, dtype, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(v))).to(device=device, dtype=dtype)
 
 
+@capi.on_tensor_device
 def compact(flags):
     """ids (int32, ascending) of the set flags and their number (one host read: the consumers are sized by it)."""
     lib = capi.load()
@@ -39,6 +40,7 @@ def compact(flags):
     return ids[:k], k
 
 
+@capi.on_tensor_device
 def gather_rows(src, ids):
     lib = capi.load()
     src = capi.f32c(src)
@@ -49,6 +51,7 @@ def gather_rows(src, ids):
     return out
 
 
+@capi.on_tensor_device
 def gather_edges(edge_index, ids, node_begin):
     lib = capi.load()
     out = torch.empty((2, ids.numel()), dtype=torch.int64, device=edge_index.device)
@@ -57,6 +60,7 @@ def gather_edges(edge_index, ids, node_begin):
     return out
 
 
+@capi.on_tensor_device
 def get_time_valid_conn_ixs(frame_num, max_frame_dist, use_cuda=True, return_undirected=True):
     """utils/graph.py:6-37.  ``frame_num``: int tensor [N]; ``max_frame_dist``: int or ``'max'``.
     Returns int64 ``[2, num_pairs]`` with row < col, on the device (the reference moves it back to the CPU)."""
@@ -80,6 +84,7 @@ def get_time_valid_conn_ixs(frame_num, max_frame_dist, use_cuda=True, return_und
     return out
 
 
+@capi.on_tensor_device
 def get_knn_mask(pwise_dist, edge_ixs, num_nodes, top_k_nns, use_cuda=True, reciprocal_k_nns=False, symmetric_edges=True):
     """utils/graph.py:40-87.  Returns a bool tensor [num_edges]: True = keep."""
     lib = capi.load()
@@ -100,6 +105,7 @@ def get_knn_mask(pwise_dist, edge_ixs, num_nodes, top_k_nns, use_cuda=True, reci
 EDGE_FEAT_NAMES = ('secs_time_dists', 'norm_feet_x_dists', 'norm_feet_y_dists', 'bb_height_dists', 'bb_width_dists')
 
 
+@capi.on_tensor_device
 def compute_edge_feats_dict(edge_ixs, det_df, fps, use_cuda=True):
     """utils/graph.py:90-124.  Returns the reference's dict: feature name -> tensor [num_edges]."""
     lib = capi.load()
@@ -115,6 +121,7 @@ def compute_edge_feats_dict(edge_ixs, det_df, fps, use_cuda=True):
     return {name: out[:, i] for i, name in enumerate(EDGE_FEAT_NAMES)}
 
 
+@capi.on_tensor_device
 def pairwise_distance(emb, edge_ixs, eps=1e-6):
     """``F.pairwise_distance(emb[edge_ixs[0]], emb[edge_ixs[1]])`` (data/mot_graph.py:298-301) without materialising
     the two gathered [E, dim] operands.  Returns [num_edges]."""
@@ -129,6 +136,7 @@ def pairwise_distance(emb, edge_ixs, eps=1e-6):
     return out
 
 
+@capi.on_tensor_device
 def construct_graph(det_df, reid_embeddings, fps, max_frame_dist, edge_feats_to_use, top_k_nns=None, reciprocal_k_nns=True,
                     inference_mode=True):
     """``MOTGraph._get_edge_ixs`` + ``construct_graph_object`` (data/mot_graph.py:195-317) for precomputed embeddings.

@@ -44,6 +44,7 @@ def tracking_loss(classified_edges, edge_labels, weight=1.0):
     return _TrackingLoss.apply(lg, edge_labels, 0, weight)
 
 
+@capi.on_tensor_device
 def compute_perform_metrics(graph_out, graph_obj):
     """utils/evaluation.py:416-437: {'accuracy','recall','precision','constr_sr'} of the last step's logits."""
     from .mpn import _prepared

@@ -6,6 +6,7 @@ attribute names and ``state_dict`` keys, so ``mot_neural_
 
 There is no CPU fallback: tensors must live on a HIP device, and a missing ``libmpnhip.so`` raises.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -31,6 +32,21 @@ def _prepared(edge_index, n_nodes, holder=None, full=True):
         except Exception:
             pass
     return g
+
+
+def check_hot_path_inputs(m, g, x, edge_attr):
+    """Shape contract of the native hot path, checked where torch would raise in the reference (the C ABI sees raw pointers
+    only): x [N, node_in_dim], edge_attr [E, edge_in_dim], and the prepared graph must describe exactly these N nodes / E edges
+    (its buffer layout is a function of (N, E): a mismatch would send the kernels out of bounds)."""
+    if x.dim() != 2 or x.shape[1] != m.enc_node.in_dim or edge_attr.dim() != 2 or edge_attr.shape[1] != m.enc_edge.in_dim:
+        raise capi.MpnhipError("input feature widths do not match the encoder (node %s, edge %s; expected [N, %d] and [E, %d])"
+                               % (tuple(x.shape), tuple(edge_attr.shape), m.enc_node.in_dim, m.enc_edge.in_dim))
+    if g.N != x.shape[0]:
+        raise capi.MpnhipError("the prepared graph has %d nodes but x has %d rows" % (g.N, x.shape[0]))
+    if g.E != edge_attr.shape[0]:
+        raise capi.MpnhipError("edge_index has %d edges but edge_attr has %d rows" % (g.E, edge_attr.shape[0]))
+    if x.device != g.device or edge_attr.device != g.device:
+        raise capi.MpnhipError("x / edge_attr / edge_index live on different devices")
 
 
 class NodeAggFn:
@@ -96,6 +112,10 @@ class TimeAwareNodeModel(nn.Module):
         gathers / MLPs / ``node_agg_fn`` / Linear native calls.  ``MetaLayer.forward`` evaluates the same module fused."""
         from .graph import compact, gather_rows
         capi.require_device(x, edge_index, edge_attr)
+        with torch.cuda.device(x.device):
+            return self._forward(x, edge_index, edge_attr, compact, gather_rows)
+
+    def _forward(self, x, edge_index, edge_attr, compact, gather_rows):
         row, col = edge_index
         ea = capi.f32c(edge_attr)
         flows = []
@@ -311,6 +331,9 @@ class MOTMPNet(nn.Module):
         self.num_enc_steps = model_params['num_enc_steps']
         self.num_class_steps = model_params['num_class_steps']
         self.last_logits = None  # [max(L,1), E]: classifier output of every step (the mask branch's input)
+        # inference only: keep the packed weight images between calls (see frozen_weights()); off by default, because an
+        # in-place write through ``p.data`` / a raw pointer does not move ``p._version`` and would go unnoticed
+        self.keep_packed_weights = False
 
     def _build_core_MPNet(self, model_params, encoder_feats_dict):
         """mpn.py:254-317."""
@@ -382,31 +405,53 @@ class MOTMPNet(nn.Module):
         m.classifier = self.classifier.edge_model.c_struct(keep, grads)
         return m
 
-    def hot_path(self, x, edge_index, edge_attr, holder=None, return_state=False):
-        """Encoder + L message-passing steps + per-step classifier: logits [max(L,1), E]."""
+    @contextlib.contextmanager
+    def frozen_weights(self):
+        """``with model.frozen_weights():`` -- the caller vouches that no hot-path weight changes inside the block (e.g. one
+        sequence of sliding-window inference, ``tracker.evaluate_graph_in_batches``).  Inference calls inside it pack the
+        weight images (about 20 small launches) once and reuse them (``mpnhip_model.weights_prepacked``); outside such a
+        block every call packs again, which is always safe.  Changes torch can see (``p._version``, ``load_state_dict``,
+        the native Adam step) still invalidate the images inside the block; writes through ``p.data`` / raw pointers do
+        NOT -- call ``invalidate_packed_weights()`` after those, or do them outside the block."""
+        old = self.keep_packed_weights
+        self.keep_packed_weights = True
+        try:
+            yield self
+        finally:
+            self.keep_packed_weights = old
+            if not old:
+                self.invalidate_packed_weights()
+
+    def invalidate_packed_weights(self):
+        """Forget every packed weight image (the next inference call packs again)."""
+        capi._packed_state.clear()
+
+    def hot_path(self, x, edge_index, edge_attr, holder=None, return_state=False, validate=True):
+        """Encoder + L message-passing steps + per-step classifier: logits [max(L,1), E].  ``validate``: raise IndexError
+        like the reference when edge_index leaves [0, N) (read once per prepared graph, after the launch; callers that build
+        the indices themselves -- the sliding-window driver -- skip it)."""
         capi.require_device(x, edge_index, edge_attr)
         if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
                                         any(p.requires_grad for p in self.hot_path_parameters())):
             from .autograd import mpn_hot_path_autograd
-            return mpn_hot_path_autograd(self, x, edge_index, edge_attr, holder)
+            return mpn_hot_path_autograd(self, x, edge_index, edge_attr, holder, validate=validate)
         lib = capi.load()
         keep = []
         m = self.c_model(keep)
         x = capi.f32c(x)
         ea = capi.f32c(edge_attr)
         N, E = x.shape[0], ea.shape[0]
-        if x.dim() != 2 or x.shape[1] != m.enc_node.in_dim or ea.dim() != 2 or ea.shape[1] != m.enc_edge.in_dim:
-            raise capi.MpnhipError("input feature widths do not match the encoder (node %s, edge %s)"
-                                   % (tuple(x.shape), tuple(ea.shape)))
         g = _prepared(edge_index, N, holder, full=False)   # inference: the primary order is all mpnhip_forward reads
+        check_hot_path_inputs(m, g, x, ea)
         L = max(int(self.num_enc_steps), 1)
         logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
         x_out = torch.empty((N, m.dn), dtype=torch.float32, device=x.device) if return_state else None
         e_out = torch.empty((E, m.de), dtype=torch.float32, device=x.device) if return_state else None
         with torch.cuda.device(x.device):
             ws = capi.workspace(lib.mpnhip_forward_workspace_bytes(m, N, E, 0), x.device, "fwd")
-            # the packed weight images at the head of the workspace survive between calls: skip re-packing them while
-            # the buffer, the model and every weight (address, torch version, native-update epoch) are unchanged
+            # inside ``frozen_weights()`` the packed weight images at the head of the workspace survive between calls: skip
+            # re-packing them while the buffer, the model and every weight (address, torch version, native-update epoch) are
+            # unchanged
             key = (m.precision, capi._weights_epoch[0]) + tuple((p_.data_ptr(), p_._version) for p_ in self.hot_path_parameters())
             # (a token that is never reused: id() of a collected model can come back, together with recycled parameter
             # addresses and equal version counts, for a model with other weights)
@@ -414,12 +459,15 @@ class MOTMPNet(nn.Module):
                 capi._model_uid[0] += 1
                 self._mpnhip_uid = capi._model_uid[0]
             state = (self._mpnhip_uid, key)
-            m.weights_prepacked = 1 if capi._packed_state.get(ws.data_ptr()) == state else 0
+            m.weights_prepacked = 1 if self.keep_packed_weights and capi._packed_state.get(ws.data_ptr()) == state else 0
             capi._packed_state.pop(ws.data_ptr(), None)
             capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits),
                                           capi.ptr(x_out), capi.ptr(e_out), capi.ptr(ws), ws.numel(), 0,
                                           capi.stream_ptr()), "mpnhip_forward")
-            capi._packed_state[ws.data_ptr()] = state
+            if self.keep_packed_weights:
+                capi._packed_state[ws.data_ptr()] = state
+        if validate:
+            g.raise_if_invalid()
         if return_state:
             return logits, x_out, e_out
         return logits

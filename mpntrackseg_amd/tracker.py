@@ -20,6 +20,7 @@ from .capi import MpnhipError, check, ptr, stream_ptr
 from .graph import get_knn_mask, compact as _compact, gather_rows as _gather_rows, gather_edges as _gather_edges
 
 
+@capi.on_tensor_device
 def window_subgraph(edge_index, edge_attr, reid_emb_dists, node_begin, node_end, top_k_nns, reciprocal_k_nns, node_offset=0):
     """Edges of the window [node_begin, node_end) after kNN pruning (mpn_tracker.py:171-178 and :107-112).
     Returns ``(sub_edge_index [2, K] (local ids + node_offset), sub_edge_attr [K, F], window_ids [W] int32, kept_ids [K] int32)``."""
@@ -53,6 +54,7 @@ def frame_windows(frame_num_per_node, frames_per_graph):
 
 
 @torch.no_grad()
+@capi.on_tensor_device
 def evaluate_graph_in_batches(model, x, edge_index, edge_attr, reid_emb_dists, frame_num_per_node, frames_per_graph,
                               top_k_nns, reciprocal_k_nns=True, set_pruned_edges_to_inactive=False, windows_per_launch=1,
                               rank=0, world_size=1, reduce_fn=None):
@@ -62,8 +64,16 @@ def evaluate_graph_in_batches(model, x, edge_index, edge_attr, reid_emb_dists, f
     / ``edge_attr`` / ``reid_emb_dists`` its symmetric edge list as ``graph.construct_graph`` builds it.
     ``reduce_fn(tensor)`` sums a tensor over ranks in place (e.g. ``torch.distributed.all_reduce``) when the windows
     are sharded (``rank``, ``world_size``)."""
-    lib = capi.load()
     capi.require_device(x, edge_index, edge_attr, reid_emb_dists)
+    # the weights do not change during one sequence: pack their images once for all its windows
+    with model.frozen_weights():
+        return _evaluate_windows(model, x, edge_index, edge_attr, reid_emb_dists, frame_num_per_node, frames_per_graph, top_k_nns,
+                                 reciprocal_k_nns, set_pruned_edges_to_inactive, windows_per_launch, rank, world_size, reduce_fn)
+
+
+def _evaluate_windows(model, x, edge_index, edge_attr, reid_emb_dists, frame_num_per_node, frames_per_graph, top_k_nns,
+                      reciprocal_k_nns, set_pruned_edges_to_inactive, windows_per_launch, rank, world_size, reduce_fn):
+    lib = capi.load()
     edge_index = edge_index.to(torch.int64).contiguous()
     x = capi.f32c(x)
     E = edge_index.shape[1]
@@ -86,7 +96,8 @@ def evaluate_graph_in_batches(model, x, edge_index, edge_attr, reid_emb_dists, f
             attr_b = torch.cat([p[1] for p in parts], dim=0)
             x_b = torch.cat([x[p[4]:p[5]] for p in parts], dim=0)
         if ei_b.shape[1] > 0:
-            logits = model.hot_path(x_b, ei_b, attr_b)[L - 1]  # classified_edges[-1] (mpn_tracker.py:132)
+            # (the window's indices were built here, inside [0, n): no error-flag read-back, the host keeps running ahead)
+            logits = model.hot_path(x_b, ei_b, attr_b, validate=False)[L - 1]  # classified_edges[-1] (mpn_tracker.py:132)
         else:
             logits = torch.empty(0, dtype=torch.float32, device=x.device)
         e_off = 0

@@ -109,11 +109,12 @@ class TrainStep:
         self.first_class_step = max(int(model.num_enc_steps) - int(model.num_class_steps), 0)
 
     def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True):
-        from .mpn import _prepared
+        from .mpn import _prepared, check_hot_path_inputs
         model = self.model
         g = _prepared(edge_index, x.shape[0], holder)
         x = capi.f32c(x)
         ea = capi.f32c(edge_attr)
+        check_hot_path_inputs(model.c_model([]), g, x, ea)
         E = ea.shape[0]
         L = max(int(model.num_enc_steps), 1)
         logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
@@ -130,4 +131,5 @@ class TrainStep:
         allreduce_mean_(self.bucket.flat, self.world_size, self.pg)
         if optimizer_step:
             self.opt.step()
+        g.raise_if_invalid()   # IndexError like the reference's x[row] gather for an edge_index outside [0, N): once per graph
         return logits

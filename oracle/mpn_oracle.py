@@ -74,60 +74,147 @@ class precision:
         _PRECISION[0] = self.old
 
 
+# ----------------------------------------------------------------------------- decision pinning (parity tests)
+# ReLU and arg-max make the path piecewise linear: its gradient jumps where a pre-activation crosses zero (or two messages
+# tie), so two fp32 evaluations that differ by rounding noise can legitimately sit on different branches and disagree in the
+# gradient by far more than rounding noise.  The tests therefore take the DECISIONS from the implementation under test:
+#   compare: run the oracle normally and count, per site, the units whose decision differs from the given one together with
+#            how far from the boundary they are (|z| / rms(z)): a correct forward disagrees only on knife-edge units;
+#   impose : relu(z) := z * given_mask, max := gather at the given arg-max -- the oracle then differentiates exactly the branch
+#            the implementation took, and the gradients must agree to rounding noise.
+# Sites: "enc_e.<i>", "enc_n.<i>", "s<step>.edge.<i>", "s<step>.flow.<i>" (both directions, full [E, w] arrays),
+# "s<step>.cls.<i>", "s<step>.node", and "s<step>.argmax" ([N, 2 dn] original edge ids, -1 = empty; [flow_in | flow_out]).
+class Decisions:
+    def __init__(self, given, mode):
+        assert mode in ("compare", "impose")
+        self.given, self.mode = given, mode
+        self.units = 0
+        self.mismatches = 0
+        self.worst_margin = 0.0      # largest |z| / rms(z) over the mismatching units
+        self.per_site = {}
+
+    def relu(self, z, site, rows=None):
+        mask = self.given[site]
+        if rows is not None:
+            mask = mask[rows]
+        if self.mode == "impose":
+            return z * mask.to(z.dtype)
+        own = z > 0
+        bad = own != mask
+        nbad = int(bad.sum())
+        self.units += z.numel()
+        if nbad:
+            scale = float(z.detach().double().pow(2).mean().sqrt())
+            margin = float(z.detach()[bad].abs().max()) / max(scale, 1e-300)
+            self.mismatches += nbad
+            self.worst_margin = max(self.worst_margin, margin)
+            self.per_site[site] = self.per_site.get(site, 0) + nbad
+        return torch.relu(z)
+
+
+_DECISIONS = [None]
+
+
+class decisions:
+    """``with oracle.decisions(Decisions(given, mode)) as d: forward(...)``"""
+    def __init__(self, d):
+        self.d = d
+
+    def __enter__(self):
+        self.old = _DECISIONS[0]
+        _DECISIONS[0] = self.d
+        return self.d
+
+    def __exit__(self, *a):
+        _DECISIONS[0] = self.old
+
+
+def relu(z, site=None, rows=None):
+    d = _DECISIONS[0]
+    if d is None or site is None:
+        return torch.relu(z)
+    return d.relu(z, site, rows)
+
+
 def linear(x, w, b):
     if _PRECISION[0] == "bf16":
         x, w = x.bfloat16().float(), w.bfloat16().float()
     return F.linear(x, w, b)
 
 
-def mlp(x, W, prefix):
+def mlp(x, W, prefix, site=None, rows=None):
     """MLP.forward (models/mlp.py:27-28) for dropout_p=0, use_batchnorm=False: Linear (+ReLU
-    unless the layer's out-dim is 1, mlp.py:17).  ``W`` maps state_dict keys to tensors."""
-    i = 0
+    unless the layer's out-dim is 1, mlp.py:17).  ``W`` maps state_dict keys to tensors.
+    ``site`` / ``rows``: decision-pinning label of this module and the subset of edges it runs on (tests only)."""
+    i, layer = 0, 0
     while f"{prefix}.fc_layers.{i}.weight" in W:
         w, b = W[f"{prefix}.fc_layers.{i}.weight"], W[f"{prefix}.fc_layers.{i}.bias"]
         x = linear(x, w, b)
         if w.shape[0] != 1:
-            x = torch.relu(x)
+            x = relu(x, None if site is None else f"{site}.{layer}", rows)
             i += 2
         else:
             i += 1
+        layer += 1
     return x
 
 
 # ----------------------------------------------------------------------------- models/mpn.py:59-69
-def edge_model(x, edge_index, e, W):
+def edge_model(x, edge_index, e, W, site=None):
     """EdgeModel.forward (models/mpn.py:67-69)."""
     row, col = edge_index
-    return mlp(torch.cat([x[row], x[col], e], dim=1), W, "MPNet.edge_model.edge_model")
+    return mlp(torch.cat([x[row], x[col], e], dim=1), W, "MPNet.edge_model.edge_model", None if site is None else site + ".edge")
+
+
+def _aggregate(agg, msg, rows_mask, row, n, site, half):
+    """node_agg_fn on one direction's messages; with imposed decisions the max becomes a gather at the given arg-max."""
+    d = _DECISIONS[0]
+    if agg != "max" or d is None or site is None:
+        return AGG[agg](msg, row[rows_mask], n)
+    dn = msg.shape[1]
+    arg = d.given[site + ".argmax"][:, half * dn:(half + 1) * dn]        # [N, dn] original edge ids, -1 = empty segment
+    full = torch.zeros((rows_mask.shape[0], dn), dtype=msg.dtype).index_put((torch.nonzero(rows_mask).view(-1),), msg)
+    picked = full.gather(0, arg.clamp(min=0)) * (arg >= 0).to(msg.dtype)
+    if d.mode == "impose":
+        return picked
+    own = AGG[agg](msg, row[rows_mask], n)
+    bad = own != picked.detach()
+    d.units += own.numel()
+    if bool(bad.any()):
+        scale = float(own.detach().double().pow(2).mean().sqrt())
+        d.mismatches += int(bad.sum())
+        d.worst_margin = max(d.worst_margin, float((own.detach() - picked.detach())[bad].abs().max()) / max(scale, 1e-300))
+        d.per_site[site + ".argmax"] = d.per_site.get(site + ".argmax", 0) + int(bad.sum())
+    return own
 
 
 # ----------------------------------------------------------------------------- models/mpn.py:71-99
-def node_model(x, edge_index, e, W, agg):
+def node_model(x, edge_index, e, W, agg, site=None):
     """TimeAwareNodeModel.forward (models/mpn.py:83-99)."""
     row, col = edge_index
     n = x.size(0)
+    fsite = None if site is None else site + ".flow"
     out_mask = row < col                                                     # :85
     out_in = torch.cat([x[col[out_mask]], e[out_mask]], dim=1)               # :86-87
-    flow_out = AGG[agg](mlp(out_in, W, "MPNet.node_model.flow_out_model"), row[out_mask], n)   # :88-89
+    flow_out = _aggregate(agg, mlp(out_in, W, "MPNet.node_model.flow_out_model", fsite, out_mask), out_mask, row, n, site, 1)   # :88-89
     in_mask = row > col                                                      # :91
     in_in = torch.cat([x[col[in_mask]], e[in_mask]], dim=1)                  # :92-93
-    flow_in = AGG[agg](mlp(in_in, W, "MPNet.node_model.flow_in_model"), row[in_mask], n)       # :94-96
+    flow_in = _aggregate(agg, mlp(in_in, W, "MPNet.node_model.flow_in_model", fsite, in_mask), in_mask, row, n, site, 0)        # :94-96
     flow = torch.cat((flow_in, flow_out), dim=1)                             # :97
-    return torch.relu(linear(flow, W["MPNet.node_model.node_model.0.weight"],
-                               W["MPNet.node_model.node_model.0.bias"]))    # :99, :309-310
+    return relu(linear(flow, W["MPNet.node_model.node_model.0.weight"],
+                       W["MPNet.node_model.node_model.0.bias"]), None if site is None else site + ".node")   # :99, :309-310
 
 
-def meta_layer(x, edge_index, e, W, agg):
+def meta_layer(x, edge_index, e, W, agg, site=None):
     """MetaLayer.forward (models/mpn.py:33-54): edge update, then node update on the NEW edges."""
-    e = edge_model(x, edge_index, e, W)
-    x = node_model(x, edge_index, e, W, agg)
+    e = edge_model(x, edge_index, e, W, site)
+    x = node_model(x, edge_index, e, W, agg, site)
     return x, e
 
 
-def classify(e, W):
+def classify(e, W, site=None):
     """classifier MLPGraphIndependent -> edge MLP only (models/mpn.py:114, :164-178, :238)."""
-    return mlp(e, W, "classifier.edge_model")
+    return mlp(e, W, "classifier.edge_model", None if site is None else site + ".cls")
 
 
 # ----------------------------------------------------------------------------- models/mpn.py:333-394
@@ -141,8 +228,8 @@ def forward(params, W, x, edge_index, edge_attr, return_state=False):
     L, k = params["num_enc_steps"], params["num_class_steps"]
     if x.dim() == 4:
         x = x.mean(dim=(2, 3))                                               # :351-352
-    e = mlp(edge_attr, W, "encoder.edge_model")                              # :355
-    x = mlp(x, W, "encoder.node_model")
+    e = mlp(edge_attr, W, "encoder.edge_model", "enc_e")                     # :355
+    x = mlp(x, W, "encoder.node_model", "enc_n")
     e0, x0 = e, x                                                            # :358-359
     first_class_step = L - k + 1                                             # :364
     classified, all_logits = [], []
@@ -151,8 +238,8 @@ def forward(params, W, x, edge_index, edge_attr, return_state=False):
             e = torch.cat((e0, e), dim=1)                                    # :370
         if params["reattach_initial_nodes"]:
             x = torch.cat((x0, x), dim=1)                                    # :372
-        x, e = meta_layer(x, edge_index, e, W, agg)                          # :376
-        dec = classify(e, W)                                                 # :377 -> :114
+        x, e = meta_layer(x, edge_index, e, W, agg, f"s{step}")              # :376
+        dec = classify(e, W, f"s{step}")                                     # :377 -> :114
         all_logits.append(dec)
         if step >= first_class_step:                                         # :379-381
             classified.append(dec)

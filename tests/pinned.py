@@ -1,0 +1,106 @@
+"""Decision-pinned gradient checks (helpers; used by tests/test_gpu_pinned.py and tools/diag).
+
+The hot path is piecewise linear (ReLU, max): where a pre-activation sits within fp32 noise of zero, two correct fp32
+evaluations may take different branches, and the gradient -- discontinuous there -- then differs by far more than rounding
+noise (measured: the fp32 ORACLE against the float64 oracle moves by up to 7e-3 relative L2 on cfg-A graphs with sum
+aggregation, profiles/r02/grad_seed_sweep.txt).  So the comparison is split in two statements that ARE sharp:
+
+ 1. decisions: the HIP forward's ReLU / arg-max decisions (read back with mpnhip_debug_saved) agree with the float64 oracle's
+    except on knife-edge units -- the oracle's own pre-activation there is within `margin` of zero relative to the layer's rms;
+ 2. gradients: on the branch the HIP forward took (decisions imposed on the float64 oracle) every gradient agrees to fp32
+    accumulation noise -- a bound 10-100x tighter than the 2e-4 of the unpinned comparison, at any graph size.
+"""
+import numpy as np
+import torch
+
+from mpntrackseg_amd import capi
+from mpntrackseg_amd.autograd import native_backward, native_forward_saved
+from oracle import mpn_oracle as O
+
+
+def hip_run(model, g, r, dev):
+    """Training forward + backward through the C ABI with the forward's decisions read back.
+    Returns (logits [L,E], {name: grad}, decisions {site: CPU tensor}, path counters)."""
+    x = torch.from_numpy(g["x"]).to(dev)
+    ea = torch.from_numpy(g["edge_attr"]).to(dev)
+    ei = torch.from_numpy(g["edge_index"]).to(dev)
+    N, E = x.shape[0], ea.shape[0]
+    L = int(model.num_enc_steps)
+    pg = capi.PreparedGraph(ei, N, validate=True)
+    logits = torch.empty((max(L, 1), E), dtype=torch.float32, device=dev)
+    capi.path_counters(reset=True)
+    ws = native_forward_saved(model, pg, x, ea, logits)
+    given = {}
+
+    def take(site, what, step=0, layer=0):
+        given[site] = (capi.saved_activation(model, pg, ws, what, step, layer) > 0).cpu()
+
+    n_en = len(model.encoder.node_model.linears())
+    n_ee = len(model.encoder.edge_model.linears())
+    n_e = len(model.MPNet.edge_model.edge_model.linears())
+    n_f = len(model.MPNet.node_model.flow_in_model.linears())
+    cls = model.classifier.edge_model.linears()
+    for i in range(n_en):
+        take("enc_n.%d" % i, "enc_node" if i + 1 < n_en else "x", 0, i)
+    for i in range(n_ee):
+        take("enc_e.%d" % i, "enc_edge" if i + 1 < n_ee else "e", 0, i)
+    for s in range(1, L + 1):
+        for i in range(n_e):
+            take("s%d.edge.%d" % (s, i), "edge_hidden" if i + 1 < n_e else "e", s, i)
+        for i in range(n_f):
+            take("s%d.flow.%d" % (s, i), "flow_hidden" if i + 1 < n_f else "msg", s, i)
+        for i in range(len(cls) - 1):
+            take("s%d.cls.%d" % (s, i), "cls_hidden", s, i)
+        take("s%d.node" % s, "x", s)
+        if model.MPNet.node_model.node_agg_fn.name == "max":
+            given["s%d.argmax" % s] = capi.saved_activation(model, pg, ws, "argmax", s).cpu().long()
+    params = model.hot_path_parameters()
+    grads = {id(p): torch.zeros_like(p) for p in params}
+    gx, gea = native_backward(model, pg, x, ea, torch.from_numpy(r).to(dev), ws, grads, need_gx=True, need_gea=True)
+    torch.cuda.synchronize()
+    counts = capi.path_counters(reset=True)
+    names = {id(p): k for k, p in model.named_parameters()}
+    out = {names[i]: t.double().cpu().numpy() for i, t in grads.items()}
+    out["grad_x"], out["grad_edge_attr"] = gx.double().cpu().numpy(), gea.double().cpu().numpy()
+    return logits.double().cpu().numpy(), out, given, counts
+
+
+def oracle_run(params, W, g, r, given=None, mode=None, dtype=torch.float64):
+    """float64 oracle forward + autograd; with `given` decisions in `mode` 'compare' or 'impose' (oracle.Decisions)."""
+    Wt = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in W.items()}
+    x = torch.from_numpy(g["x"]).to(dtype).requires_grad_(True)
+    ea = torch.from_numpy(g["edge_attr"]).to(dtype).requires_grad_(True)
+    d = O.Decisions(given, mode) if given is not None else None
+    if d is not None:
+        with O.decisions(d):
+            _, lg, _, _ = O.forward(params, Wt, x, torch.from_numpy(g["edge_index"]), ea, return_state=True)
+    else:
+        _, lg, _, _ = O.forward(params, Wt, x, torch.from_numpy(g["edge_index"]), ea, return_state=True)
+    lg = torch.stack([l.view(-1) for l in lg])
+    keys = list(Wt)
+    ts = [x, ea] + [Wt[k] for k in keys]
+    gr = torch.autograd.grad((lg * torch.from_numpy(r).to(dtype)).sum(), ts, allow_unused=True)
+    gr = [v if v is not None else torch.zeros_like(t) for v, t in zip(gr, ts)]
+    out = {k: v.double().numpy() for k, v in zip(keys, gr[2:])}
+    out["grad_x"], out["grad_edge_attr"] = gr[0].double().numpy(), gr[1].double().numpy()
+    return lg.detach().double().numpy(), out, d
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def max_rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def compare_grads(got, ref, l2_tol, max_tol):
+    """(failures, report lines) over every tensor of `ref`"""
+    bad, log = [], []
+    for k in ref:
+        l2, mx = rel_l2(got[k], ref[k]), max_rel(got[k], ref[k])
+        line = "%-52s rel_l2 %.2e  max/max %.2e" % (k, l2, mx)
+        log.append(line)
+        if not (l2 <= l2_tol and mx <= max_tol):
+            bad.append(line)
+    return bad, log

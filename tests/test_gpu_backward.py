@@ -2,7 +2,10 @@
 (a) the reference's own autograd results stored in tests/golden/g1_tiny_*.npz and (b) torch autograd of
 the CPU oracle.  Loss = sum_steps sum_edges logit * r (r seeded), so every step's logits receive a
 gradient, as the mask branch does in the reference.
-Tolerance: max |d| <= 2e-4 * max|ref| per tensor (fp32 re-association over up to 50k-term sums)."""
+Tolerance: max |d| <= 2e-4 * max|ref| per tensor (fp32 re-association over up to 50k-term sums) on the small graphs;
+`robust=True` cases (cfg-A / cfg-B sizes, max aggregation) run the DECISION-PINNED comparison of tests/pinned.py instead:
+ReLU / arg-max decisions must agree with the float64 oracle up to knife-edge units, and on the branch taken every gradient
+must agree to 2e-5 (tests/gradcheck.py explains why an unpinned bound cannot be sharp there)."""
 import numpy as np
 import pytest
 import torch
@@ -74,33 +77,36 @@ def test_g1_reference_autograd(golden, agg):
         assert nerr(pg[k], z["G:" + k]) < GTOL, k
 
 
-def close_enough(a, b, tol, robust):
-    """robust=True (max aggregation on larger graphs): the sub-gradient of max is discontinuous where two
-    messages of a segment nearly tie, so an fp32 re-association difference of 1e-7 in the forward can pick
-    the other arg max and reroute a gradient path.  Measured on the ORACLE ITSELF (cfg-A, max): perturbing x
-    by 1e-7 relative moves its own grad_x by 6e-3 of the max in 21 node rows (sum aggregation: 5e-7).
-    The element-wise bound therefore cannot hold; require a small overall error instead."""
-    if not robust:
-        return nerr(a, b) < tol
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    rel_l2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
-    return rel_l2 < 1e-2 and nerr(a, b) < 5e-2
+def close_enough(a, b, tol, robust, name="", log=None):
+    from gradcheck import grad_close
+    return grad_close(a, b, tol, robust, name, log)
 
 
-def check_against_oracle(params, W, g, seed=11, tol=GTOL, robust=False):
+def check_against_oracle(params, W, g, seed=11, tol=GTOL, robust=False, precision="fp32", logit_check=None):
+    if robust:
+        import test_gpu_pinned as tp
+        tp.run_case(params, W, g, precision, seed=seed)
+        return
     L = max(params["num_enc_steps"], 1)
     E = g["edge_index"].shape[1]
     r = synth.normal(seed, (L, E))
     model = make_model(params, W)
+    model.gemm_precision = precision
     lo, gx, gea, pg = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r)
     lr, rx, rea, rpg = oracle_grads(params, W, g["x"], g["edge_index"], g["edge_attr"], r)
-    assert nerr(lo, lr) < 1e-4
-    def stats(a, b):
-        return "max %.3g rel_l2 %.3g" % (nerr(a, b), float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-12)))
-    assert close_enough(gx, rx, tol, robust), "grad_x " + stats(gx, rx)
-    assert close_enough(gea, rea, tol, robust), "grad_edge_attr " + stats(gea, rea)
-    for k in W:
-        assert close_enough(pg[k], rpg[k], tol, robust), k + " " + stats(pg[k], rpg[k])
+    if logit_check is not None:
+        logit_check(lo, lr)
+    elif params["node_agg_fn"] == "sum":
+        assert nerr(lo, lr) < 1e-4 or float(np.abs(lo - lr).max()) < 1e-4
+    else:
+        assert float(np.abs(lo.astype(np.float64) - lr).max()) <= 1e-4     # mean / max: absolute
+    log, bad = [], []
+    for name, a, b in [("grad_x", gx, rx), ("grad_edge_attr", gea, rea)] + [(k, pg[k], rpg[k]) for k in W]:
+        ok, msg = close_enough(a, b, tol, robust, name, log)
+        if not ok:
+            bad.append(msg)
+    print("\n".join(log))
+    assert not bad, "\n".join(bad)
 
 
 @pytest.mark.parametrize("agg", ["sum", "mean", "max"])

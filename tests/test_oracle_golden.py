@@ -183,3 +183,50 @@ def test_g8_embedding_loader_oracle_matches_reference(golden):
     # the reference's assertion fires when the query is not in stored order
     with pytest.raises(AssertionError):
         EO.load_precomputed_embeddings(z["stored_1d"], z["stored_frame"], z["det_frame"][::-1], z["det_id"][::-1])
+
+
+def _oracle_fwd_bwd(params, W0, g, r):
+    W = O.to_tensors(W0, requires_grad=True)
+    xp = torch.from_numpy(g["x"]).requires_grad_(True)
+    ea = torch.from_numpy(g["edge_attr"]).requires_grad_(True)
+    _, logits, xL, eL = O.forward(params, W, xp, torch.from_numpy(g["edge_index"]), ea, return_state=True)
+    lg = torch.stack([l.view(-1) for l in logits])
+    loss = (lg * torch.from_numpy(r)).sum()
+    keys = list(W.keys())
+    grads = torch.autograd.grad(loss, [xp, ea] + [W[k] for k in keys])
+    return lg.detach().numpy(), xL.detach().numpy(), {k: v.numpy() for k, v in zip(keys, grads[2:])}, grads[0].numpy(), grads[1].numpy()
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g12_dense_knn_forward_and_reference_autograd(golden, agg):
+    """BASELINE.json configs[2] stand-in: the oracle's forward and its autograd against the REFERENCE's on the dense kNN graph."""
+    from gradcheck import check_grads_against_fixture
+    z = golden(f"g12_dense_knn_{agg}.npz")
+    g = synth.make_knn_graph(frames=20, dets=25, top_k=60, seed=3, node_in_dim=64)
+    E = g["edge_index"].shape[1]
+    assert E == int(z["E"]) and synth.checksum(g["edge_index"]) == int(z["cs_edge_index"]) and E >= 48 * 500
+    params = synth.model_params(32, 12, agg, node_in_dim=64)
+    W0 = synth.make_weights(params, seed=7, gain=float(z["gain"]))
+    lg, xL, pg, gx, gea = _oracle_fwd_bwd(params, W0, g, synth.normal(11, (12, E)))
+    assert np.abs(lg[:, z["edge_ids"]] - z["logits"]).max() < 2e-6 * max(1.0, float(z["step_max"].max()))
+    assert rel_err(xL, z["x_final"]) < 2e-6
+    bad, log = check_grads_against_fixture(z, pg, gx, gea, tol=1e-5)
+    assert not bad, "\n".join(bad)
+
+
+def test_g11_cfgB_sum_o1_forward_and_reference_autograd(golden):
+    """The headline workload (cfg-B, sum, 12 steps) with O(1) logits: oracle forward + autograd against the reference's."""
+    from gradcheck import check_grads_against_fixture
+    z = golden("g11_cfgB_sum_o1.npz")
+    c = synth.CONFIGS["B"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    assert synth.checksum(g["x"]) == int(z["cs_x"])
+    params = synth.model_params(c["d"], c["L"], "sum")
+    W0 = synth.make_weights(params, seed=7, gain=float(z["gain"]))
+    assert synth.checksum(np.concatenate([v.ravel() for v in W0.values()])) == int(z["cs_weights"])
+    lg, xL, pg, gx, gea = _oracle_fwd_bwd(params, W0, g, synth.normal(11, (c["L"], c["E"])))
+    q = np.abs(lg[:, z["edge_ids"]] - z["logits"]) / np.maximum(1.0, np.abs(z["logits"]))
+    assert q.max() < 2e-6
+    assert rel_err(xL[:64], z["x_final_rows"]) < 2e-6
+    bad, log = check_grads_against_fixture(z, pg, gx, gea, tol=1e-5)
+    assert not bad, "\n".join(bad)

@@ -19,6 +19,9 @@ Fixtures:
   g3_cfgB_{agg}.npz            cfg-B (5000/50000/d128/L12): logits at 4096 fixed edges x 12 steps +
                                per-step sum / abs-sum / max checksums.
   g0_l0.npz                    num_enc_steps == 0 special case (mpn.py:387-389).
+  g11_cfgB_sum_o1.npz          cfg-B, sum aggregation, 12 steps, weights scaled to O(1) logits: sampled logits, checksums and the
+                               reference's autograd gradients (the headline training workload).
+  g12_dense_knn_{agg}.npz      dense reciprocal-kNN graph (E / N = 64, d = 32, 12 steps): sampled logits + reference autograd.
   g7_graph_utils.npz           the reference's utils/graph.py on a synthetic detection table (synth.make_detections):
                                get_time_valid_conn_ixs ('max' and 3 frames), compute_edge_feats_dict, F.pairwise_distance,
                                get_knn_mask (reciprocal on/off; one direction per pair and both directions).
@@ -345,6 +348,76 @@ def gen_cfg(mpn, name, tag, sample=None):
         print(tag, agg, "max|logit| per step", rec["step_max"][[0, -1]])
 
 
+def _grad_record(rec, names, grads, gx, gea, ids_e):
+    """Gradient fixtures: small tensors whole, large ones as their first 20,000 elements + the Euclidean norm of all."""
+    for k, gr in zip(names, grads):
+        a = gr.numpy()
+        rec["G:" + k] = a if a.size <= 20000 else a.reshape(-1)[:20000].copy()
+        rec["Gn:" + k] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    a = gx.numpy()
+    rec["grad_x"] = a if a.size <= 40000 else a[:16].copy()
+    rec["grad_x_norm"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    rec["grad_x_rownorm"] = np.sqrt((a.astype(np.float64) ** 2).sum(1))
+    b = gea.numpy()
+    rec["grad_edge_attr"] = b[ids_e]
+    rec["grad_edge_attr_norm"] = np.float64(np.sqrt((b.astype(np.float64) ** 2).sum()))
+
+
+def _ref_fwd_bwd(mpn, params, W, g, r):
+    model = build_reference_model(mpn, params, W)
+    xp = torch.from_numpy(g["x"]).clone().requires_grad_(True)
+    ea = torch.from_numpy(g["edge_attr"]).clone().requires_grad_(True)
+    logits, xL, eL = ref_hot_path(model, xp, torch.from_numpy(g["edge_index"]), ea)
+    L = len(logits)
+    loss = sum((logits[s].view(-1) * torch.from_numpy(r[s])).sum() for s in range(L))
+    hot = {k: p for k, p in model.named_parameters() if k in W}
+    grads = torch.autograd.grad(loss, [xp, ea] + list(hot.values()))
+    lg = np.stack([t.detach().numpy().reshape(-1) for t in logits])
+    return lg, xL.detach(), eL.detach(), list(hot.keys()), grads
+
+
+def gen_g11(mpn):
+    """The HEADLINE workload with O(1) logits: cfg-B (5k nodes / 50k edges / 128-d / 12 steps), node_agg_fn = 'sum' (the shipped
+    default), He weights scaled by 0.7 so that the sum-aggregated magnitudes stay O(1) over 12 steps (max |logit| 9.4 at step
+    12) -- per-element logit parity means something there -- plus the REFERENCE's autograd of loss = sum logits * r."""
+    c = synth.CONFIGS["B"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    params = synth.model_params(c["d"], c["L"], "sum")
+    W = synth.make_weights(params, seed=7, gain=0.7)
+    r = synth.normal(11, (c["L"], c["E"]))
+    lg, xL, eL, names, grads = _ref_fwd_bwd(mpn, params, W, g, r)
+    ids = (synth.uniform01(99, 4096, stream=0) * c["E"]).astype(np.int64)
+    rec = {"gain": np.float64(0.7), "cs_x": np.uint64(synth.checksum(g["x"])),
+           "cs_weights": np.uint64(synth.checksum(np.concatenate([v.ravel() for v in W.values()]))),
+           "edge_ids": ids, "logits": lg[:, ids], "step_sum": lg.astype(np.float64).sum(1),
+           "step_abssum": np.abs(lg).astype(np.float64).sum(1), "step_max": np.abs(lg).max(1),
+           "x_final_rows": xL.numpy()[:64], "e_final_rows": eL.numpy()[ids[:256]]}
+    _grad_record(rec, names, grads[2:], grads[0], grads[1], ids)
+    np.savez_compressed(os.path.join(GOLD, "g11_cfgB_sum_o1.npz"), **rec)
+    print("g11 max|logit| per step", rec["step_max"])
+
+
+def gen_g12(mpn):
+    """BASELINE.json configs[2] stand-in (SURVEY.md section 8d cfg-C): dense reciprocal-kNN graph, 20 frames x 25 detections,
+    top-60 (E / N = 64: long segments -- the block-per-segment reductions of the HIP backward), reference dims d = 32, 12 steps,
+    all three aggregations, weights scaled so that the logits stay O(1); reference forward AND reference autograd."""
+    g = synth.make_knn_graph(frames=20, dets=25, top_k=60, seed=3, node_in_dim=64)
+    E = g["edge_index"].shape[1]
+    ids = (synth.uniform01(98, 8192, stream=0) * E).astype(np.int64)
+    for agg, gain in (("sum", 0.45), ("mean", 1.0), ("max", 1.0)):
+        params = synth.model_params(32, 12, agg, node_in_dim=64)
+        W = synth.make_weights(params, seed=7, gain=gain)
+        r = synth.normal(11, (12, E))
+        lg, xL, eL, names, grads = _ref_fwd_bwd(mpn, params, W, g, r)
+        rec = {"gain": np.float64(gain), "E": E, "cs_edge_index": np.uint64(synth.checksum(g["edge_index"])),
+               "edge_ids": ids, "logits": lg[:, ids], "step_sum": lg.astype(np.float64).sum(1),
+               "step_abssum": np.abs(lg).astype(np.float64).sum(1), "step_max": np.abs(lg).max(1),
+               "x_final": xL.numpy(), "e_final_rows": eL.numpy()[ids[:1024]]}
+        _grad_record(rec, names, grads[2:], grads[0], grads[1], ids)
+        np.savez_compressed(os.path.join(GOLD, f"g12_dense_knn_{agg}.npz"), **rec)
+        print("g12", agg, "E", E, "max|logit|", rec["step_max"][[0, -1]])
+
+
 def gen_g7():
     """utils/graph.py of the reference (graph construction / kNN pruning helpers)."""
     import pandas as pd
@@ -425,7 +498,7 @@ def gen_g8():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3")
+    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3,g11,g12")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     os.makedirs(GOLD, exist_ok=True)
@@ -440,6 +513,8 @@ def main():
     if "g8" in only: gen_g8()
     if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
     if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
+    if "g11" in only: gen_g11(mpn)
+    if "g12" in only: gen_g12(mpn)
 
 
 if __name__ == "__main__":
