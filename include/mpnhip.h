@@ -200,6 +200,14 @@ int mpnhip_segment_reduce(const float* src, const int64_t* row, int64_t m, int d
 int mpnhip_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n,
                   int k, int relu, void* stream);
 
+/* The weight / bias gradient autograd derives for one nn.Linear of models/mlp.py, batched over the
+ * message-passing steps that share the weight:  grad_w[o][c] += sum_b sum_m dZ[b][m][o] * H[b][m][c],  grad_b[o] += sum dZ[b][m][o].
+ * dZ [nbatch][rows][n_out] (gradient at the layer's pre-activation), H [nbatch][rows][k_in] (the layer's input), both dense
+ * row-major; grad_w [n_out][k_in], grad_b [n_out] or NULL.  Fixed summation order (no float atomics): bitwise reproducible. */
+size_t mpnhip_weight_grad_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch);
+int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* MLP.forward (models/mlp.py:27-28): all layers; scratch [2, M, max(out_dims)] floats. */
 size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m);
 int mpnhip_mlp_forward(const mpnhip_mlp* mlp, const float* x, float* y, int64_t m, void* workspace,
@@ -337,6 +345,9 @@ int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_u
  * a prepared graph: src [E, dim] in SORTED edge order, out [N, 2*dim]. */
 int mpnhip_time_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, const float* src, int dim, int agg,
                           float* out, int iters, float* avg_us, void* stream);
+/* Average duration (us) of `iters` back-to-back mpnhip_weight_grad calls (product + slab sum). */
+int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
+                            void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream);
 /* Average duration (us) of `iters` launches of y = relu(x W^T + b). */
 int mpnhip_time_linear(const float* x, const float* w, const float* b, float* y, int64_t m, int n, int k, int iters,
                        float* avg_us, void* stream);

@@ -117,6 +117,8 @@ struct TnArgs {
     int nbatch;            // >= 1
     int chunk, nsplit;     // filled by tn_plan: rows per chunk, chunks per batch
     int red_ny, red_stage; // slab reduction in two stages (launch_gemm_tn): ny partial sums first, then their sum
+    int xcd_map;           // 1: XCD-aware block -> (tile, chunk) mapping
+    int tiles, ny8;        // filled by launch_gemm_tn: output tiles, row chunks x batches padded to a multiple of 8 (XCD mapping)
 };
 void tn_plan(TnArgs& a);
 size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);

@@ -199,6 +199,11 @@ __device__ __forceinline__ void lds_wait(bf16x8 (&a)[3]) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
 }
 __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const Split8& b) {
+#ifdef MPNHIP_SPLIT9   // diagnostic build: all nine piece products
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[2], acc, 0, 0, 0);
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.p[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[1], acc, 0, 0, 0);

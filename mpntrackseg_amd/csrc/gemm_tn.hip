@@ -30,6 +30,7 @@ __device__ __forceinline__ float4 keep4t(bool ok, float4 v) {
 // field-wise select of the group (indexing the by-value kernel argument with blockIdx.z would force
 // the whole struct into scratch memory)
 #define TN_G(field) (blockIdx.z == 0 ? args.g[0].field : args.g[1].field)
+#define TN_GG(grp, field) ((grp) == 0 ? args.g[0].field : args.g[1].field)
 
 template <int TBN>
 __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
@@ -43,15 +44,28 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     const int li = lane & 31, lh = lane >> 5;
     const int n_out = args.n_out, k_in = args.k_in, csplit = args.csplit;
     const int ntile_c = (k_in + TBN - 1) / TBN;
-    const int o0 = (blockIdx.x / ntile_c) * TBM;
-    const int c0 = (blockIdx.x % ntile_c) * TBN;
+    // XCD-aware block -> (tile, row chunk) mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
+    // b % 8, each with its own 4 MB L2): the output tiles of ONE row chunk all read the same dZ / H rows, so they are given
+    // to consecutive slots of the SAME XCD -- they start together, and the rows one of them pulls into that L2 serve the
+    // others (before: the tiles of a chunk were consecutive block ids = 5 different XCDs, every re-read went to the
+    // Infinity Cache / HBM and the kernel ran at that bandwidth, not at the MFMA rate).  Placement is for speed only.
+    int bid = blockIdx.x;
+    const int per_group = args.tiles * args.ny8;
+    const int grp = bid / per_group;
+    bid -= grp * per_group;
+    const int slot = args.xcd_map ? bid >> 3 : bid;
+    const int tile = slot % args.tiles;
+    const int by = args.xcd_map ? (slot / args.tiles) * 8 + (bid & 7) : slot / args.tiles;
+    if (by >= args.nsplit * args.nbatch) return;
+    const int o0 = (tile / ntile_c) * TBM;
+    const int c0 = (tile % ntile_c) * TBN;
 
-    const int* rbp = TN_G(row_begin);
-    const int* rep = TN_G(row_end);
+    const int* rbp = TN_GG(grp, row_begin);
+    const int* rep = TN_GG(grp, row_end);
     const int rb = rbp ? *rbp : 0;
-    const int re = rep ? *rep : (int)TN_G(m_static);
-    const int batch = blockIdx.y / args.nsplit;
-    const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
+    const int re = rep ? *rep : (int)TN_GG(grp, m_static);
+    const int batch = by / args.nsplit;
+    const int r0 = rb + (by % args.nsplit) * args.chunk;
     int r1 = r0 + args.chunk;
     r1 = r1 < re ? r1 : re;
     if (r0 >= r1) return;  // empty chunk: the reduce kernel skips it too
@@ -64,18 +78,21 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     int cc = c0 + bc;
     cc = cc + 3 < k_in ? cc : k_in - 4;
     const bool bseg2 = cc >= csplit;                     // csplit % 4 == 0: a float4 lies in one segment
-    const float* hbase = (bseg2 ? TN_G(H2) : TN_G(H)) + (bseg2 ? cc - csplit : cc) +
-                         (int64_t)batch * (bseg2 ? TN_G(h2_bstride) : TN_G(h_bstride));
-    const int64_t ldh = bseg2 ? TN_G(ldh2) : TN_G(ldh);
-    const float* zbase = TN_G(dZ) + oc + (int64_t)batch * TN_G(z_bstride);
-    const int64_t ldz = TN_G(ldz);
+    const float* hbase = (bseg2 ? TN_GG(grp, H2) : TN_GG(grp, H)) + (bseg2 ? cc - csplit : cc) +
+                         (int64_t)batch * (bseg2 ? TN_GG(grp, h2_bstride) : TN_GG(grp, h_bstride));
+    const int64_t ldh = bseg2 ? TN_GG(grp, ldh2) : TN_GG(grp, ldh);
+    const float* zbase = TN_GG(grp, dZ) + oc + (int64_t)batch * TN_GG(grp, z_bstride);
+    const int64_t ldz = TN_GG(grp, ldz);
 
     f32x16 acc[TW];
 #pragma unroll
     for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float bsum = 0.f;
+    // bias gradient = column sums of dZ: accumulated from the loader's own registers (every thread owns four columns of two rows
+    // of each stage: 8 adds), combined across the 16 row groups once at the end -- no LDS column walk in the stage loop, and
+    // no wave that is slower than the others at the barrier
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 a_reg[2], b_reg[NB];
 
     // raw loads only (rows clamped); the zero-select for rows past the chunk end happens at LDS-store time so
@@ -94,8 +111,11 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
     };
     auto store = [&](int m0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            *reinterpret_cast<float4*>(&As[(ar + 16 * j) * PA + ac]) = keep4t(m0 + ar + 16 * j < r1, a_reg[j]);
+        for (int j = 0; j < 2; ++j) {
+            const float4 v = keep4t(m0 + ar + 16 * j < r1, a_reg[j]);
+            *reinterpret_cast<float4*>(&As[(ar + 16 * j) * PA + ac]) = v;
+            bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             *reinterpret_cast<float4*>(&Bs[(br + (1024 / TBN) * j) * PB + bc]) = keep4t(m0 + br + (1024 / TBN) * j < r1, b_reg[j]);
@@ -130,15 +150,11 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
                 for (int j = 0; j < TW; ++j) b_cur[j] = b_nxt[j];
             }
         }
-        if (c0 == 0 && tid < TBM) {
-#pragma unroll
-            for (int kk = 0; kk < TBK; ++kk) bsum += As[kk * PA + tid];
-        }
         __syncthreads();
     }
     // ---- write the partial tile into this chunk's slab --------------------------------------------
     const int kpad = k_in + 4;
-    float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * kpad;
+    float* slab = TN_GG(grp, slab) + (size_t)by * n_out * kpad;
 #pragma unroll
     for (int tj = 0; tj < TW; ++tj) {
         const int c = c0 + wn * 32 * TW + tj * 32 + li;
@@ -148,7 +164,17 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
             if (o < n_out && c < k_in) slab[(size_t)o * kpad + c] = acc[tj][r];
         }
     }
-    if (c0 == 0 && tid < TBM && o0 + tid < n_out) slab[(size_t)(o0 + tid) * kpad + k_in] = bsum;
+    if (c0 == 0) {
+        // the 16 row groups' partial column sums meet in LDS (As is free after the loop's last barrier), fixed order
+        *reinterpret_cast<float4*>(&As[ar * PA + ac]) = bacc;
+        __syncthreads();
+        if (tid < TBM && o0 + tid < n_out) {
+            float bsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += As[r * PA + tid];
+            slab[(size_t)(o0 + tid) * kpad + k_in] = bsum;
+        }
+    }
 }
 
 // Any shape / alignment / row gathers (the K = 6 edge-encoder input read through the sort permutation, the
@@ -419,11 +445,18 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
     count_path(fast ? PC_TN_MFMA : (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL") ? PC_TN_SMALL : PC_TN_GENERIC));
     if (fast) {
         const int tbn = a.k_in <= 64 ? 64 : 128;
-        int tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn);
+        a.tiles = ((a.n_out + TBM - 1) / TBM) * ((a.k_in + tbn - 1) / tbn);
+        a.ny8 = (a.nsplit * a.nbatch + 7) / 8 * 8;   // (row chunks x batches, padded to the 8 XCDs: see the kernel's block mapping)
+        // measured on MI355X (tools/wgrad_bench.py, cfg-B shapes, 5 steps per product): the XCD-aware mapping pays where a handful
+        // of output tiles share every H row (edge layer 1, 5 tiles: 282 -> 259 us) and costs a little elsewhere (3 tiles: 156 ->
+        // 176 us; 128 tiles: 140 -> 173 us -- there the chunks' tiles no longer start together)
+        a.xcd_map = a.tiles >= 4 && a.tiles <= 8 ? 1 : 0;
+        if (const char* e = getenv("MPNHIP_TN_XCD")) a.xcd_map = e[0] == '1';   // A-B switch for measurements
+        const unsigned nblocks = (unsigned)(a.tiles * a.ny8 * a.ngroups);
         if (tbn == 64)
-            hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
+            hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(nblocks), dim3(TNT), 0, s, a);
         else
-            hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles, a.nsplit * a.nbatch, a.ngroups), dim3(TNT), 0, s, a);
+            hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(nblocks), dim3(TNT), 0, s, a);
     } else if (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL")) {
         hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(1, a.nsplit * a.nbatch, a.ngroups), dim3(256), 0, s, a);
     } else {
@@ -462,3 +495,62 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
 }
 
 }  // namespace mpnhip
+
+using namespace mpnhip;
+
+extern "C" size_t mpnhip_weight_grad_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch) {
+    if (n_out < 1 || k_in < 1 || rows < 0) return 0;
+    return align_up(tn_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch) * sizeof(float), 256) + 256;
+}
+
+static int weight_grad_args(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
+                            void* workspace, size_t workspace_bytes, TnArgs* out) {
+    MPN_CHECK_ARG(n_out >= 1 && k_in >= 1 && rows >= 0 && nbatch >= 1, "weight_grad: bad sizes");
+    MPN_CHECK_ARG((dZ && H && grad_w) || rows == 0, "weight_grad: null pointer");
+    const size_t need = mpnhip_weight_grad_workspace_bytes(n_out, k_in, rows, nbatch);
+    if (rows > 0 && (!workspace || workspace_bytes < need)) {
+        set_error("weight_grad: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    TnArgs a = {};
+    a.ngroups = 1; a.n_out = n_out; a.k_in = k_in; a.csplit = k_in; a.m_upper = rows; a.nbatch = nbatch;
+    TnGroup& g = a.g[0];
+    g.dZ = dZ; g.ldz = n_out; g.z_bstride = rows * n_out;
+    g.H = H; g.ldh = k_in; g.h_bstride = rows * k_in;
+    g.m_static = rows;
+    g.slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    g.grad_w = grad_w; g.ldw = k_in; g.grad_b = grad_b;
+    *out = a;
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
+                                  float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
+    TnArgs a;
+    MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
+    if (rows == 0) return MPNHIP_OK;
+    return launch_gemm_tn(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
+                                       float* grad_b, void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(avg_us && iters > 0 && rows > 0, "time_weight_grad: bad argument");
+    TnArgs a;
+    MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
+    hipEvent_t t0, t1;
+    MPN_HIP(hipEventCreate(&t0));
+    MPN_HIP(hipEventCreate(&t1));
+    MPN_TRY(launch_gemm_tn(a, s));
+    MPN_HIP(hipEventRecord(t0, s));
+    for (int i = 0; i < iters; ++i) MPN_TRY(launch_gemm_tn(a, s));
+    MPN_HIP(hipEventRecord(t1, s));
+    MPN_HIP(hipEventSynchronize(t1));
+    float ms = 0.f;
+    MPN_HIP(hipEventElapsedTime(&ms, t0, t1));
+    *avg_us = ms * 1000.f / iters;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return MPNHIP_OK;
+}
+
