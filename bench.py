@@ -177,6 +177,7 @@ def main():
 
     if mode == "fwd":
         model.eval()
+        model.keep_packed_weights = True   # inference with fixed weights (MOTMPNet.frozen_weights): packed images are reused
 
         def step():
             with torch.no_grad():
@@ -192,7 +193,8 @@ def main():
         step()
     profiled = rank == 0 and not args.no_roofline
     if profiled:
-        lib.mpnhip_profile_enable(6)  # HIP events attached to every 6th launch of the dominant kernel and of the aggregation kernel
+        lib.mpnhip_profile_enable(6)  # HIP events attached to every 6th launch of each profiled kernel kind
+    capi.path_counters(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -203,12 +205,19 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = None
+    counts = capi.path_counters(reset=True)
     if profiled:
+        # the two kernels of the backward first (mpnhip_profile_read resets every kind)
+        extra = {}
+        for name, kind in (("chain_bwd", 2), ("weight_grad", 3)):
+            u, n, w = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_double(0)
+            capi.check(lib.mpnhip_profile_read_kind(kind, ctypes.byref(u), ctypes.byref(n), ctypes.byref(w)), "profile_read_kind")
+            extra[name] = (u.value, n.value, w.value)
         gu, gc, au, ac, eu = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_float(0), ctypes.c_int(0), ctypes.c_float(0)
         capi.check(lib.mpnhip_profile_read(ctypes.byref(gu), ctypes.byref(gc), ctypes.byref(au), ctypes.byref(ac),
                                            ctypes.byref(eu)), "profile_read")
         lib.mpnhip_profile_enable(0)
-        prof = (gu.value, gc.value, au.value, ac.value, eu.value)
+        prof = (gu.value, gc.value, au.value, ac.value, eu.value, extra, {k: v / float(args.steps) for k, v in counts.items()})
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -238,13 +247,14 @@ def main():
     if prof is not None:
         keep = []
         chain = bool(lib.mpnhip_edge_chain_active(model.c_model(keep)))
-        out.update(rooflines(prof, c, args, N, E, chain))
+        out.update(rooflines(prof, c, args, N, E, chain, mode))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, W, g, mode == "train")
     def forward_rate():
         # forward-only rate beside the training rate (the north-star target is quoted on forward)
         model.eval()
-        with torch.no_grad():
+        # (inference: the weights do not change between the calls -- their packed images are kept, MOTMPNet.frozen_weights)
+        with torch.no_grad(), model.frozen_weights():
             for _ in range(3):
                 model.hot_path(x, ei, ea, holder=holder)
             torch.cuda.synchronize()
@@ -289,19 +299,25 @@ def main():
 def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
     tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
-    path = os.path.join(REPO, "profiles", "r01", "pmc_summary.json" if precision == "fp32" else "pmc_summary_split.json")
     if cfg_name != "B" or precision == "bf16":
         return None
-    try:
-        return json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(REPO, "profiles", rnd, "pmc_summary.json" if precision == "fp32" else "pmc_summary_split.json")
+        try:
+            v = json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            v = None
+        if v is not None:
+            return v
+    return None
 
 
-def rooflines(prof, c, args, N, E, chain):
-    """Roofline fractions from the in-stream HIP-event timings taken over the timed region:
-    dominant kernel = first-layer edge-MLP GEMM (fp32 MFMA); HBM-bound kernel = segmented aggregation."""
-    gemm_us, gemm_n, agg_us, agg_n, empty_us = prof
+def rooflines(prof, c, args, N, E, chain, mode="fwd"):
+    """Roofline fractions from the in-stream HIP-event timings taken over the timed region (events attached to the dispatches
+    on the stream each kernel is launched on).  `roofline` is the kernel with the largest time per step IN THE MEASURED MODE:
+    inference = the fused forward chain; training = whichever of forward chain / backward chain / weight-gradient products
+    takes most of a step (round 2: the weight-gradient product kernel); the others are reported beside it."""
+    gemm_us, gemm_n, agg_us, agg_n, empty_us, extra, per_step = prof
     # avg_us: HIP events attached to the kernel's own dispatch on the launch stream (hipExtLaunchKernelGGL start / stop
     # events): the dispatch's begin -> end, what rocprofv3's kernel trace reports too (profiles/).  `empty_event_pair_us`
     # is what a plain record pair with nothing between costs on this box -- the overhead the attached events avoid.
@@ -334,6 +350,13 @@ def rooflines(prof, c, args, N, E, chain):
                            # [x_row | x_col | e] and [x_col | e'] inputs multiplied per edge), for comparability
                            "naive_flop_equivalent_tflops": 2.0 * E * ((4 * dn + 2 * de) * he + he * de + (2 * dn + de) * hn + hn * dn
                                                                       + de * hc + hc) / (gemm_us * 1e-6) / 1e12}
+        # compulsory bytes of one fused message-passing step (every distinct input read once, every
+        # output written once) -- what `traffic` (PMC, the chain kernel alone) is to be read against
+        alg_bytes = E * (2 * de * 4 + de * 4 + 8 + 4) + N * (2 * dn * 4 + dn * 4)
+        res["roofline"]["algorithmic_bytes"] = alg_bytes
+        if res["roofline"]["traffic"]:
+            res["roofline"]["traffic_over_algorithmic"] = res["roofline"]["traffic"] / alg_bytes
+        res["roofline"]["ms_per_step"] = gemm_us * c["L"] / 1e3
     elif gemm_n:
         K, Nn = 2 * de, he
         flops = 2.0 * E * K * Nn  # algorithmic: E rows x [e0|e] (2 de) x he outputs
@@ -353,6 +376,37 @@ def rooflines(prof, c, args, N, E, chain):
                                        "traffic": pmc_traffic("k_aggregate", args.config, args.precision), "avg_us": agg_us,
                                        "empty_event_pair_us": empty_us, "launches": agg_n,
                                        "algorithmic_bytes": bytes_agg}
+    if mode == "train" and "roofline" in res:
+        split = args.precision == "fp32_split"
+        peak = 157.3
+        res["roofline_fwd_chain"] = res.pop("roofline")
+        cand = {"roofline_fwd_chain": res["roofline_fwd_chain"]["ms_per_step"]}
+        bu, bn, _ = extra.get("chain_bwd", (0.0, 0, 0.0))
+        if bn and chain:
+            ke = 2 * de
+            macs_b = hn * dn + de * hn + hc * de + hc + he * de + ke * he      # B2 .. B6 of the backward chain (csrc/edge_chain.hip)
+            fl = 2.0 * E * macs_b
+            ach = fl / (bu * 1e-6) / 1e12 * (6.0 if split else 1.0)
+            pk = 2516.6 if split else peak
+            res["roofline_bwd_chain"] = {"bound": "mfma", "kernel": "edge_chain_bwd_kernel: fused activation-gradient chain of one MP step, %d edges x %d MACs" % (E, macs_b),
+                                         "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "avg_us": bu, "launches": bn,
+                                         "traffic": pmc_traffic("edge_chain_bwd", args.config, args.precision), "algorithmic_flops": fl,
+                                         "ms_per_step": bu * c["L"] / 1e3}
+            cand["roofline_bwd_chain"] = res["roofline_bwd_chain"]["ms_per_step"]
+        tu, tn_, tw = extra.get("weight_grad", (0.0, 0, 0.0))
+        if tn_:
+            per = per_step.get("gemm_tn_mfma", 0.0)
+            ach = tw / (tu * 1e-6) / 1e12
+            res["roofline_weight_grad"] = {"bound": "mfma", "kernel": "gemm_tn_kernel: dW += dZ^T H over the steps of a group (fp32 v_mfma_f32_32x32x2_f32), "
+                                                                      "%.1f launches per step, side stream" % per,
+                                           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "avg_us": tu, "launches": tn_,
+                                           "traffic": pmc_traffic("gemm_tn", args.config, args.precision),
+                                           "algorithmic_flops": tw, "launches_per_step": per, "ms_per_step": tu * per / 1e3}
+            cand["roofline_weight_grad"] = res["roofline_weight_grad"]["ms_per_step"]
+        top = max(cand, key=cand.get)
+        res["roofline"] = dict(res[top], dominant_of={k: round(v, 3) for k, v in cand.items()},
+                               what="the kernel with the largest time per training step (ms_per_step = avg_us x launches per step); "
+                                    "also listed under '%s'" % top)
     return res
 
 

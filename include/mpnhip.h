@@ -341,6 +341,17 @@ int mpnhip_edge_chain_active(const mpnhip_model* model);
 int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches,
                         float* empty_pair_us /* cost of an event pair with nothing between, for calibration */);
 
+/* The same hooks, one kernel kind at a time: MPNHIP_PROF_CHAIN = the kernel mpnhip_profile_read reports as "gemm" (forward),
+ * _AGG = the aggregation kernel, _CHAIN_BWD = the fused backward chain of mpnhip_backward, _WEIGHT_GRAD = the MFMA
+ * weight-gradient product kernel (gemm_tn_kernel; launched on the library's side stream as well as on the caller's -- the events
+ * are attached to each dispatch on whatever stream it goes to).  avg_work: average algorithmic flops per timed launch (only
+ * _WEIGHT_GRAD reports it: its launches differ in shape).  Synchronises and resets the kind's counters. */
+#define MPNHIP_PROF_CHAIN 0
+#define MPNHIP_PROF_AGG 1
+#define MPNHIP_PROF_CHAIN_BWD 2
+#define MPNHIP_PROF_WEIGHT_GRAD 3
+int mpnhip_profile_read_kind(int kind, float* avg_us, int* launches, double* avg_work);
+
 /* Average duration in microseconds of `iters` back-to-back launches of the aggregation kernel on
  * a prepared graph: src [E, dim] in SORTED edge order, out [N, 2*dim]. */
 int mpnhip_time_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, const float* src, int dim, int agg,

@@ -102,6 +102,7 @@ SIGNATURES = {
     "mpnhip_edge_chain_active": (_I, [C.POINTER(Model)]),
     "mpnhip_profile_read": (_I, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int),
                                  C.POINTER(C.c_float)]),
+    "mpnhip_profile_read_kind": (_I, [_I, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mpnhip_time_aggregate": (_I, [_P, _I, _L, _P, _I, _I, _P, _I, C.POINTER(C.c_float), _P]),
     "mpnhip_time_linear": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, C.POINTER(C.c_float), _P]),
 }

@@ -291,6 +291,8 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
     a.csplit = H2.p ? csplit : k_in;
     a.m_upper = rows;
     a.nbatch = nbatch;
+    // (with device-side row ranges the groups partition the `rows` rows between them; without, each group covers all of them)
+    a.flops = 2.0 * (double)rows * (rr ? 1 : ngroups) * nbatch * n_out * k_in;
     for (int q = 0; q < ngroups; ++q) {
         TnGroup& g = a.g[q];
         g.dZ = dZ.p;
@@ -722,7 +724,9 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             a.dE0 = p.dE0; a.dEprev = step == 1 ? p.dE0 : p.dZed[ne - 1] + (size_t)(b_ - 1) * es;
             a.wf2_out = p.wf2p[0]; a.wf2_in = p.wf2p[1]; a.wfe_out = p.wfep[0]; a.wfe_in = p.wfep[1];
             a.wc1 = p.wc1p; a.wc2 = cls.weight[1]; a.w2 = p.w2p; a.w1e = p.w1ep;
+            prof_begin(PROF_CHAIN_BWD, s);
             MPN_TRY(launch_edge_chain_bwd(a, s));
+            prof_end(PROF_CHAIN_BWD, s);
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
             if (E >= 48 * N) {
                 // dense graphs (long segments): the three reductions as ONE launch of the block-per-segment kernel

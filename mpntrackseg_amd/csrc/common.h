@@ -114,6 +114,7 @@ struct TnArgs {
     int ngroups;
     int n_out, k_in, csplit;
     int64_t m_upper;       // upper bound of the rows of ONE batch
+    double flops;          // algorithmic flops of the launch (2 rows n_out k_in over all batches / groups): profile hooks only
     int nbatch;            // >= 1
     int chunk, nsplit;     // filled by tn_plan: rows per chunk, chunks per batch
     int red_ny, red_stage; // slab reduction in two stages (launch_gemm_tn): ny partial sums first, then their sum
@@ -174,8 +175,9 @@ struct SegReduce2 {
 int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream);
 
 // in-stream event timing of two designated kernels (see mpnhip_profile_enable)
-enum { PROF_GEMM = 0, PROF_AGG = 1 };
-void prof_begin(int kind, hipStream_t s);
+enum { PROF_GEMM = 0, PROF_AGG = 1, PROF_CHAIN_BWD = 2, PROF_TN = 3, PROF_KINDS = 4 };
+// `work`: algorithmic work of the bracketed launch (flops or bytes), summed for mpnhip_profile_read_kind
+void prof_begin(int kind, hipStream_t s, double work = 0.0);
 void prof_end(int kind, hipStream_t s);
 // true (once per bracket) while a bracket is open: the events to attach to the designated kernel's dispatch
 bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop);

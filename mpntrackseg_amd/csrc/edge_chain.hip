@@ -1186,21 +1186,21 @@ int launch_edge_chain_bwd(const EdgeChainBwdArgs& a_in, hipStream_t s) {
     switch (chain_variant(a.he, a.de, a.hn, a.dn)) {
         case 128:
             if (a.split && exact)
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true, true>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<10, 2, 7, 4, true, true>), dim3(blocks), dim3(256), s, a);
             else if (a.split)
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false, true>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<10, 2, 7, 4, false, true>), dim3(blocks), dim3(256), s, a);
             else if (exact)
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, true, false>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<10, 2, 7, 4, true, false>), dim3(blocks), dim3(256), s, a);
             else
-                hipLaunchKernelGGL((edge_chain_bwd_kernel<10, 2, 7, 4, false, false>), dim3(blocks), dim3(256), 0, s, a);
+                MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<10, 2, 7, 4, false, false>), dim3(blocks), dim3(256), s, a);
             break;
         case 64:
-            if (a.split) hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((edge_chain_bwd_kernel<5, 1, 4, 2, false, false>), dim3(blocks), dim3(256), 0, s, a);
+            if (a.split) MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<5, 1, 4, 2, false, true>), dim3(blocks), dim3(256), s, a);
+            else MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<5, 1, 4, 2, false, false>), dim3(blocks), dim3(256), s, a);
             break;
         case 32:
-            if (a.split) hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((edge_chain_bwd_kernel<3, 1, 2, 1, false, false>), dim3(blocks), dim3(256), 0, s, a);
+            if (a.split) MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<3, 1, 2, 1, false, true>), dim3(blocks), dim3(256), s, a);
+            else MPN_LAUNCH_PROFILED((edge_chain_bwd_kernel<3, 1, 2, 1, false, false>), dim3(blocks), dim3(256), s, a);
             break;
         default: set_error("edge_chain_bwd: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }

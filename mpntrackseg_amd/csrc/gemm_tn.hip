@@ -453,10 +453,12 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
         a.xcd_map = a.tiles >= 4 && a.tiles <= 8 ? 1 : 0;
         if (const char* e = getenv("MPNHIP_TN_XCD")) a.xcd_map = e[0] == '1';   // A-B switch for measurements
         const unsigned nblocks = (unsigned)(a.tiles * a.ny8 * a.ngroups);
+        prof_begin(PROF_TN, s, a.flops);
         if (tbn == 64)
-            hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(nblocks), dim3(TNT), 0, s, a);
+            MPN_LAUNCH_PROFILED(gemm_tn_kernel<64>, dim3(nblocks), dim3(TNT), s, a);
         else
-            hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(nblocks), dim3(TNT), 0, s, a);
+            MPN_LAUNCH_PROFILED(gemm_tn_kernel<128>, dim3(nblocks), dim3(TNT), s, a);
+        prof_end(PROF_TN, s);
     } else if (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL")) {
         hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(1, a.nsplit * a.nbatch, a.ngroups), dim3(256), 0, s, a);
     } else {
@@ -520,6 +522,7 @@ static int weight_grad_args(const float* dZ, const float* H, int64_t rows, int n
     g.m_static = rows;
     g.slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
     g.grad_w = grad_w; g.ldw = k_in; g.grad_b = grad_b;
+    a.flops = 2.0 * (double)rows * nbatch * n_out * k_in;
     *out = a;
     return MPNHIP_OK;
 }

@@ -44,18 +44,20 @@ namespace {
 constexpr int PROF_MAX = 2048;
 struct ProfState {
     bool on = false;
-    hipEvent_t ev[2][PROF_MAX][2];
-    bool made[2] = {false, false};
-    int n[2] = {0, 0};
+    hipEvent_t ev[PROF_KINDS][PROF_MAX][2];
+    double work[PROF_KINDS][PROF_MAX];
+    bool made[PROF_KINDS] = {};
+    int n[PROF_KINDS] = {};
     int open_kind = -1;
     bool taken = false;
     hipStream_t stream = nullptr;
     int stride = 1;        // time every stride-th launch of each kind
-    int seen[2] = {0, 0};
+    int seen[PROF_KINDS] = {};
+    double open_work = 0.0;
 } g_prof;
 }  // namespace
 
-void prof_begin(int kind, hipStream_t s) {
+void prof_begin(int kind, hipStream_t s, double work) {
     if (!g_prof.on || g_prof.n[kind] >= PROF_MAX - 64) return;
     if (g_prof.seen[kind]++ % g_prof.stride != 0) return;  // sampled: the attached events are not free (~0.5 us each)
     if (!g_prof.made[kind]) {
@@ -71,6 +73,7 @@ void prof_begin(int kind, hipStream_t s) {
     g_prof.open_kind = kind;
     g_prof.taken = false;
     g_prof.stream = s;
+    g_prof.open_work = work;
 }
 
 bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
@@ -84,7 +87,10 @@ bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
 
 void prof_end(int kind, hipStream_t s) {
     if (!g_prof.on || g_prof.open_kind != kind || g_prof.n[kind] >= PROF_MAX - 64) return;
-    if (g_prof.taken) g_prof.n[kind]++;  // (a bracket nobody launched into is dropped)
+    if (g_prof.taken) {  // (a bracket nobody launched into is dropped)
+        g_prof.work[kind][g_prof.n[kind]] = g_prof.open_work;
+        g_prof.n[kind]++;
+    }
     g_prof.open_kind = -1;
 }
 
@@ -806,9 +812,26 @@ extern "C" int mpnhip_edge_chain_active(const mpnhip_model* model) {
 extern "C" int mpnhip_profile_enable(int on) {
     g_prof.on = on != 0;
     g_prof.stride = on > 1 ? on : 1;
-    g_prof.seen[0] = g_prof.seen[1] = 0;
-    g_prof.n[0] = g_prof.n[1] = 0;
+    for (int k = 0; k < PROF_KINDS; ++k) g_prof.seen[k] = g_prof.n[k] = 0;
     g_prof.open_kind = -1;
+    return MPNHIP_OK;
+}
+
+extern "C" int mpnhip_profile_read_kind(int kind, float* avg_us, int* launches, double* avg_work) {
+    MPN_CHECK_ARG(kind >= 0 && kind < PROF_KINDS, "profile_read_kind: kind %d", kind);
+    MPN_HIP(hipDeviceSynchronize());
+    double tot = 0.0, work = 0.0;
+    for (int i = 0; i < g_prof.n[kind]; ++i) {
+        float ms = 0.f;
+        MPN_HIP(hipEventElapsedTime(&ms, g_prof.ev[kind][i][0], g_prof.ev[kind][i][1]));
+        tot += ms;
+        work += g_prof.work[kind][i];
+    }
+    const int n = g_prof.n[kind];
+    if (avg_us) *avg_us = n ? (float)(tot * 1000.0 / n) : 0.f;
+    if (launches) *launches = n;
+    if (avg_work) *avg_work = n ? work / n : 0.0;
+    g_prof.n[kind] = 0;
     return MPNHIP_OK;
 }
 
