@@ -8,7 +8,18 @@ LIB := $(CSRC)/libmpnhip.so
 # EXTRA=-DMPNHIP_CHAIN_TS builds the fused chain kernels with per-phase cycle stamps (tools/chain_stamps.py)
 CXXFLAGS := -O3 -fPIC -std=c++17 --offload-arch=$(ARCH) -Wall -Wno-unused-function $(EXTRA)
 
-all: $(LIB)
+# torch.ops.mpnhip.* : a C++ shim over the C ABI registering the operators with the PyTorch dispatcher (TORCH_LIBRARY); plain g++
+# against the torch headers -- no kernel in it, nothing hipified
+TORCH_DIR := $(shell python3 -c "import os, torch; print(os.path.dirname(torch.__file__))" 2>/dev/null)
+TORCH_LIB := $(CSRC)/libmpnhip_torch.so
+TORCH_ABI := $(shell python3 -c "import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))" 2>/dev/null)
+
+all: $(LIB) $(TORCH_LIB)
+
+$(TORCH_LIB): $(CSRC)/torch_ops.cpp include/mpnhip.h $(LIB)
+	g++ -O2 -fPIC -std=c++17 -shared -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -D_GLIBCXX_USE_CXX11_ABI=$(TORCH_ABI) \
+	    -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
+	    $< -o $@ -L$(CSRC) -lmpnhip -L$(TORCH_DIR)/lib -lc10 -lc10_hip -ltorch_cpu -ltorch_hip -ltorch -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h include/mpnhip.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
@@ -17,6 +28,6 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(TORCH_LIB)
 
 .PHONY: all clean

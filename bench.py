@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_split", "bf16"],
                     help="operand precision of the Linear products; bf16 (fp32 accumulate) is inference only and is NOT the "
                          "headline configuration (BASELINE.json configs[4])")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, one rank per GPU); gloo lets several ranks "
+                         "share ONE GPU -- a functional run of the N > 1 path where only one GPU is available, not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -104,12 +107,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     from mpntrackseg_amd import capi, synth
     from mpntrackseg_amd.mpn import MOTMPNet
 
@@ -239,7 +247,9 @@ def main():
                                                           "training step (fwd+bwd%s)" % ("+RCCL grad all-reduce" if world > 1 else "")
                                                           if mode == "train" else "inference forward"),
                    "nodes": N, "edges": E, "feat_dim": c["d"], "mp_steps": c["L"], "agg": args.agg, "mode": mode,
-                   "parallelism": "graphs sharded 1 per GPU (dp%d)" % world},
+                   "parallelism": "graphs sharded 1 per GPU (dp%d)" % world if args.backend == "nccl" or world == 1 else
+                                  "dp%d over gloo, %d ranks per GPU (functional run of the N > 1 path, not a scaling number)"
+                                  % (world, (world + torch.cuda.device_count() - 1) // torch.cuda.device_count())},
         "graph_prep_ms": prep_ms, "graph_prep_steady_ms": prep_steady_ms,
         "edge_steps_per_ms": value * c["L"],
     }

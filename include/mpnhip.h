@@ -175,6 +175,21 @@ int mpnhip_backward(const mpnhip_model* model, const void* graph_buf, int n_node
                     const float* grad_e_out, float* grad_x, float* grad_edge_attr, void* fwd_workspace,
                     size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 
+/* Data-parallel training: the same backward with flags.  MPNHIP_BWD_DEFER_SIDE_JOIN: when the
+ * backward runs its weight-gradient groups on the library's side stream (mpnhip_backward_uses_side_stream(model) == 1: four
+ * or more steps), do NOT make `stream` wait for that stream before returning.  On return the gradients of the message-passing
+ * modules and of the classifier are complete in SIDE-stream order, the encoder's gradients and grad_x / grad_edge_attr in
+ * `stream` order: the trainer enqueues the all-reduce of the first bucket on mpnhip_side_stream() -- it then overlaps the
+ * encoder's backward -- and joins with mpnhip_side_stream_join(stream) (or its collective's own wait) before it reads them. */
+#define MPNHIP_BWD_DEFER_SIDE_JOIN 1
+int mpnhip_backward_flags(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges, const float* x,
+                          const float* edge_attr, const float* grad_logits, const float* grad_x_out, const float* grad_e_out,
+                          float* grad_x, float* grad_edge_attr, void* fwd_workspace, size_t fwd_workspace_bytes,
+                          void* bwd_workspace, size_t bwd_workspace_bytes, int flags, void* stream);
+int mpnhip_backward_uses_side_stream(const mpnhip_model* model);
+void* mpnhip_side_stream(void);              /* hipStream_t of the current device's side stream (created on first use) */
+int mpnhip_side_stream_join(void* stream);   /* `stream` waits for everything enqueued on the side stream so far */
+
 /* ---------------------------------------------------------------------------------------------
  * Operator level.
  * ------------------------------------------------------------------------------------------- */

@@ -30,8 +30,9 @@ def native_forward_saved(model, g, x, ea, logits):
     return ws
 
 
-def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, need_gea=False):
-    """mpnhip_backward; ``grads``: id(param) -> buffer the parameter gradient is ACCUMULATED into."""
+def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, need_gea=False, defer_side_join=False):
+    """mpnhip_backward; ``grads``: id(param) -> buffer the parameter gradient is ACCUMULATED into.
+    ``defer_side_join``: MPNHIP_BWD_DEFER_SIDE_JOIN (include/mpnhip.h) -- the caller joins the side stream itself."""
     lib = capi.load()
     keep = []
     m = model.c_model(keep, grads=grads)
@@ -41,9 +42,9 @@ def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, 
     gl = capi.f32c(grad_logits)
     with torch.cuda.device(x.device):
         bws = capi.workspace(lib.mpnhip_backward_workspace_bytes(m, N, E), x.device, "bwd")
-        capi.check(lib.mpnhip_backward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(gl), None, None,
-                                       capi.ptr(gx), capi.ptr(gea), capi.ptr(fwd_ws), fwd_ws.numel(), capi.ptr(bws),
-                                       bws.numel(), capi.stream_ptr()), "mpnhip_backward")
+        capi.check(lib.mpnhip_backward_flags(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(gl), None, None,
+                                             capi.ptr(gx), capi.ptr(gea), capi.ptr(fwd_ws), fwd_ws.numel(), capi.ptr(bws),
+                                             bws.numel(), 1 if defer_side_join else 0, capi.stream_ptr()), "mpnhip_backward")
     return gx, gea
 
 
@@ -52,9 +53,17 @@ class _HotPath(torch.autograd.Function):
     def forward(ctx, model, g, x, edge_attr, *params):
         xd = capi.f32c(x.detach())
         ead = capi.f32c(edge_attr.detach())
-        L = max(int(model.num_enc_steps), 1)
-        logits = torch.empty((L, ead.shape[0]), dtype=torch.float32, device=xd.device)
-        ctx.fwd_ws = native_forward_saved(model, g, xd, ead, logits)
+        from . import torch_ops
+        ctx.via_ops = torch_ops.available()
+        if ctx.via_ops:
+            # through the dispatcher (csrc/torch_ops.cpp): the same C-ABI calls, outputs allocated by the op
+            ctx.spec, _ = torch_ops.model_spec(model)
+            with torch.cuda.device(xd.device):
+                logits, ctx.fwd_ws = torch_ops.call("forward", g.buf, xd, ead, [p.detach() for p in params], ctx.spec, 1, None, False)
+        else:
+            L = max(int(model.num_enc_steps), 1)
+            logits = torch.empty((L, ead.shape[0]), dtype=torch.float32, device=xd.device)
+            ctx.fwd_ws = native_forward_saved(model, g, xd, ead, logits)
         ctx.model, ctx.g = model, g
         # through save_for_backward: autograd's version check then catches an in-place change of x / edge_attr / a weight
         # between forward and backward (the saved activations would no longer belong to them)
@@ -70,6 +79,16 @@ class _HotPath(torch.autograd.Function):
                                    "run the forward again")
         saved = ctx.saved_tensors   # (raises if one of them was modified in place since the forward)
         x, ea, params = saved[0], saved[1], ctx.params
+        if ctx.via_ops:
+            from . import torch_ops
+            with torch.cuda.device(x.device):
+                out = torch_ops.call("backward", ctx.g.buf, x, ea, capi.f32c(grad_logits), ctx.fwd_ws, [p.detach() for p in params], ctx.spec,
+                                     bool(ctx.needs_input_grad[2]), bool(ctx.needs_input_grad[3]))
+            ctx.fwd_ws = None
+            n = len(params)
+            gx = out[n] if ctx.needs_input_grad[2] else None
+            gea = out[n + 1] if ctx.needs_input_grad[3] else None
+            return (None, None, gx, gea) + tuple(out[i] if p.requires_grad else None for i, p in enumerate(params))
         grads = {id(p): torch.zeros_like(p) for p in params}
         gx, gea = native_backward(ctx.model, ctx.g, x, ea, grad_logits, ctx.fwd_ws, grads,
                                   need_gx=ctx.needs_input_grad[2], need_gea=ctx.needs_input_grad[3])

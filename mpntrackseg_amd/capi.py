@@ -65,6 +65,10 @@ SIGNATURES = {
     "mpnhip_forward": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "mpnhip_backward_workspace_bytes": (_Z, [C.POINTER(Model), _I, _L]),
     "mpnhip_backward": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "mpnhip_backward_flags": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "mpnhip_backward_uses_side_stream": (_I, [C.POINTER(Model)]),
+    "mpnhip_side_stream": (_P, []),
+    "mpnhip_side_stream_join": (_I, [_P]),
     "mpnhip_meta_layer_workspace_bytes": (_Z, [C.POINTER(Model), _I, _L]),
     "mpnhip_meta_layer_forward": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _Z, _P]),
     "mpnhip_segment_reduce_workspace_bytes": (_Z, [_L, _I]),

@@ -443,10 +443,38 @@ extern "C" size_t mpnhip_backward_workspace_bytes(const mpnhip_model* model, int
     return plan_backward(*model, d, n_nodes, n_edges, nullptr, nullptr);
 }
 
+static bool backward_forks(const mpnhip_model& m) { return m.num_enc_steps >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM"); }
+
+extern "C" int mpnhip_backward_uses_side_stream(const mpnhip_model* model) { return model && backward_forks(*model) ? 1 : 0; }
+
+extern "C" void* mpnhip_side_stream(void) {
+    SideStream* side = nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    return side_stream_ready(&side) == MPNHIP_OK ? static_cast<void*>(side->stream) : nullptr;
+}
+
+extern "C" int mpnhip_side_stream_join(void* stream_) {
+    SideStream* side = nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    MPN_TRY(side_stream_ready(&side));
+    MPN_HIP(hipEventRecord(side->done, side->stream));
+    MPN_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream_), side->done, 0));
+    return MPNHIP_OK;
+}
+
 extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
                                const float* x, const float* edge_attr, const float* grad_logits, const float* grad_x_out,
                                const float* grad_e_out, float* grad_x, float* grad_edge_attr, void* fwd_workspace,
                                size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream_) {
+    return mpnhip_backward_flags(model, graph_buf, n_nodes, n_edges, x, edge_attr, grad_logits, grad_x_out, grad_e_out, grad_x,
+                                 grad_edge_attr, fwd_workspace, fwd_workspace_bytes, bwd_workspace, bwd_workspace_bytes, 0, stream_);
+}
+
+extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges,
+                                     const float* x, const float* edge_attr, const float* grad_logits, const float* grad_x_out,
+                                     const float* grad_e_out, float* grad_x, float* grad_edge_attr, void* fwd_workspace,
+                                     size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, int flags,
+                                     void* stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     MPN_CHECK_ARG(model && graph_buf, "backward: null model / graph");
     const mpnhip_model& m = *model;
@@ -632,7 +660,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
     // CUs idle for the last third of their run at cfg-B); only the last group runs after the loop.  Groups are issued
     // to ONE side stream in order, so they can share its slab buffer and their "+=" into the gradients stay ordered.
     SideStream* side = nullptr;
-    const bool want_fork = L >= 4 && !getenv("MPNHIP_NO_SIDE_STREAM") && side_stream_ready(&side) == MPNHIP_OK;
+    const bool want_fork = backward_forks(m) && side_stream_ready(&side) == MPNHIP_OK;
     std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
     if (want_fork) side_lock.lock();
     SideJoin join;
@@ -838,7 +866,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
         MPN_TRY(weight_grad(p, p.slab, 1, {p.dPsum, pw, 0}, nullptr, {x0, dn, 0}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr,
                             N, 1, s));
     }
-    auto unpack_node_grads = [&]() -> int {
+    auto unpack_node_grads = [&](hipStream_t us) -> int {
         // the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] back into the layers' grads (their biases were handled above)
         struct { float* dst; int64_t ld; int c0; int r0; int rows; } parts[4] = {
             {m.edge.grad_weight[0], m.edge.in_dim, 0, 0, he},
@@ -847,7 +875,7 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
         for (auto& q : parts) {
             int64_t tot = (int64_t)q.rows * kx;
-            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.gWnode + (size_t)q.r0 * kx,
+            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, us, p.gWnode + (size_t)q.r0 * kx,
                                kx, q.dst, q.ld, q.c0, q.rows, kx);
             MPN_LAUNCH_CHECK();
         }
@@ -861,9 +889,12 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             MPN_HIP(hipEventRecord(side->ready, s));
             MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
             MPN_TRY(mp_weight_grads(0, last_n, side->stream, p.slab_side));
+            // (the unpacking follows on the side stream as well: with it every gradient of the message-passing modules and of
+            // the classifier is final IN SIDE-STREAM ORDER, while the caller's stream still runs the encoder's backward)
+            MPN_TRY(unpack_node_grads(side->stream));
         } else {
             MPN_TRY(mp_weight_grads(0, last_n, s, p.slab));
-            MPN_TRY(unpack_node_grads());
+            MPN_TRY(unpack_node_grads(s));
         }
     } else {
         // mpn.py:387-389: only the classifier sits between the encoder output and the logits
@@ -970,11 +1001,17 @@ extern "C" int mpnhip_backward(const mpnhip_model* model, const void* graph_buf,
             }
         }
     }
-    if (L > 0 && forked) {  // join: every "+=" of the side stream's groups is in; then the unpacking, on the caller's stream
-        MPN_HIP(hipEventRecord(side->done, side->stream));
-        MPN_HIP(hipStreamWaitEvent(s, side->done, 0));
-        join.joined = true;
-        MPN_TRY(unpack_node_grads());
+    if (L > 0 && forked) {
+        // join: every "+=" of the side stream's groups (and the unpacking) is in.  MPNHIP_BWD_DEFER_SIDE_JOIN leaves it to the
+        // caller (mpnhip_side_stream_join): a data-parallel trainer first puts the all-reduce of the message-passing modules'
+        // gradients on the side stream, where it overlaps the encoder's backward still running on the caller's stream.
+        if (flags & MPNHIP_BWD_DEFER_SIDE_JOIN) {
+            join.joined = true;
+        } else {
+            MPN_HIP(hipEventRecord(side->done, side->stream));
+            MPN_HIP(hipStreamWaitEvent(s, side->done, 0));
+            join.joined = true;
+        }
     }
     return MPNHIP_OK;
 }

@@ -426,15 +426,37 @@ class MOTMPNet(nn.Module):
         """Forget every packed weight image (the next inference call packs again)."""
         capi._packed_state.clear()
 
+    def _hp_params(self):
+        """hot_path_parameters(), built once (the module structure does not change after __init__)."""
+        c = getattr(self, '_hp_params_cache', None)
+        if c is None:
+            c = self._hp_params_cache = self.hot_path_parameters()
+        return c
+
+    def _packed_key(self, precision_code):
+        """What the packed weight images depend on: precision, native-update epoch, every weight's address and version."""
+        return (precision_code, capi._weights_epoch[0]) + tuple((p_.data_ptr(), p_._version) for p_ in self._hp_params())
+
+    def _uid(self):
+        # (a token that is never reused: id() of a collected model can come back, together with recycled parameter
+        # addresses and equal version counts, for a model with other weights)
+        if getattr(self, '_mpnhip_uid', None) is None:
+            capi._model_uid[0] += 1
+            self._mpnhip_uid = capi._model_uid[0]
+        return self._mpnhip_uid
+
     def hot_path(self, x, edge_index, edge_attr, holder=None, return_state=False, validate=True):
         """Encoder + L message-passing steps + per-step classifier: logits [max(L,1), E].  ``validate``: raise IndexError
         like the reference when edge_index leaves [0, N) (read once per prepared graph, after the launch; callers that build
         the indices themselves -- the sliding-window driver -- skip it)."""
         capi.require_device(x, edge_index, edge_attr)
         if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
-                                        any(p.requires_grad for p in self.hot_path_parameters())):
+                                        any(p.requires_grad for p in self._hp_params())):
             from .autograd import mpn_hot_path_autograd
             return mpn_hot_path_autograd(self, x, edge_index, edge_attr, holder, validate=validate)
+        from . import torch_ops
+        if torch_ops.available() and not return_state:
+            return self._hot_path_ops(x, edge_index, edge_attr, holder, validate, torch_ops)
         lib = capi.load()
         keep = []
         m = self.c_model(keep)
@@ -452,24 +474,51 @@ class MOTMPNet(nn.Module):
             # inside ``frozen_weights()`` the packed weight images at the head of the workspace survive between calls: skip
             # re-packing them while the buffer, the model and every weight (address, torch version, native-update epoch) are
             # unchanged
-            key = (m.precision, capi._weights_epoch[0]) + tuple((p_.data_ptr(), p_._version) for p_ in self.hot_path_parameters())
-            # (a token that is never reused: id() of a collected model can come back, together with recycled parameter
-            # addresses and equal version counts, for a model with other weights)
-            if getattr(self, '_mpnhip_uid', None) is None:
-                capi._model_uid[0] += 1
-                self._mpnhip_uid = capi._model_uid[0]
-            state = (self._mpnhip_uid, key)
-            m.weights_prepacked = 1 if self.keep_packed_weights and capi._packed_state.get(ws.data_ptr()) == state else 0
+            state = (self._uid(), self._packed_key(m.precision)) if self.keep_packed_weights else None
+            m.weights_prepacked = 1 if state is not None and capi._packed_state.get(ws.data_ptr()) == state else 0
             capi._packed_state.pop(ws.data_ptr(), None)
             capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits),
                                           capi.ptr(x_out), capi.ptr(e_out), capi.ptr(ws), ws.numel(), 0,
                                           capi.stream_ptr()), "mpnhip_forward")
-            if self.keep_packed_weights:
+            if state is not None:
                 capi._packed_state[ws.data_ptr()] = state
         if validate:
             g.raise_if_invalid()
         if return_state:
             return logits, x_out, e_out
+        return logits
+
+    def _hot_path_ops(self, x, edge_index, edge_attr, holder, validate, torch_ops):
+        """The inference hot path through the dispatcher: ``torch.ops.mpnhip.forward`` (csrc/torch_ops.cpp) -- the same C-ABI call;
+        the op owns the output allocation and the workspace (kept here per stream so that packed weight images can survive
+        between calls inside ``frozen_weights()``), and the model crosses as the cached (spec, weights) pair."""
+        c = getattr(self, '_ops_cache', None)
+        ptrs = tuple(p_.data_ptr() for p_ in self._hp_params())
+        prec = getattr(self, 'gemm_precision', 'fp32')
+        if c is None or c[0] != ptrs or c[1] != prec or c[2] != int(self.num_enc_steps):
+            spec, weights = torch_ops.model_spec(self)
+            c = self._ops_cache = (ptrs, prec, int(self.num_enc_steps), spec, weights, spec[8], spec[9 + spec[7] + 1])
+        spec, weights = c[3], c[4]
+        x = capi.f32c(x)
+        ea = capi.f32c(edge_attr)
+        g = _prepared(edge_index, x.shape[0], holder, full=False)
+        if g.E != ea.shape[0] or x.dim() != 2 or ea.dim() != 2 or x.shape[1] != c[5] or ea.shape[1] != c[6] or x.device != g.device \
+                or ea.device != g.device:
+            check_hot_path_inputs(self.c_model([]), g, x, ea)   # (raises with the detailed message)
+        with torch.cuda.device(x.device):
+            skey = int(torch.cuda.current_stream().cuda_stream)
+            wss = self.__dict__.setdefault('_ops_ws', {})
+            ws, ws_state = wss.get(skey, (None, None))
+            state = (self._uid(), self._packed_key(spec[6])) if self.keep_packed_weights else None
+            prepacked = state is not None and ws is not None and ws_state == state and capi._packed_state.get(ws.data_ptr()) == state
+            logits, ws_out = torch_ops.call("forward", g.buf, x, ea, weights, spec, 0, ws, prepacked)
+            if state is not None:
+                capi._packed_state[ws_out.data_ptr()] = state
+            else:
+                capi._packed_state.pop(ws_out.data_ptr(), None)
+            wss[skey] = (ws_out, state)
+        if validate:
+            g.raise_if_invalid()
         return logits
 
     def forward(self, data):

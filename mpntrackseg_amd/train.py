@@ -1,10 +1,13 @@
-"""Data-parallel training step: one graph per GPU, flat gradient bucket, one RCCL all-reduce.
+"""Data-parallel training step: one graph per GPU, flat gradient buckets, RCCL all-reduce overlapped with the backward.
 
 The reference trains on one GPU with ``accumulate_grad_batches: 8`` (configs/tracking_cfg.yaml:4,
 scripts/train.py:76); W GPUs x 1 graph with gradient averaging is the same optimisation step executed
 in space instead of time.  The graphs share nothing but the weights, so the
-data path has no collective; the only exchange is ONE all-reduce(sum) of the flat fp32 gradient bucket
-per optimizer step (1.2 MB at the reference dims: latency-bound, hence a single bucket)."""
+data path has no collective; the only exchange is the all-reduce(sum) / W of the flat fp32 gradient buffer
+per optimizer step (1.2 MB at the reference dims, 19 MB at d = 128), issued as two buckets: the gradients of the
+message-passing modules and the classifier are final when the backward's last weight-gradient group is (on the
+library's side stream) -- their all-reduce starts there and runs under the encoder's backward; the encoder's bucket
+follows on the caller's stream."""
 import torch
 
 from . import capi
@@ -60,6 +63,7 @@ class FlatBucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views = {}
+        self.offsets = dict((id(p), off) for p, off in zip(self.params, offs))
         for p, off in zip(self.params, offs):
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views[id(p)] = v
@@ -105,8 +109,35 @@ class TrainStep:
         self.world_size = world_size
         self.pg = process_group
         self.bucket = FlatBucket(model.hot_path_parameters())
+        # hot_path_parameters(): encoder.node_model, encoder.edge_model, then the message-passing modules and the classifier:
+        # flat[:enc_elems] is the encoder's bucket (final last, on the caller's stream), flat[enc_elems:] the other one
+        enc = set(id(p) for p in list(model.encoder.node_model.parameters()) + list(model.encoder.edge_model.parameters()))
+        first_mp = [p for p in self.bucket.params if id(p) not in enc][0]
+        self.enc_elems = self.bucket.offsets[id(first_mp)]
+        self._side = None
         self.opt = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay)
         self.first_class_step = max(int(model.num_enc_steps) - int(model.num_class_steps), 0)
+
+    def allreduce_buckets(self, side_pending):
+        """all-reduce(sum) / W of the flat gradient buffer.  ``side_pending``: the backward left its side stream un-joined
+        (MPNHIP_BWD_DEFER_SIDE_JOIN): the message-passing bucket's collective is ordered behind THAT stream, so it overlaps
+        the encoder's backward still queued on the caller's stream; the encoder's bucket follows in the caller's order."""
+        import torch.distributed as dist
+        flat, k = self.bucket.flat, self.enc_elems
+        with torch.cuda.device(flat.device):
+            if side_pending:
+                if self._side is None:
+                    self._side = torch.cuda.ExternalStream(capi.load().mpnhip_side_stream(), device=flat.device)
+                with torch.cuda.stream(self._side):
+                    w_mp = dist.all_reduce(flat[k:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                w_enc = dist.all_reduce(flat[:k], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) if k else None
+                w_mp.wait()
+                if w_enc is not None:
+                    w_enc.wait()
+                capi.check(capi.load().mpnhip_side_stream_join(capi.stream_ptr()), "mpnhip_side_stream_join")
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            flat.mul_(1.0 / self.world_size)
 
     def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True):
         from .mpn import _prepared, check_hot_path_inputs
@@ -127,8 +158,11 @@ class TrainStep:
         from .loss import tracking_loss_and_grad
         self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0)
         self.bucket.zero_()
-        native_backward(model, g, x, ea, glog, ws, self.bucket.views)
-        allreduce_mean_(self.bucket.flat, self.world_size, self.pg)
+        lib = capi.load()
+        defer = self.world_size > 1 and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))
+        native_backward(model, g, x, ea, glog, ws, self.bucket.views, defer_side_join=defer)
+        if self.world_size > 1:
+            self.allreduce_buckets(defer)
         if optimizer_step:
             self.opt.step()
         g.raise_if_invalid()   # IndexError like the reference's x[row] gather for an edge_index outside [0, N): once per graph

@@ -1,9 +1,10 @@
 """CPU ORACLE for the two callers' steps right after the hot path.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: ``pl_module/pl_module.py`` and ``utils/evaluation.py`` cannot be imported in the authoring
-container (pytorch_lightning / motmetrics / sacred are not installed), so these restatements are checked by
-reading only; each function cites the reference lines it follows (paths relative to
-/root/reference/src/mot_neural_solver/).
+PIN: ``tests/golden/g9_loss_metrics.npz`` holds the outputs of the reference's own ``MOTNeuralSolver._compute_loss`` (value and
+autograd gradient), ``compute_perform_metrics`` and ``compute_constr_satisfaction_rate``, produced in the authoring container by
+``tools/make_golden.py gen_g9`` (the modules are imported with empty placeholders for the packages their OTHER functions
+need: pytorch_lightning, motmetrics, the evaluation kits); ``tests/test_oracle_golden.py`` checks these restatements against
+it.  Each function cites the reference lines it follows (paths relative to /root/reference/src/mot_neural_solver/).
 """
 import torch
 import torch.nn.functional as F

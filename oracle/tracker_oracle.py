@@ -8,10 +8,12 @@ Follows, line by line where it matters:
   construct_graph             data/mot_graph.py:195-218 (_get_edge_ixs) and :283-317 (construct_graph_object)
   evaluate_graph_in_batches   tracker/mpn_tracker.py:96-141 (_predict_edges_and_masks) and :143-198
 
-PIN: the three utils/graph.py functions are pinned by tests/golden/g7_graph_utils.npz, generated by importing the
-reference in the authoring container (tools/make_golden.py gen_g7).  construct_graph / evaluate_graph_in_batches are
-**parity unpinned**: mot_graph.py / mpn_tracker.py need torch_geometric, pandas frames built by the dataset classes,
-lapsolver and pytorch_lightning, none of which is installed here, so they are restated from the source only."""
+PIN: the three utils/graph.py functions are pinned by tests/golden/g7_graph_utils.npz, and evaluate_graph_in_batches by
+tests/golden/g10_windows.npz -- the reference's own MPNTracker._evaluate_graph_in_batches / _predict_edges_and_masks run in
+the authoring container on a synthetic sequence with the reference model (tools/make_golden.py gen_g10: placeholder modules
+for the packages mpn_tracker.py imports for its OTHER methods, the hard-coded 'cuda' device redirected to the CPU).
+construct_graph is the composition of the pinned functions with the tensor concatenations of mot_graph.py:311-315 (the
+MOTGraph class itself needs the dataset classes and is not importable here)."""
 import numpy as np
 import torch
 import torch.nn.functional as F

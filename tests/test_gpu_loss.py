@@ -1,5 +1,5 @@
 """Native tracking loss / step metrics against the CPU restatement of
-pl_module.py:88-107 and utils/evaluation.py:340-437 (oracle/loss_oracle.py; parity unpinned -- see its header)."""
+pl_module.py:88-107 and utils/evaluation.py:340-437 (oracle/loss_oracle.py) and the fixtures the REFERENCE functions themselves produced (tests/golden/g9_loss_metrics.npz)."""
 import numpy as np
 import pytest
 import torch
@@ -81,3 +81,40 @@ def test_flat_adam_matches_torch_adam():
             fopt.step()
             for r, m in zip(ref, mine):
                 assert float((r.detach() - m.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_tracking_loss_against_reference_compute_loss(golden, tag):
+    """csrc/loss.hip against MOTNeuralSolver._compute_loss of the reference itself (tests/golden/g9_loss_metrics.npz: loss value
+    and its autograd gradient w.r.t. every classified step; incl. the no-positive-label and the single-edge cases)."""
+    z = golden("g9_loss_metrics.npz")
+    logits = torch.from_numpy(z[f"{tag}:logits"]).to(dev())
+    labels = torch.from_numpy(z[f"{tag}:labels"]).to(dev())
+    w = float(z[f"{tag}:weight"])
+    loss, grad = tracking_loss_and_grad(logits, labels, 0, w)
+    ref = float(z[f"{tag}:loss"])
+    assert abs(float(loss[0]) - ref) <= 1e-5 * max(1.0, abs(ref))
+    assert float(np.abs(grad.cpu().numpy() - z[f"{tag}:grad"]).max()) <= 1e-6 * max(1.0, float(np.abs(z[f"{tag}:grad"]).max()))
+    lg = logits.clone().requires_grad_(True)
+    k, E = lg.shape
+    out = tracking_loss([lg[s].view(E, 1) for s in range(k)], labels, weight=w)
+    out.backward()
+    assert abs(float(out) - ref) <= 1e-5 * max(1.0, abs(ref))
+    assert float(np.abs(lg.grad.cpu().numpy() - z[f"{tag}:grad"]).max()) <= 1e-6 * max(1.0, float(np.abs(z[f"{tag}:grad"]).max()))
+
+
+@pytest.mark.parametrize("tag", ["m1", "m2", "m3"])
+def test_step_metrics_against_reference(golden, tag):
+    """mpnhip_step_metrics against the reference's compute_perform_metrics / compute_constr_satisfaction_rate."""
+    z = golden("g9_loss_metrics.npz")
+
+    class G:
+        pass
+    go = G()
+    go.edge_index = torch.from_numpy(z["edge_index"]).to(dev())
+    go.edge_labels = torch.from_numpy(z[f"{tag}:labels"]).to(dev())
+    go.num_nodes = 120
+    got = compute_perform_metrics({"classified_edges": [torch.from_numpy(z[f"{tag}:logit"]).to(dev())]}, go)
+    want = z[f"{tag}:metrics"]
+    for i, k in enumerate(("accuracy", "recall", "precision", "constr_sr")):
+        assert abs(got[k] - float(want[i])) < 1e-6, k

@@ -204,3 +204,23 @@ def test_graph_build_more_shapes():
     assert bool(G.get_knn_mask(torch.tensor([0.5]).to(d0), one.to(d0), 2, 1, reciprocal_k_nns=True, symmetric_edges=False)[0])
     big = G.get_knn_mask(torch.rand(ei.shape[1]).to(d0), ei.to(d0), 200, 10 ** 6, reciprocal_k_nns=True, symmetric_edges=False)
     assert bool(big.all())
+
+
+@pytest.mark.parametrize("windows_per_launch", [1, 3])
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_sliding_window_against_reference_tracker(golden, tag, windows_per_launch):
+    """tracker.evaluate_graph_in_batches (HIP hot path, native window selection / kNN / accumulation) against the reference's own
+    MPNTracker._evaluate_graph_in_batches run with the reference model (tests/golden/g10_windows.npz)."""
+    z = golden("g10_windows.npz")
+    inactive, recip, fpg, top_k = [int(v) for v in z[f"{tag}:cfg"]]
+    params = synth.model_params(32, 4, "sum", num_class_steps=2, node_in_dim=64)
+    W = synth.make_weights(params, seed=7, gain=0.6)
+    model = MOTMPNet(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    model = model.to(dev()).eval()
+    t = {k: torch.from_numpy(z[f"{tag}:{k}"]).to(dev()) for k in ("x", "edge_index", "edge_attr", "reid_emb_dists")}
+    got = tracker.evaluate_graph_in_batches(model, t["x"], t["edge_index"], t["edge_attr"], t["reid_emb_dists"], z[f"{tag}:frame"], fpg, top_k,
+                                            reciprocal_k_nns=bool(recip), set_pruned_edges_to_inactive=bool(inactive),
+                                            windows_per_launch=windows_per_launch)
+    ref = z[f"{tag}:final_edge_preds"]
+    assert float(np.abs(got.cpu().numpy() - ref).max()) < 2e-5

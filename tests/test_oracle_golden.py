@@ -230,3 +230,50 @@ def test_g11_cfgB_sum_o1_forward_and_reference_autograd(golden):
     assert rel_err(xL[:64], z["x_final_rows"]) < 2e-6
     bad, log = check_grads_against_fixture(z, pg, gx, gea, tol=1e-5)
     assert not bad, "\n".join(bad)
+
+
+# ------------------------------------------------------------------------------------ the callers' steps
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_g9_tracking_loss_oracle_against_reference_compute_loss(golden, tag):
+    """oracle/loss_oracle.py against MOTNeuralSolver._compute_loss of the reference (value and autograd gradient)."""
+    from oracle import loss_oracle as LO
+    z = golden("g9_loss_metrics.npz")
+    logits = torch.from_numpy(z[f"{tag}:logits"]).clone().requires_grad_(True)
+    labels = torch.from_numpy(z[f"{tag}:labels"])
+    k, E = logits.shape
+    loss = LO.tracking_loss([logits[s].view(E, 1) for s in range(k)], labels, weight=float(z[f"{tag}:weight"]))
+    loss.backward()
+    assert abs(float(loss) - float(z[f"{tag}:loss"])) <= 1e-6 * max(1.0, abs(float(z[f"{tag}:loss"])))
+    assert np.abs(logits.grad.numpy() - z[f"{tag}:grad"]).max() <= 1e-7 * max(1.0, np.abs(z[f"{tag}:grad"]).max())
+
+
+@pytest.mark.parametrize("tag", ["m1", "m2", "m3"])
+def test_g9_step_metrics_oracle_against_reference(golden, tag):
+    from oracle import loss_oracle as LO
+    z = golden("g9_loss_metrics.npz")
+    ei = torch.from_numpy(z["edge_index"])
+    m = LO.compute_perform_metrics([torch.from_numpy(z[f"{tag}:logit"])], ei, torch.from_numpy(z[f"{tag}:labels"]), 120)
+    got = np.array([m["accuracy"], m["recall"], m["precision"], m["constr_sr"]])
+    assert np.abs(got - z[f"{tag}:metrics"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_g10_sliding_window_oracle_against_reference_tracker(golden, tag):
+    """oracle/tracker_oracle.evaluate_graph_in_batches (driving oracle/mpn_oracle.forward) against
+    MPNTracker._evaluate_graph_in_batches of the reference driving the reference model."""
+    from oracle import tracker_oracle as TO
+    z = golden("g10_windows.npz")
+    inactive, recip, fpg, top_k = [int(v) for v in z[f"{tag}:cfg"]]
+    params = synth.model_params(32, 4, "sum", num_class_steps=2, node_in_dim=64)
+    W = O.to_tensors(synth.make_weights(params, seed=7, gain=0.6))
+
+    def fwd(x, ei, ea):
+        with torch.no_grad():
+            return O.forward(params, W, x, ei, ea)[-1].view(-1)
+    got = TO.evaluate_graph_in_batches(fwd, torch.from_numpy(z[f"{tag}:x"]), torch.from_numpy(z[f"{tag}:edge_index"]),
+                                       torch.from_numpy(z[f"{tag}:edge_attr"]), torch.from_numpy(z[f"{tag}:reid_emb_dists"]),
+                                       z[f"{tag}:frame"], fpg, top_k, reciprocal_k_nns=bool(recip),
+                                       set_pruned_edges_to_inactive=bool(inactive))
+    ref = z[f"{tag}:final_edge_preds"]
+    assert got.shape == ref.shape and float(np.abs(ref).max()) > 0.05
+    assert np.abs(got.numpy() - ref).max() < 2e-6

@@ -22,6 +22,8 @@ Fixtures:
   g11_cfgB_sum_o1.npz          cfg-B, sum aggregation, 12 steps, weights scaled to O(1) logits: sampled logits, checksums and the
                                reference's autograd gradients (the headline training workload).
   g12_dense_knn_{agg}.npz      dense reciprocal-kNN graph (E / N = 64, d = 32, 12 steps): sampled logits + reference autograd.
+  g9_loss_metrics.npz          MOTNeuralSolver._compute_loss (+ autograd) and compute_perform_metrics / compute_constr_satisfaction_rate.
+  g10_windows.npz              MPNTracker._evaluate_graph_in_batches on a synthetic sequence with the reference model.
   g7_graph_utils.npz           the reference's utils/graph.py on a synthetic detection table (synth.make_detections):
                                get_time_valid_conn_ixs ('max' and 3 frames), compute_edge_feats_dict, F.pairwise_distance,
                                get_knn_mask (reciprocal on/off; one direction per pair and both directions).
@@ -84,7 +86,7 @@ def _scatter_max(src, index, dim=-1, out=None, dim_size=None):
 
 
 def _scatter_min(src, index, dim=-1, out=None, dim_size=None):
-    raise NotImplementedError
+    raise NotImplementedError   # (imported by data/mot_graph.py at module level; no function under test calls it)
 
 
 def _scatter_softmax(src, index, dim=-1, eps=1e-12):
@@ -496,9 +498,200 @@ def gen_g8():
     print("g8_embedding_files.npz", {k: v.shape for k, v in out.items()})
 
 
+def _placeholder_modules(specs):
+    """Empty stand-ins for third-party / unrelated packages a reference module imports at MODULE level for its OTHER functions
+    (nothing of them is touched by the function under test); attributes are set to None unless a value is given."""
+    for name, attrs in specs:
+        if name in sys.modules:
+            m = sys.modules[name]
+        else:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for a in attrs:
+            if isinstance(a, tuple):
+                setattr(m, a[0], a[1])
+            elif not hasattr(m, a):
+                setattr(m, a, None)
+        if "." in name:   # make `import a.b` find b as an attribute of a
+            parent, child = name.rsplit(".", 1)
+            if parent in sys.modules:
+                setattr(sys.modules[parent], child, m)
+
+
+class _GeoData:
+    """Stand-in for torch_geometric.data.Data (third party, not installed): an attribute container with the two derived
+    properties the reference code reads -- num_nodes (settable, else rows of x) and num_edges (columns of edge_index)."""
+    def __init__(self, **kwargs):
+        self._num_nodes = None
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def num_nodes(self):
+        return self._num_nodes if self._num_nodes is not None else self.x.shape[0]
+
+    @num_nodes.setter
+    def num_nodes(self, v):
+        self._num_nodes = v
+
+    @property
+    def num_edges(self):
+        return self.edge_index.shape[1]
+
+
+def _import_tracking_stack():
+    """utils/evaluation.py, pl_module/pl_module.py and tracker/mpn_tracker.py of the reference.  Their module-level imports pull in
+    pytorch_lightning, torch_geometric, motmetrics, the MOTS / KITTI evaluation kits, pulp, pycocotools, torchvision, skimage,
+    matplotlib, tracktor -- none installed here and none used by the functions under test (_compute_loss,
+    compute_perform_metrics, compute_constr_satisfaction_rate, _predict_edges_and_masks, _evaluate_graph_in_batches)."""
+    install_shim()
+    sys.modules["torch_scatter"].scatter_min = _scatter_min
+    if "/root/reference/src" not in sys.path:
+        sys.path.insert(0, "/root/reference/src")
+
+    class _Base:
+        def __init__(self, *a, **k):
+            pass
+    _placeholder_modules([
+        ("pytorch_lightning", [("LightningModule", _Base), ("Callback", _Base)]),
+        ("torch_geometric", []), ("torch_geometric.data", [("Data", _GeoData), ("DataLoader", None)]),
+        # (evaluation.py builds its MOT-metric report formatters at import time: mm.metrics.create().formatters, mm.io.*_names)
+        ("motmetrics", [("metrics", types.SimpleNamespace(create=lambda: types.SimpleNamespace(formatters={"mota": None}))),
+                        ("io", types.SimpleNamespace(motchallenge_metric_names={"mota": "MOTA"}))]),
+        ("MOTChallengeEvalKit", []), ("MOTChallengeEvalKit.MOTS", []),
+        ("MOTChallengeEvalKit.MOTS.evalMOTS", ["MOTS_evaluator"]),
+        ("TrackEval", []), ("TrackEval.scripts", []), ("TrackEval.scripts.run_kitti_mots", ["eval_kitti_mots"]),
+        ("pulp", []), ("pycocotools", []), ("pycocotools.mask", []),
+        ("skimage", []), ("skimage.io", ["imread"]),
+        ("matplotlib", []), ("matplotlib.pyplot", []),
+        ("torchvision", []), ("torchvision.ops", ["roi_align"]), ("torchvision.transforms", ["Compose", "Resize", "ToTensor", "Normalize"]),
+        ("torchvision.models", []), ("torchvision.models.detection", []), ("torchvision.models.detection.roi_heads", ["paste_masks_in_image"]),
+        ("torchvision.models.utils", ["load_state_dict_from_url"]),
+        ("tracktor_masked", []), ("tracktor_masked.maskrcnn_fpn", ["MaskRCNN_FPN"]),
+        # reference modules that are unrelated to the functions under test and need yet more packages
+        ("mot_neural_solver.data.augmentation", ["MOTGraphAugmentor"]),
+        ("mot_neural_solver.data.mot_graph_dataset", ["MOTGraphDataset"]),
+        ("mot_neural_solver.models.resnet", ["resnet50_fc256", "load_pretrained_weights"]),
+    ])
+    import mot_neural_solver.data  # noqa: F401  (package first, so that the placeholders above hang off it)
+    from mot_neural_solver.utils import evaluation as EV
+    from mot_neural_solver.tracker import mpn_tracker as TR
+    from mot_neural_solver.pl_module import pl_module as PL
+    return EV, TR, PL
+
+
+def gen_g9():
+    """MOTNeuralSolver._compute_loss (pl_module/pl_module.py:88-120; tracking term: no matched masks) with its autograd gradient
+    w.r.t. every classified step's logits, and compute_perform_metrics / compute_constr_satisfaction_rate
+    (utils/evaluation.py:340-437), on seeded inputs incl. the no-positive-label and single-edge cases."""
+    EV, TR, PL = _import_tracking_stack()
+    rec = {}
+    cases = [("a", 1000, 3, 0.2), ("b", 6000, 12, 0.02), ("c", 777, 4, 0.0), ("d", 1, 1, 1.0)]
+    for tag, E, k, frac in cases:
+        logits = synth.normal(3, (k, E), std=3.0)
+        labels = (synth.uniform01(4, E) < frac).astype(np.float32)
+        lg = torch.from_numpy(logits).clone().requires_grad_(True)
+        outputs = {"classified_edges": [lg[s].view(E, 1) for s in range(k)],
+                   "mask_predictions": [torch.zeros((2, 1, 4, 4)) for _ in range(k)]}
+        batch = types.SimpleNamespace(edge_labels=torch.from_numpy(labels), mask_labels=torch.zeros((2, 1, 4, 4)),
+                                      mask_gt_ixs=torch.zeros(0, dtype=torch.long))
+        solver = types.SimpleNamespace(hparams={"train_params": {"loss_weights": {"tracking": 0.75, "segmentation": 1.0}}})
+        loss = PL.MOTNeuralSolver._compute_loss(solver, outputs, batch)
+        loss.backward()
+        rec.update({f"{tag}:logits": logits, f"{tag}:labels": labels, f"{tag}:loss": np.float64(float(loss)),
+                    f"{tag}:grad": lg.grad.numpy(), f"{tag}:weight": np.float64(0.75)})
+    # metrics: two batched tracking graphs (both edge directions present), one self loop, thresholded logits
+    g = synth.batch_graphs([synth.make_graph(60, 400, T=6, seed=sd, node_in_dim=4) for sd in (1, 2)])
+    ei = g["edge_index"].copy()
+    ei[:, 3] = [7, 7]
+    for tag, seed, frac in (("m1", 8, 0.25), ("m2", 18, 0.6), ("m3", 28, 0.0)):
+        E = ei.shape[1]
+        logit = synth.normal(seed, (E, 1))
+        labels = (synth.uniform01(seed + 1, E) < frac).astype(np.float32)
+        go = types.SimpleNamespace(edge_index=torch.from_numpy(ei), edge_labels=torch.from_numpy(labels), num_nodes=120)
+        m = EV.compute_perform_metrics({"classified_edges": [torch.from_numpy(logit)]}, go)
+        sr, flow_in, flow_out = EV.compute_constr_satisfaction_rate(go, (torch.from_numpy(logit).view(-1) > 0).float(), return_flow_vals=True)
+        rec.update({f"{tag}:logit": logit, f"{tag}:labels": labels,
+                    f"{tag}:metrics": np.array([m["accuracy"], m["recall"], m["precision"], m["constr_sr"]], np.float64),
+                    f"{tag}:flow_in": flow_in.numpy(), f"{tag}:flow_out": flow_out.numpy()})
+    rec["edge_index"] = ei
+    np.savez_compressed(os.path.join(GOLD, "g9_loss_metrics.npz"), **rec)
+    print("g9 ok:", {k: float(v) for k, v in rec.items() if k.endswith(":loss")}, rec["m1:metrics"])
+
+
+def gen_g10():
+    """MPNTracker._evaluate_graph_in_batches + _predict_edges_and_masks (tracker/mpn_tracker.py:96-210) on a synthetic sequence,
+    driven with the REFERENCE model (mask branch included) on CPU.  Two redirections, because the code hard-codes the device:
+    the module's `torch.device('cuda')` resolves to the CPU and get_knn_mask is called with use_cuda=False."""
+    EV, TR, PL = _import_tracking_stack()
+    from mot_neural_solver.utils import graph as G
+    import torch.nn.functional as F
+    mpn = import_reference()
+
+    class _TorchProxy:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*a, **k):
+            return torch.device("cpu")
+    TR.torch = _TorchProxy()
+    real_knn = G.get_knn_mask
+    TR.get_knn_mask = lambda **kw: real_knn(**dict(kw, use_cuda=False))
+    captured = {}
+    real_undirected = TR.to_undirected_graph
+
+    def capture_then_undirected(mot_graph, attrs_to_update=("edge_preds", "edge_labels")):
+        captured["final_edge_preds"] = mot_graph.graph_obj.edge_preds.clone()
+        return real_undirected(mot_graph, attrs_to_update=attrs_to_update)
+    TR.to_undirected_graph = capture_then_undirected
+
+    rec = {}
+    for tag, inactive, recip, fpg, top_k in (("w1", False, True, 5, 6), ("w2", True, False, 4, 4)):
+        det = synth.make_detections(frames=9, dets_lo=3, dets_hi=6, seed=5, emb_dim=32, node_in_dim=64, frame_stride=2)
+        n = det["frame"].shape[0]
+        import pandas as pd
+        df = pd.DataFrame({k: det[k] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y")})
+        ei = G.get_time_valid_conn_ixs(torch.from_numpy(det["frame"]), "max", use_cuda=False)
+        feats = G.compute_edge_feats_dict(ei, df, 25.0, use_cuda=False)
+        ef = torch.stack([feats[k] for k in ("secs_time_dists", "norm_feet_x_dists", "norm_feet_y_dists", "bb_height_dists",
+                                             "bb_width_dists")]).T
+        emb = torch.from_numpy(det["reid"])
+        dist = F.pairwise_distance(emb[ei[0]], emb[ei[1]]).view(-1, 1)
+        ef = torch.cat((ef, dist), dim=1)
+        edge_index = torch.cat((ei, torch.stack((ei[1], ei[0]))), dim=1)
+        edge_attr = torch.cat((ef, ef), dim=0)
+        emb_dists = torch.cat((dist, dist))
+        params = synth.model_params(32, 4, "sum", num_class_steps=2, node_in_dim=64)
+        W = synth.make_weights(params, seed=7, gain=0.6)
+        W.update(synth.make_mask_weights(seed=17))
+        full = dict(params)
+        full.update(MASK_PARAMS)
+        model = mpn.MOTMPNet(full)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+        x = torch.from_numpy(det["x"]).view(n, 64, 1, 1)
+        x_ext = torch.from_numpy(synth.normal(9, (n, 256, 14, 14), stream=1, std=0.5))
+        from mot_neural_solver.data.mot_graph import Graph
+        graph_obj = Graph(x=x, x_ext=x_ext, edge_attr=edge_attr, reid_emb_dists=emb_dists, edge_index=edge_index)
+        full_graph = types.SimpleNamespace(frames=sorted(set(det["frame"].tolist())), graph_df=df, graph_obj=graph_obj,
+                                           frames_per_graph=fpg)
+        tracker = TR.MPNTracker(dataset=None, graph_model=model, use_gt=False,
+                                eval_params={"set_pruned_edges_to_inactive": inactive},
+                                dataset_params={"top_k_nns": top_k, "reciprocal_k_nns": recip, "gt_mask_spatial_size": [56, 56]})
+        tracker.full_graph = full_graph
+        tracker._evaluate_graph_in_batches()
+        rec.update({f"{tag}:frame": det["frame"], f"{tag}:x": det["x"], f"{tag}:edge_index": edge_index.numpy(),
+                    f"{tag}:edge_attr": edge_attr.numpy(), f"{tag}:reid_emb_dists": emb_dists.numpy(),
+                    f"{tag}:final_edge_preds": captured["final_edge_preds"].numpy(),
+                    f"{tag}:cfg": np.array([int(inactive), int(recip), fpg, top_k], np.int64)})
+        print("g10", tag, "nodes", n, "edges", edge_index.shape[1], "mean pred", float(captured["final_edge_preds"].mean()),
+              "windows", len(full_graph.frames) - fpg + 1)
+    np.savez_compressed(os.path.join(GOLD, "g10_windows.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3,g11,g12")
+    ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3,g11,g12,g10,g9")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     os.makedirs(GOLD, exist_ok=True)
@@ -513,6 +706,8 @@ def main():
     if "g8" in only: gen_g8()
     if "g2" in only: gen_cfg(mpn, "A", "g2_cfgA")
     if "g3" in only: gen_cfg(mpn, "B", "g3_cfgB", sample=4096)
+    if "g10" in only: gen_g10()
+    if "g9" in only: gen_g9()
     if "g11" in only: gen_g11(mpn)
     if "g12" in only: gen_g12(mpn)
 
