@@ -33,16 +33,39 @@ class MLP(nn.Module):
         return [m for m in self.fc_layers if isinstance(m, nn.Linear)]
 
     def require_fast_path(self):
-        if not self.fast_path:
+        """BatchNorm1d / Dropout (mlp.py:14,20; never enabled in the shipped configs, tracking_cfg.yaml:150-167): in eval mode
+        Dropout is the identity and BatchNorm is an affine map of the Linear's output that folds into its weight and bias
+        (``effective_linears``), so inference runs on the same kernels.  TRAINING with them -- batch statistics, random masks
+        and their gradients -- is not covered by the HIP path and raises."""
+        if not self.fast_path and self.training:
             raise capi.MpnhipError(
-                "BatchNorm / Dropout inside the MPN MLPs is not covered by the HIP path "
-                "(all shipped reference configs use use_batchnorm=False, dropout_p=0: configs/tracking_cfg.yaml:150-167)")
+                "training with BatchNorm / Dropout inside the MPN MLPs is not covered by the HIP path: call .eval() (BatchNorm "
+                "then folds into the Linear layers), or build the model with use_batchnorm=False, dropout_p=0 as all shipped "
+                "reference configs do (configs/tracking_cfg.yaml:150-167)")
+
+    def effective_linears(self):
+        """[(weight, bias)] of the Linear layers as the kernels see them: eval-mode BatchNorm1d folded in
+        (y = gamma (W x + b - mean) / sqrt(var + eps) + beta  =>  W' = s W, b' = s (b - mean) + beta, s = gamma / sqrt(var + eps))."""
+        out, mods = [], list(self.fc_layers)
+        for i, m in enumerate(mods):
+            if not isinstance(m, nn.Linear):
+                continue
+            w, b = m.weight.detach(), m.bias.detach()
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+            if bn is not None:
+                s = (bn.weight.detach() if bn.affine else torch.ones_like(bn.running_var)) / torch.sqrt(bn.running_var + bn.eps)
+                beta = bn.bias.detach() if bn.affine else torch.zeros_like(bn.running_mean)
+                w, b = (w * s.view(-1, 1)).contiguous(), ((b - bn.running_mean) * s + beta).contiguous()
+            out.append((w, b))
+        return out
 
     def c_struct(self, keep, grads=None):
         """``mpnhip_mlp`` for this module; ``grads`` maps id(param) -> gradient buffer (same shape)."""
         self.require_fast_path()
+        if grads is not None and not self.fast_path:
+            raise capi.MpnhipError("gradients of an MLP with BatchNorm / Dropout are not covered by the HIP path")
         s = capi.Mlp()
-        lin = [(l.weight.detach(), l.bias.detach()) for l in self.linears()]
+        lin = self.effective_linears()
         for w, b in lin:
             capi.require_device(w, b)
         capi.fill_mlp(s, lin, keep=keep)

@@ -495,7 +495,8 @@ class MOTMPNet(nn.Module):
         c = getattr(self, '_ops_cache', None)
         ptrs = tuple(p_.data_ptr() for p_ in self._hp_params())
         prec = getattr(self, 'gemm_precision', 'fp32')
-        if c is None or c[0] != ptrs or c[1] != prec or c[2] != int(self.num_enc_steps):
+        folded = not all(m_.fast_path for m_ in self.modules() if isinstance(m_, MLP))   # BatchNorm: fold afresh every call
+        if c is None or c[0] != ptrs or c[1] != prec or c[2] != int(self.num_enc_steps) or folded:
             spec, weights = torch_ops.model_spec(self)
             c = self._ops_cache = (ptrs, prec, int(self.num_enc_steps), spec, weights, spec[8], spec[9 + spec[7] + 1])
         spec, weights = c[3], c[4]

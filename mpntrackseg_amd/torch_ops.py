@@ -72,7 +72,11 @@ def model_spec(model):
             m.require_fast_path()
             layers = m.linears()
         spec += [len(layers), int(layers[0].weight.shape[1])] + [int(l.weight.shape[0]) for l in layers]
-        for l in layers:
-            weights += [l.weight.detach(), l.bias.detach()]
+        if m is None or m.fast_path:
+            for l in layers:
+                weights += [l.weight.detach(), l.bias.detach()]
+        else:   # eval-mode BatchNorm folded into the Linear layers (mlp.py: effective_linears)
+            for w, b in m.effective_linears():
+                weights += [w, b]
     spec[1] = int(model.MPNet.edge_model.edge_model.linears()[-1].weight.shape[0])   # de = the edge MLP's output width
     return spec, weights

@@ -595,3 +595,58 @@ def test_two_streams_do_not_share_scratch():
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert np.array_equal(o1.cpu().numpy(), ref1) and np.array_equal(o2.cpu().numpy(), ref2)
+
+
+def test_mlp_batchnorm_and_dropout_eval_mode():
+    """MLP with use_batchnorm / dropout (models/mlp.py:14,20): eval mode folds BatchNorm1d into the Linear layers and drops the
+    Dropout -- checked against stock torch modules with the same state; training with them raises."""
+    torch.manual_seed(3)
+    mlp = MLP(12, [24, 16, 1], dropout_p=0.3, use_batchnorm=True)
+    for m in mlp.fc_layers:
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.normal_(1.0, 0.2)
+            m.bias.data.normal_(0, 0.2)
+    x = torch.from_numpy(synth.normal(2, (333, 12)))
+    mlp.eval()
+    with torch.no_grad():
+        ref = torch.nn.Sequential.forward(mlp.fc_layers, x.clone())     # stock torch evaluation of the same Sequential
+        got = mlp.to(dev())(x.to(dev()))
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
+    mlp.train()
+    with pytest.raises(capi.MpnhipError):
+        with torch.no_grad():
+            mlp(x.to(dev()))
+    # the same inside the full model: a MOTMPNet built with batch-norm MLPs runs its hot path in eval mode
+    params = synth.model_params(32, 2, "sum", node_in_dim=64)
+    for k in ("edge_model_feats_dict", "node_model_feats_dict"):
+        params[k]["use_batchnorm"] = True
+    model = MOTMPNet(params).to(dev()).eval()
+    g = synth.make_graph(80, 500, seed=4, node_in_dim=64)
+    with torch.no_grad():
+        lg = model.hot_path(torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["edge_index"]).to(dev()),
+                            torch.from_numpy(g["edge_attr"]).to(dev()))
+    # freshly initialised BatchNorm (mean 0, var 1, gamma 1, beta 0) only rescales by 1 / sqrt(1 + eps): compare with the oracle on
+    # the folded weights
+    W = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, MLP):
+            for i, (w, b) in zip([j for j, m_ in enumerate(mod.fc_layers) if isinstance(m_, torch.nn.Linear)], mod.effective_linears()):
+                W["%s.fc_layers.%d.weight" % (name, i)] = w.cpu()
+                W["%s.fc_layers.%d.bias" % (name, i)] = b.cpu()
+    lin = model.MPNet.node_model.node_model[0]
+    W["MPNet.node_model.node_model.0.weight"], W["MPNet.node_model.node_model.0.bias"] = lin.weight.detach().cpu(), lin.bias.detach().cpu()
+    # the oracle's mlp() walks fc_layers indices 0, 2, 4 (Linear, ReLU): re-key the BatchNorm models' 0, 3 (Linear, BN, ReLU)
+    Wk = {}
+    for k, v in W.items():
+        parts = k.split(".fc_layers.")
+        if len(parts) == 2 and any(p in k for p in ("MPNet.edge_model", "flow_in_model", "flow_out_model")):
+            idx, rest = parts[1].split(".")
+            Wk["%s.fc_layers.%d.%s" % (parts[0], {0: 0, 3: 2}[int(idx)], rest)] = v
+        else:
+            Wk[k] = v
+    with torch.no_grad():
+        ref = torch.stack([l.view(-1) for l in O.forward(params, Wk, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
+                                                        torch.from_numpy(g["edge_attr"]), return_state=True)[1]]).numpy()
+    assert rel_err(lg.cpu().numpy(), ref) < 1e-4
