@@ -184,6 +184,7 @@ struct BwdPlan {
     float* dAGG;                        // [N, 2dn]
     float* dCat;                        // [max(E ke, N kx)] gradient w.r.t. the concatenated [initial | current] features
     float* dPsum;                       // [N, pw] sum over the steps of dP (the re-attached x0's share is one product)
+    float* dZ1sum;                      // [E, he] sum over the steps of the edge MLP's first-layer dZ (the re-attached e0's share)
     float* dZn;                         // [L][N, dn]
     float* dP;                          // [L][N, pw]
     float* dZfl[MPNHIP_MAX_LAYERS];     // flow MLP layer i:   [L][E, out_i]
@@ -226,6 +227,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     p.dXh = a.f((size_t)N * d.dn);
     p.dX0 = a.f((size_t)N * d.dn);
     p.dPsum = a.f((size_t)N * d.pw);
+    p.dZ1sum = a.f((size_t)E * d.he);
     p.dE0 = a.f((size_t)E * d.de);
     p.dAGG = a.f((size_t)N * 2 * d.dn);
     {
@@ -256,6 +258,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     upd(mlp_slab(m.enc_node, m.enc_node.in_dim, N, 1));
     upd(mlp_slab(m.enc_edge, m.enc_edge.in_dim, E, 1));
     upd(mlp_slab(m.edge, d.ke, E, (int)L));
+    for (int nb = 1; nb <= (int)L; ++nb) upd(tn_slab_floats(d.he, d.de, E, nb));   // (the e0-hoisted forms of the edge layer-0 product)
     upd(mlp_slab(m.flow_in, d.de, E, (int)L));
     upd(mlp_slab(m.classifier, d.de, E, (int)L));
     upd(tn_slab_floats(d.dn, 2 * d.dn, N, (int)L));
@@ -591,6 +594,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // The re-attached x0 does not change from step to step: its share of dX (and of the packed projection weight's gradient)
     // comes from the SUM of the steps' dP, once, after the loop
     const bool hoist_x = d.nf == 2 && L > 1 && N > 0 && pw % 4 == 0 && dn % 4 == 0 && !getenv("MPNHIP_NO_DX0_HOIST");
+    // The same for the re-attached e0 on the edge side (fused chain, whole 64-column passes: 32 < de <= 64): the gradient w.r.t. e0
+    // through the edge MLP's first layer and the e0 columns of that layer's weight gradient are ONE product each with
+    // S = sum_s dZ1_s after the loop -- 2 E he de MACs less in every step's backward chain and in every step's weight gradient
+    // (2 x 2.05 of ~31 GFLOP per step at cfg-B), for one pass over the kept dZ1 blocks.
+    const bool hoist_e0 = use_chain && d.ef == 2 && L > 1 && pad32(de) == 64 && he % 4 == 0 && de % 4 == 0 && !getenv("MPNHIP_NO_DE0_HOIST");
     // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per
     // weight (batch index = step - 1).  Issued on `st` with the slab buffer `slab`.
     auto mp_weight_grads = [&](int b0, int nb, hipStream_t st, float* slab) -> int {
@@ -628,7 +636,13 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                                     nullptr, E, nb, st));
             }
             MPN_TRY(mlp_weight_grads(p, slab, m.edge, nullptr, dzed_b, he_b, sstride, nullptr, E, nb, st));
-            {   // edge layer 0: e-part columns [2kx, 2kx + ke) = [e0 | e_{s-1}], and the bias
+            if (hoist_e0) {
+                // edge layer 0: the e_{s-1} columns [2kx + de, 2kx + 2 de) and the bias; the e0 columns follow after the loop
+                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx + de, nullptr};
+                float* gb[2] = {m.edge.grad_bias[0], nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {dzed_b[0], he, (int64_t)E * he}, nullptr, {f.e_hist + es * zb, de, (int64_t)es},
+                                    {nullptr, 0, 0}, de, nullptr, he, de, gw, m.edge.in_dim, gb, nullptr, E, nb, st));
+            } else {   // edge layer 0: e-part columns [2kx, 2kx + ke) = [e0 | e_{s-1}], and the bias
                 float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
                 float* gb[2] = {m.edge.grad_bias[0], nullptr};
                 const bool two = d.ef == 2;
@@ -744,6 +758,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
             EdgeChainBwdArgs a = {};
             a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0; a.split = bwd_split ? 1 : 0;
+            a.skip_e0 = hoist_e0 ? 1 : 0;
             a.he = he; a.de = de; a.hn = hn; a.dn = dn; a.hc = cls.out_dims[0];
             a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
             a.dAGG = p.dAGG; a.mask = reinterpret_cast<const unsigned*>(b.MK); a.ARG = b.ARG;
@@ -758,15 +773,17 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69)
             if (E >= 48 * N) {
                 // dense graphs (long segments): the three reductions as ONE launch of the block-per-segment kernel
-                const SegReduce2 c3[3] = {{dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn},
-                                          {dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0},
-                                          {dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he}};
+                const SegReduce2 c3[3] = {{dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, 0, 0},
+                                          {dzed[0], he, g.rperm, g.rseg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, 0, 0},
+                                          {dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, 0, 0}};
                 MPN_TRY(segment_reduce_csr2_x3(c3, E, s));
             } else {
-                MPN_TRY(segment_reduce_csr2(dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, s, E));
+                // sparse graphs: ONE launch of the short-segment kernel for the three (segment.hip, k_segment_reduce3).
                 // (by row: the sorted order IS (direction, row), so a node's rows are three contiguous runs of the CSR -- no list)
-                MPN_TRY(segment_reduce_csr2(dzed[0], he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, s, E, 3, (int)N));
-                MPN_TRY(segment_reduce_csr2(dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, s, E));
+                const SegReduce2 c3[3] = {{dzfl[0], hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, 0, 0},
+                                          {dzed[0], he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, 3, (int)N},
+                                          {dzed[0], he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, 0, 0}};
+                MPN_TRY(segment_reduce_csr2_x3(c3, E, s));
             }
         } else if (E > 0) {
             // ---- B. aggregation backward + ReLU of the last flow layer ---------------------------
@@ -865,6 +882,17 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         float* gw[2] = {p.gWnode, nullptr};
         MPN_TRY(weight_grad(p, p.slab, 1, {p.dPsum, pw, 0}, nullptr, {x0, dn, 0}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr,
                             N, 1, s));
+    }
+    if (hoist_e0) {
+        // S = sum_s dZ1_s (the blocks are all kept for the weight gradients);  dE0 += S W1[:, e0 columns];  dW1[:, e0 columns] += S^T e0
+        const int64_t n4 = E * he / 4;
+        hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dZed[0], E * he, (int)L, n4, p.dZ1sum);
+        MPN_LAUNCH_CHECK();
+        const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
+        MPN_TRY(act_grad(1, p.dZ1sum, he, nullptr, Wa, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s));
+        float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
+        MPN_TRY(weight_grad(p, p.slab, 1, {p.dZ1sum, he, 0}, nullptr, {e0, de, 0}, {nullptr, 0, 0}, de, nullptr, he, de, gw, m.edge.in_dim,
+                            nullptr, nullptr, E, 1, s));
     }
     auto unpack_node_grads = [&](hipStream_t us) -> int {
         // the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] back into the layers' grads (their biases were handled above)

@@ -53,6 +53,8 @@ struct EdgeChainArgs {
 struct EdgeChainBwdArgs {
     int E, N, agg, first_step, cat_two;
     int split;             // 1: the weight images are split images (pack_split)
+    int skip_e0;           // 1: B6 leaves out the column pass(es) of the re-attached e0 half: their gradient is ONE product with the
+                           // sum of the steps' dZ1 after the step loop (backward.hip).  Needs whole passes: 2 DE a multiple of 128.
     int he, de, hn, dn, hc;  // real widths
     const int* header;
     const int* srow;

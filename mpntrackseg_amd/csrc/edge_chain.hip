@@ -912,10 +912,12 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz1[t][r] = 0.f;
     const int rows6_0 = HE < NR6 ? HE : NR6;
+    // (skip_e0: the passes of the e0 half -- the first KEp / 128 of them -- are not computed here)
+    const int pass6_0 = A.skip_e0 ? npass6 / 2 : 0;
 #pragma unroll
     for (int i = 0; i < NCH5; ++i) {
         const bool more = i + 1 < NCH5;
-        const float* nsrc = more ? A.w2 + (i + 1) * (NR5 * HE * SCN / 2) : A.w1e;
+        const float* nsrc = more ? A.w2 + (i + 1) * (NR5 * HE * SCN / 2) : A.w1e + (int64_t)pass6_0 * HE * ncol6 * SCN / 2;
         const int nn4 = more ? N4_5 : rows6_0 * ncol6 / 4 * SCN / 2;
         chunk_fetch<chunk_q(cmax(N4_5, N4_6MAX)), SP>(nsrc, nn4, tid, wbuf_at(c + 1));
         // two sweeps over the same chunk keep the weight staging registers at about T1 / 2 per step
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
 
     TS(8);
     // ---- B6: d[e0 | e_{s-1}] = W1e^T dZ1, up to 64 (padded) output columns per pass ---------------------------------
-    for (int pass = 0; pass < npass6; ++pass) {
+    for (int pass = pass6_0; pass < npass6; ++pass) {
         // output tile tt (32 padded columns) of the pass belongs to half tt / T2 of [e0 | e_{s-1}], tile tt % T2 in it;
         // the first half is the re-attached initial features (accumulated over all steps: C-in = the running sum, read
         // here so that the MFMAs hide the load), the second e_{s-1} -- which IS e0 at the first step

@@ -68,9 +68,26 @@ __device__ inline void vmax(float& a, int* ia, const float& b, int id) {
 }
 
 template <int VEC>
+__device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid);
+
+template <int VEC>
 __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
+    seg_short_body<VEC>(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// three independent short-segment reductions in one launch (the backward's three scatter-adds of a step on sparse graphs: each
+// alone is ~6,000 waves that live for three dependent memory round trips -- offsets, indices, rows -- i.e. latency-bound at
+// ~25 us; together they overlap one another's round trips and pay one launch).  b0 / b1: blocks of the first / first two.
+__global__ __launch_bounds__(256) void k_segment_reduce3(SegArgs a0, SegArgs a1, SegArgs a2, int b0, int b1) {
+    const int b = blockIdx.x;
+    if (b < b0) seg_short_body<4>(a0, b * 256 + threadIdx.x);
+    else if (b < b1) seg_short_body<4>(a1, (b - b0) * 256 + threadIdx.x);
+    else seg_short_body<4>(a2, (b - b1) * 256 + threadIdx.x);
+}
+
+template <int VEC>
+__device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid) {
     typedef typename Vec<VEC>::T V;
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nblk = a.nblk > 1 ? a.nblk : 1;
     const int item = gtid / a.sub;
     const int s = item / nblk;
@@ -289,8 +306,8 @@ static bool try_launch_block(SegArgs& a, int64_t total_rows, hipStream_t stream)
     return true;
 }
 
-static int launch_seg(SegArgs a, hipStream_t stream) {
-    if (a.nseg <= 0 || a.dim <= 0) return MPNHIP_OK;
+// lanes per work item / column blocks of the short-segment kernel; returns the number of 256-thread blocks, *vec_out = float4 path
+static unsigned seg_short_geometry(SegArgs& a, bool* vec_out) {
     bool vec = (a.dim % 4 == 0) && (a.lds % 4 == 0) && (a.ldo % 4 == 0) && (a.off0 % 4 == 0) && (a.off1 % 4 == 0) &&
                (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.out & 15) == 0);
     int per = vec ? a.dim / 4 : a.dim;
@@ -298,16 +315,22 @@ static int launch_seg(SegArgs a, hipStream_t stream) {
     while (sub < per && sub < 64) sub <<= 1;
     a.nblk = 1;
     if (per > sub || (per & (per - 1))) {
-        // the row is not one power-of-two group of lanes (e.g. 80 or 56 x 16 bytes): column blocks of the largest
-        // power of two that divides it, one work item per (segment, block), so that no lane idles and no lane walks
-        // the segment twice; rows are still read in pieces of >= 256 contiguous bytes
         int p2 = per & -per;
         if (p2 > 64) p2 = 64;
-        if (p2 * (vec ? 16 : 4) >= 256) { sub = p2; a.nblk = per / p2; }  // (128-byte pieces measured slower than idle lanes)
+        if (p2 * (vec ? 16 : 4) >= 256) { sub = p2; a.nblk = per / p2; }
     }
     a.sub = sub;
-    int64_t threads = (int64_t)a.nseg * sub * a.nblk;
-    unsigned blocks = (unsigned)((threads + 255) / 256);
+    *vec_out = vec;
+    return (unsigned)(((int64_t)a.nseg * sub * a.nblk + 255) / 256);
+}
+
+static int launch_seg(SegArgs a, hipStream_t stream) {
+    if (a.nseg <= 0 || a.dim <= 0) return MPNHIP_OK;
+    // (rows that are not one power-of-two group of lanes, e.g. 80 or 56 x 16 bytes: column blocks of the largest power of two
+    // that divides them, one work item per (segment, block), so that no lane idles and no lane walks the segment twice; rows
+    // are still read in pieces of >= 256 contiguous bytes -- 128-byte pieces measured slower than idle lanes)
+    bool vec = false;
+    const unsigned blocks = seg_short_geometry(a, &vec);
     count_path(PC_SEG_SHORT);
     if (vec) hipLaunchKernelGGL(k_segment_reduce<4>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(k_segment_reduce<1>, dim3(blocks), dim3(256), 0, stream, a);
@@ -578,21 +601,41 @@ static SegArgs seg_args2(const SegReduce2& c) {
     SegArgs a = {};
     a.src = c.src; a.lds = c.lds; a.list = c.list; a.ptr = c.ptr; a.nseg = c.nseg; a.dim = c.dim; a.agg = MPNHIP_AGG_SUM;
     a.out = c.out; a.ldo = c.ldo; a.nmod = c.nmod > 0 ? c.nmod : 1; a.off0 = c.off0; a.off1 = c.off1;
+    a.runs = c.runs; a.run_stride = c.run_stride;
     return a;
 }
 
 // three segment_reduce_csr2 calls; ONE launch when all three take the block-per-segment kernel (dense graphs)
 int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream) {
     SegArgs a[3] = {seg_args2(c[0]), seg_args2(c[1]), seg_args2(c[2])};
-    if (block_eligible(a[0], total_rows) && block_eligible(a[1], total_rows) && block_eligible(a[2], total_rows)) {
+    const bool no_runs = c[0].runs <= 1 && c[1].runs <= 1 && c[2].runs <= 1;
+    if (no_runs && block_eligible(a[0], total_rows) && block_eligible(a[1], total_rows) && block_eligible(a[2], total_rows)) {
         count_path(PC_SEG_BLOCK3);
         hipLaunchKernelGGL(k_segment_reduce_block3, dim3(a[0].nseg + a[1].nseg + a[2].nseg), dim3(256), 0, stream, a[0], a[1], a[2]);
         MPN_LAUNCH_CHECK();
         return MPNHIP_OK;
     }
+    // sparse graphs (short segments): the three in one launch of the short-segment kernel when all take its float4 path and none
+    // would take the block-per-segment kernel on its own
+    {
+        bool v[3], blk = false;
+        unsigned nb[3];
+        for (int i = 0; i < 3; ++i) {
+            SegArgs t = a[i];
+            blk = blk || (c[i].runs <= 1 && block_eligible(t, total_rows));
+            nb[i] = a[i].nseg > 0 && a[i].dim > 0 ? seg_short_geometry(a[i], &v[i]) : 0;
+            if (nb[i] == 0) v[i] = true;
+        }
+        if (!blk && v[0] && v[1] && v[2] && nb[0] + nb[1] + nb[2] > 0 && !getenv("MPNHIP_NO_SEG3")) {
+            count_path(PC_SEG_SHORT3);
+            hipLaunchKernelGGL(k_segment_reduce3, dim3(nb[0] + nb[1] + nb[2]), dim3(256), 0, stream, a[0], a[1], a[2], (int)nb[0], (int)(nb[0] + nb[1]));
+            MPN_LAUNCH_CHECK();
+            return MPNHIP_OK;
+        }
+    }
     for (int i = 0; i < 3; ++i)
         MPN_TRY(segment_reduce_csr2(c[i].src, c[i].lds, c[i].list, c[i].ptr, c[i].nseg, c[i].dim, c[i].out, c[i].ldo, c[i].nmod, c[i].off0,
-                                    c[i].off1, stream, total_rows));
+                                    c[i].off1, stream, total_rows, c[i].runs > 1 ? c[i].runs : 1, c[i].run_stride));
     return MPNHIP_OK;
 }
 
