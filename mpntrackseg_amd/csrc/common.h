@@ -125,6 +125,10 @@ void tn_plan(TnArgs& a);
 size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);
 int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 
+// few rows, long K (node encoder at the reference's graph sizes): split-K into `scratch`, then a fixed-order sum (gemm.hip)
+bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k, int relu,
+                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status);
+size_t linear_splitk_scratch_floats(int64_t m, int n, int k);
 // Convenience: y = act(x W^T + b)
 int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k,
            int relu, hipStream_t stream);
@@ -199,7 +203,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_COUNT
 };
 void count_path(int id);
 

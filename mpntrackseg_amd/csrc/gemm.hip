@@ -581,4 +581,106 @@ int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y
     return launch_gemm(a, A_KCONTIG, B_KCONTIG, stream);
 }
 
+// ---- few rows, long K: split-K ------------------------------------------------------------------------------------------
+// y = act(x W^T + b) with M of a few hundred rows and K in the thousands (the node encoder's first layer at the reference's graph
+// sizes: [140 .. 500, 2048] x [2048, 128]): the tiled kernel above has ceil(M / 64) x ceil(N / 64) = 6 .. 16 blocks walking the
+// whole K -- 54 us on an otherwise idle chip, 40 % of a KITTI-sized forward.  Here the K range is cut into `S` slices as well
+// (grid.z): every block reduces one slice of one 64 x 64 tile with fp32 MFMAs into a partial tile [S][M][N], and a second
+// small kernel sums the S partials in a fixed order and applies bias / ReLU.  Deterministic; needs M N S floats of scratch.
+constexpr int SK_BK = 32, SK_P = 65;
+
+__global__ __launch_bounds__(256) void k_gemm_splitk(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, int M, int N,
+                                                     int K, int kc, float* __restrict__ part) {
+    __shared__ float As[SK_BK * SK_P], Bs[SK_BK * SK_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k0 = blockIdx.z * kc;
+    const int k1 = k0 + kc < K ? k0 + kc : K;
+    // loader: thread covers rows (tid / 8 + 32 j) of the tile at k offset (tid % 8) * 4
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    const float* ap[2];
+    const float* bp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int m = m0 + lr + 32 * j, n = n0 + lr + 32 * j;
+        m = m < M ? m : M - 1;
+        n = n < N ? n : N - 1;
+        ap[j] = x + (int64_t)m * ldx;
+        bp[j] = w + (int64_t)n * K;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kt = k0; kt < k1; kt += SK_BK) {
+        const int k = kt + lk;
+        const bool ok = k < k1;                 // K % 4 == 0 and kc % 32 == 0: a float4 is entirely in or out of the slice
+        float4 a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            a[j] = ok ? *reinterpret_cast<const float4*>(ap[j] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[j] = ok ? *reinterpret_cast<const float4*>(bp[j] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = lr + 32 * j;
+            As[(lk + 0) * SK_P + c] = a[j].x; As[(lk + 1) * SK_P + c] = a[j].y; As[(lk + 2) * SK_P + c] = a[j].z; As[(lk + 3) * SK_P + c] = a[j].w;
+            Bs[(lk + 0) * SK_P + c] = b[j].x; Bs[(lk + 1) * SK_P + c] = b[j].y; Bs[(lk + 2) * SK_P + c] = b[j].z; Bs[(lk + 3) * SK_P + c] = b[j].w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SK_BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + lh) * SK_P + wm * 32 + li], Bs[(kk + lh) * SK_P + wn * 32 + li], acc, 0, 0, 0);
+    }
+    float* out = part + (size_t)blockIdx.z * M * N;
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && n < N) out[(size_t)m * N + n] = acc[r];
+    }
+}
+
+__global__ void k_splitk_sum(const float* __restrict__ part, int64_t mn, int S, const float* __restrict__ bias, int N, int relu,
+                             float* __restrict__ y, int64_t ldy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mn) return;
+    float s = part[i];
+    for (int z = 1; z < S; ++z) s += part[(int64_t)z * mn + i];
+    const int n = (int)(i % N);
+    if (bias) s += bias[n];
+    if (relu) s = fmaxf(s, 0.f);
+    y[(i / N) * ldy + n] = s;
+}
+
+// true (and launched) when the shape calls for it and the scratch suffices; false: the caller takes the tiled kernel
+bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k, int relu,
+                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status) {
+    *status = MPNHIP_OK;
+    if (g_precision != 0 || getenv("MPNHIP_NO_SPLITK")) return false;
+    const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
+    if (!scratch || m <= 0 || m > 4096 || k < 512 || k % 4 != 0 || ldx % 4 != 0 || tiles >= 96 || (((uintptr_t)x | (uintptr_t)w) & 15)) return false;
+    int S = (int)(384 / tiles);
+    if (S > k / 64) S = k / 64;
+    if (S < 2) return false;
+    int kc = ((k + S - 1) / S + 31) / 32 * 32;
+    S = (k + kc - 1) / kc;
+    if ((size_t)S * m * n > scratch_floats) return false;
+    count_path(PC_GEMM_SPLITK);
+    hipLaunchKernelGGL(k_gemm_splitk, dim3((n + 63) / 64, (unsigned)((m + 63) / 64), S), dim3(256), 0, stream, x, ldx, w, (int)m, n, k, kc, scratch);
+    const int64_t mn = m * n;
+    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, mn, S, b, n, relu, y, ldy);
+    if (hipGetLastError() != hipSuccess) { set_error("split-K linear: launch failed"); *status = MPNHIP_ERR_HIP; }
+    return true;
+}
+
+size_t linear_splitk_scratch_floats(int64_t m, int n, int k) {
+    const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
+    if (m <= 0 || m > 4096 || k < 512 || tiles >= 96) return 0;
+    int S = (int)(384 / tiles);
+    if (S > k / 64) S = k / 64;
+    return S >= 2 ? (size_t)(S + 1) * m * n : 0;
+}
+
 }  // namespace mpnhip

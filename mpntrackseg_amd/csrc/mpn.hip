@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -453,8 +453,17 @@ static bool edge_encoder_fused(const mpnhip_mlp& m, const float* x, const int* i
 
 // full MLP (all layers) with ping-pong or per-layer hidden buffers; a_idx permutes the input rows
 static int mlp_forward(const mpnhip_mlp& m, const float* x, int64_t ldx, const int* a_idx, float* const* hidden, float* y,
-                       int64_t rows, hipStream_t s) {
+                       int64_t rows, hipStream_t s, float* splitk = nullptr, size_t splitk_floats = 0) {
     for (int i = 0; i < m.n_layers; ++i) {
+        if (splitk && !a_idx) {
+            int st = MPNHIP_OK;
+            const int k_in = i == 0 ? m.in_dim : m.out_dims[i - 1];
+            if (linear_splitk(i == 0 ? x : hidden[i - 1], i == 0 ? ldx : k_in, m.weight[i], m.bias[i], i == m.n_layers - 1 ? y : hidden[i],
+                              m.out_dims[i], rows, m.out_dims[i], k_in, m.out_dims[i] != 1, splitk, splitk_floats, s, &st)) {
+                if (st != MPNHIP_OK) return st;
+                continue;
+            }
+        }
         GemmArgs a = {};
         a.ngroups = 1;
         a.N = m.out_dims[i];
@@ -544,7 +553,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     float* x0 = p.x_hist;
     float* e0 = p.e_hist;
     hidden_ptrs(m.enc_node, p.enc_n, N, save != 0, hid);
-    MPN_TRY(mlp_forward(m.enc_node, x, m.enc_node.in_dim, nullptr, hid, x0, N, s));
+    MPN_TRY(mlp_forward(m.enc_node, x, m.enc_node.in_dim, nullptr, hid, x0, N, s, p.splitk, p.splitk_floats));
     hidden_ptrs(m.enc_edge, p.enc_e, E, save != 0, hid);
     {
         int st = MPNHIP_OK;

@@ -132,6 +132,8 @@ struct FwdPlan {
     int hist_slots;
     StepBufs step0;
     size_t step_stride_bytes;  // 0 when the step buffers are reused (inference)
+    float* splitk;             // scratch of the split-K form of the node encoder's layers (few rows, long K), or nullptr
+    size_t splitk_floats;
     size_t total;
 };
 
@@ -206,6 +208,15 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     if (save && d.L > 1) {
         p.step_stride_bytes = a.off - before;
         a.off = before + p.step_stride_bytes * (size_t)d.L;
+    }
+    {
+        size_t sk = 0;
+        for (int i = 0; i < m.enc_node.n_layers; ++i) {
+            const size_t f = linear_splitk_scratch_floats(N, m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1]);
+            sk = f > sk ? f : sk;
+        }
+        p.splitk_floats = sk;
+        p.splitk = sk ? a.f(sk) : nullptr;
     }
     p.total = a.off;
     if (out) *out = p;
