@@ -556,6 +556,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                                    p.w1ep + (int64_t)(col0 / 64) * HE * ncol6 * 3 / 2, s, ncol6 / 32, (col0 % 64) / 32));
             }
         } else {
+            PackBatch pb;
+            pack_batch_begin(&pb);   // (the eight images as one launch; nothing below returns before the flush)
             for (int q = 0; q < 2; ++q) {
                 MPN_TRY(pack_padded(fl[q]->weight[1], hn, 0, dn, hn, p.wf2p[q], DN, HN, HN, 0, s));
                 MPN_TRY(pack_padded(fl[q]->weight[0], fl[q]->in_dim, kx, hn, de, p.wfep[q], HN, DE, DE, 0, s));
@@ -569,6 +571,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 MPN_TRY(pack_padded(m.edge.weight[0], m.edge.in_dim, 2 * kx + hlf * de, he, de,
                                     p.w1ep + (int64_t)(col0 / 64) * HE * ncol6, HE, DE, ncol6, col0 % 64, s));
             }
+            MPN_TRY(pack_batch_flush(s));
         }
     }
 

@@ -196,6 +196,26 @@ bool prof_launch_events(hipEvent_t* start, hipEvent_t* stop);
             hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                              \
     } while (0)
 
+// Deferred weight packing: the ~15-25 tiny copy / pad / transpose launches that build the packed weight images of a forward (and the
+// 8 of a backward) are RECORDED while a batch is open and run as ONE launch at the flush (k_pack_multi, mpn.hip) -- at the
+// reference's graph sizes those launches, ~5 us apart, were 6 % of a training step.
+struct PackOp {
+    const float* src;   // nullptr: zeros
+    float* dst;
+    int64_t lds;
+    int c0, rows, cols, rows_pad, cols_pad, ldd, dst_c0;
+    int transposed;     // 0: dst[r * ldd + dst_c0 + c] = src[r * lds + c0 + c] (r < rows, c < cols; else 0) over rows_pad x cols_pad
+                        // 1: dst[k * cols_pad + n] = src[n * lds + c0 + k] (k < rows, n < cols; else 0) over rows_pad (k) x cols_pad (n)
+};
+struct PackBatch {
+    static constexpr int MAX = 32;
+    PackOp op[MAX];
+    int n;
+};
+void pack_batch_begin(PackBatch* b);            // opens `b` for the calling thread (n = 0)
+bool pack_batch_add(const PackOp& op);          // true: recorded (a batch is open and has room)
+int pack_batch_flush(hipStream_t stream);       // launches what was recorded, closes the batch
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Host-side counters of the kernel variants launched (mpnhip_debug_counters): test instrumentation that lets a parity test

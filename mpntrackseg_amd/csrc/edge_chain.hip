@@ -1075,6 +1075,7 @@ int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, i
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s) {
     const int64_t n = (int64_t)n_pad * k_pad;
     if (n <= 0) return MPNHIP_OK;
+    if (pack_batch_add({W, WT, ldw, k0, k_cols, n_rows, k_pad, n_pad, n_pad, 0, 1})) return MPNHIP_OK;
     hipLaunchKernelGGL(k_transpose_padded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, k0, n_rows, k_cols, WT, n_pad, k_pad);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
@@ -1084,6 +1085,7 @@ int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float
                 int dst_c0, hipStream_t s) {
     const int64_t n = (int64_t)rows_pad * cols_pad;
     if (n <= 0) return MPNHIP_OK;
+    if (pack_batch_add({src, dst, lds, c0, rows, cols, rows_pad, cols_pad, ldd, dst_c0, 0})) return MPNHIP_OK;
     hipLaunchKernelGGL(k_pack_padded, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, c0, rows, cols, dst, rows_pad,
                        cols_pad, ldd, dst_c0);
     MPN_LAUNCH_CHECK();

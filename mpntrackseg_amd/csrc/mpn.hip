@@ -133,15 +133,69 @@ __global__ void k_avgpool(const float* __restrict__ x, int64_t rows, int hw, flo
     if (r < rows && l == 0) y[r] = acc / (float)hw;
 }
 
+// ------------------------------------------------------------------------------------ deferred packing (common.h)
+static thread_local PackBatch* g_pack_batch = nullptr;
+
+__device__ __forceinline__ void pack_one(const PackOp& o, int64_t i) {
+    const int64_t n = (int64_t)o.rows_pad * o.cols_pad;
+    if (i >= n) return;
+    const int r = (int)(i / o.cols_pad), c = (int)(i % o.cols_pad);
+    const bool in = o.src && r < o.rows && c < o.cols;
+    if (o.transposed) o.dst[i] = in ? o.src[(int64_t)c * o.lds + o.c0 + r] : 0.f;
+    else o.dst[(int64_t)r * o.ldd + o.dst_c0 + c] = in ? o.src[(int64_t)r * o.lds + o.c0 + c] : 0.f;
+}
+
+// blockIdx.y = op (static indices into the by-value argument: a dynamic one would move the whole table to scratch memory)
+__global__ __launch_bounds__(256) void k_pack_multi(PackBatch b) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    switch (blockIdx.y) {
+#define MPN_PACK_CASE(k) case k: pack_one(b.op[k], i); break;
+        MPN_PACK_CASE(0) MPN_PACK_CASE(1) MPN_PACK_CASE(2) MPN_PACK_CASE(3) MPN_PACK_CASE(4) MPN_PACK_CASE(5) MPN_PACK_CASE(6) MPN_PACK_CASE(7)
+        MPN_PACK_CASE(8) MPN_PACK_CASE(9) MPN_PACK_CASE(10) MPN_PACK_CASE(11) MPN_PACK_CASE(12) MPN_PACK_CASE(13) MPN_PACK_CASE(14) MPN_PACK_CASE(15)
+        MPN_PACK_CASE(16) MPN_PACK_CASE(17) MPN_PACK_CASE(18) MPN_PACK_CASE(19) MPN_PACK_CASE(20) MPN_PACK_CASE(21) MPN_PACK_CASE(22) MPN_PACK_CASE(23)
+        MPN_PACK_CASE(24) MPN_PACK_CASE(25) MPN_PACK_CASE(26) MPN_PACK_CASE(27) MPN_PACK_CASE(28) MPN_PACK_CASE(29) MPN_PACK_CASE(30) MPN_PACK_CASE(31)
+#undef MPN_PACK_CASE
+        default: break;
+    }
+}
+
+void pack_batch_begin(PackBatch* b) {
+    b->n = 0;
+    g_pack_batch = getenv("MPNHIP_NO_PACK_BATCH") ? nullptr : b;
+}
+
+bool pack_batch_add(const PackOp& op) {
+    PackBatch* b = g_pack_batch;
+    if (!b || b->n >= PackBatch::MAX) return false;
+    if ((int64_t)op.rows_pad * op.cols_pad > 0) b->op[b->n++] = op;
+    return true;
+}
+
+int pack_batch_flush(hipStream_t s) {
+    PackBatch* b = g_pack_batch;
+    g_pack_batch = nullptr;
+    if (!b || b->n == 0) return MPNHIP_OK;
+    int64_t mx = 0;
+    for (int i = 0; i < b->n; ++i) {
+        const int64_t n = (int64_t)b->op[i].rows_pad * b->op[i].cols_pad;
+        mx = n > mx ? n : mx;
+    }
+    hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)((mx + 255) / 256), b->n), dim3(256), 0, s, *b);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
 static int copy_block(const float* src, int64_t lds, int c0, float* dst, int64_t ldd, int rows, int cols, hipStream_t s) {
     int64_t n = (int64_t)rows * cols;
     if (n <= 0) return MPNHIP_OK;
+    if (pack_batch_add({src, dst, lds, c0, rows, cols, rows, cols, (int)ldd, 0, 0})) return MPNHIP_OK;
     hipLaunchKernelGGL(k_copy_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, c0, dst, ldd, rows, cols);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
 static int copy_vec(const float* src, float* dst, int n, hipStream_t s) {
     if (n <= 0) return MPNHIP_OK;
+    if (pack_batch_add({src, dst, n, 0, 1, n, 1, n, n, 0, 0})) return MPNHIP_OK;
     hipLaunchKernelGGL(k_copy_vec, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
@@ -544,8 +598,13 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         p.cw.split = chain_split(m);
     } else {
         count_path(PC_WEIGHT_PACK);
-        MPN_TRY(pack_node_weights(m, d, p.Wnode, p.bnode, s));
-        MPN_TRY(pack_chain_weights(m, d, p.cw, s));
+        PackBatch pb;
+        pack_batch_begin(&pb);   // (the fp32 images' copies / transposes are recorded and run as one launch)
+        int rc = pack_node_weights(m, d, p.Wnode, p.bnode, s);
+        if (rc == MPNHIP_OK) rc = pack_chain_weights(m, d, p.cw, s);
+        const int rf = pack_batch_flush(s);
+        MPN_TRY(rc);
+        MPN_TRY(rf);
     }
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
