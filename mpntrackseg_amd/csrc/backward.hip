@@ -731,7 +731,9 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     bool& forked = join.forked;
     bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
     bool node_a_done = false;   // dZn / dAGG of the coming step were already produced by node_step32_bwd
-    const bool fuse_node_bwd = dn == 32 && N <= 4096 && pw <= 1088 && !getenv("MPNHIP_NO_NODE_FUSION");
+    // (k_node_step32_bwd stages the weights in LDS: 128 pw + 8 KB + ... <= 64 KB, 16-byte aligned rows)
+    const bool fuse_node_bwd = dn == 32 && N <= 4096 && pw <= 384 && kx % 4 == 0 &&
+                               ((((uintptr_t)f.Wnode) | ((uintptr_t)m.node.weight[0])) & 15) == 0 && !getenv("MPNHIP_NO_NODE_FUSION");
 
     for (int step = L; step >= 1; --step) {
         const int b_ = step - 1;  // batch (block) index of this step

@@ -471,41 +471,59 @@ struct NodeStepBwdArgs {
     float* dAGG;             // [N, 64] out
 };
 
+// Block = 4 nodes.  The projection weights' current-feature columns (pw x 32 floats, 35 KB at the reference dims) and the node
+// update weights (8 KB) are staged in LDS with coalesced 16-byte loads -- the first version read them element by element from L2
+// inside the contraction loops (68 dependent loads per thread: 20-28 us per launch, latency); now ~6 us.
+constexpr int NSB_NODES = 4;
 __global__ __launch_bounds__(256) void k_node_step32_bwd(NodeStepBwdArgs a) {
-    __shared__ float dp_s[2][1088 + 4];    // the two nodes' dP rows (pw <= 1088)
-    __shared__ float part[4][64];
-    __shared__ float dz_s[2][32];
+    extern __shared__ float nsb_smem[];
+    float* wx_s = nsb_smem;                          // [pw][32]
+    float* wu_s = wx_s + (size_t)a.pw * 32;          // [32][64]
+    float* dp_s = wu_s + 32 * 64;                    // [4][pw]
+    float* part = dp_s + NSB_NODES * (size_t)a.pw;   // [2][128]
+    float* dz_s = part + 2 * 128;                    // [4][32]
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * 2;
-    for (int i = tid; i < 2 * a.pw; i += 256) {
-        const int nl = i >= a.pw ? 1 : 0, pidx = i - nl * a.pw;
-        dp_s[nl][pidx] = n0 + nl < a.N ? a.dP[(int64_t)(n0 + nl) * a.pw + pidx] : 0.f;
+    const int n0 = blockIdx.x * NSB_NODES;
+    for (int i = tid; i < a.pw * 8; i += 256) {      // rows of 32 floats = 8 float4 (ldwx % 4 == 0, 16-byte aligned: checked by the launcher)
+        const int pp = i >> 3, q = i & 7;
+        *reinterpret_cast<float4*>(wx_s + pp * 32 + 4 * q) = *reinterpret_cast<const float4*>(a.Wx + (int64_t)pp * a.ldwx + 4 * q);
+    }
+    for (int i = tid; i < 32 * 16; i += 256) *reinterpret_cast<float4*>(wu_s + 4 * i) = *reinterpret_cast<const float4*>(a.Wu + 4 * i);
+    for (int i = tid; i < NSB_NODES * a.pw; i += 256) {
+        const int nl = i / a.pw, pidx = i - nl * a.pw;
+        dp_s[i] = n0 + nl < a.N ? a.dP[(int64_t)(n0 + nl) * a.pw + pidx] : 0.f;
     }
     __syncthreads();
-    {   // dX: 64 outputs, the contraction over pw split over four thread groups (fixed order when they meet)
-        const int o = tid & 63, kq = tid >> 6;
+    {   // dX: 4 nodes x 32 outputs, the contraction over pw split in two halves (fixed order when they meet)
+        const int o = tid & 127, half = tid >> 7;
         const int nl = o >> 5, c = o & 31;
-        const int per = (a.pw + 3) / 4, p0 = kq * per, p1 = p0 + per < a.pw ? p0 + per : a.pw;
-        float s = 0.f;
-        for (int pp = p0; pp < p1; ++pp) s = fmaf(dp_s[nl][pp], a.Wx[(int64_t)pp * a.ldwx + c], s);
-        part[kq][o] = s;
+        const int per = (a.pw + 1) / 2, p0 = half * per, p1 = p0 + per < a.pw ? p0 + per : a.pw;
+        const float* dp = dp_s + nl * a.pw;
+        float s0 = 0.f, s1 = 0.f;
+        int pp = p0;
+        for (; pp + 1 < p1; pp += 2) {
+            s0 = fmaf(dp[pp], wx_s[pp * 32 + c], s0);
+            s1 = fmaf(dp[pp + 1], wx_s[(pp + 1) * 32 + c], s1);
+        }
+        if (pp < p1) s0 = fmaf(dp[pp], wx_s[pp * 32 + c], s0);
+        part[half * 128 + o] = s0 + s1;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 128) {
         const int nl = tid >> 5, c = tid & 31;
-        const float dx = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        const float dx = part[tid] + part[128 + tid];
         const bool ok = n0 + nl < a.N;
         const float xv = ok ? a.x_prev[(int64_t)(n0 + nl) * 32 + c] : 0.f;
         const float dz = xv > 0.f ? dx : 0.f;
-        dz_s[nl][c] = dz;
+        dz_s[tid] = dz;
         if (ok) a.dZn[(int64_t)(n0 + nl) * 32 + c] = dz;
     }
     __syncthreads();
-    if (tid < 128) {   // dAGG: 2 nodes x 64 outputs, 32 FMAs each
+    {   // dAGG: 4 nodes x 64 outputs, 32 FMAs each
         const int nl = tid >> 6, j = tid & 63;
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) s = fmaf(dz_s[nl][c], a.Wu[c * 64 + j], s);
+        for (int c = 0; c < 32; ++c) s = fmaf(dz_s[nl * 32 + c], wu_s[c * 64 + j], s);
         if (n0 + nl < a.N) a.dAGG[(int64_t)(n0 + nl) * 64 + j] = s;
     }
 }
@@ -514,9 +532,11 @@ int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldw
                     float* dAGG, hipStream_t stream) {
     if (N <= 0) return MPNHIP_OK;
     if (pw > 1088) { set_error("node_step32_bwd: projection width too large"); return MPNHIP_ERR_UNSUPPORTED; }
+    if ((ldwx & 3) || (((uintptr_t)Wx | (uintptr_t)Wu) & 15)) { set_error("node_step32_bwd: weights must be 16-byte aligned"); return MPNHIP_ERR_ARG; }
     NodeStepBwdArgs a = {dP, N, pw, Wx, ldwx, x_prev, Wu, dZn, dAGG};
     count_path(PC_NODE_STEP32_BWD);
-    hipLaunchKernelGGL(k_node_step32_bwd, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, stream, a);
+    const size_t smem = ((size_t)pw * 32 + 32 * 64 + NSB_NODES * (size_t)pw + 2 * 128 + NSB_NODES * 32) * sizeof(float);   // <= 160 KB at pw = 1088
+    hipLaunchKernelGGL(k_node_step32_bwd, dim3((unsigned)((N + NSB_NODES - 1) / NSB_NODES)), dim3(256), smem, stream, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

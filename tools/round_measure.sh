@@ -1,34 +1,42 @@
 #!/bin/bash
 # Round measurement set (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats of the default bench
 # command, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only), tracking-driver numbers.
-# Outputs land in gpurun_out/r01/; copy what should be judged into profiles/r01/.
+# Outputs land in gpurun_out/$RND/; copy what should be judged into profiles/$RND/.
+RND=${RND:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r01
+O=$R/gpurun_out/$RND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_r01.json
-python $R/bench.py --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_r01.json
-python $R/bench.py --config C --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_train_r01.json
-python $R/bench.py --config C --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_fwd_r01.json
-python $R/bench.py --config D --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgD_train_r01.json
-# MPNHIP_PREC_FP32_SPLIT (fp32 results from three-piece bf16 operands in the fused chain kernels): own bench lines + PMC passes
-python $R/bench.py --precision fp32_split --no-cpu-baseline 2>&1 | tail -1 > $O/bench_split_r01.json
-python $R/bench.py --precision fp32_split --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_split_r01.json
-python $R/bench.py --config C --precision fp32_split --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_train_split_r01.json
-python $R/bench.py --config C --precision fp32_split --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_fwd_split_r01.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_split -- python $R/bench.py --precision fp32_split --no-cpu-baseline > $O/stats_split.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_split -- python $R/bench.py --precision fp32_split --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_fetch_split.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_split -- python $R/bench.py --precision fp32_split --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_write_split.log 2>&1
+python $R/bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_$RND.json
+python $R/bench.py --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_$RND.json
+python $R/bench.py --config C --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_train_$RND.json
+python $R/bench.py --config C --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_fwd_$RND.json
+python $R/bench.py --config D --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgD_train_$RND.json
+python $R/bench.py --config D --mode fwd --steps 300 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgD_fwd_$RND.json
+python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 2>&1 | tail -1 > $O/bench_cfgE_bf16_fwd_$RND.json
+python $R/bench.py --config E --precision fp32 --mode fwd --steps 6 --warmup 2 --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_cfgE_fp32_fwd_$RND.json
+# MPNHIP_PREC_FP32_SPLIT (opt-in): own bench lines
+python $R/bench.py --precision fp32_split --no-cpu-baseline 2>&1 | tail -1 > $O/bench_split_$RND.json
+python $R/bench.py --precision fp32_split --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_split_$RND.json
+# kernel stats of the default command and of the cfg-E line
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-split-line > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd -- python $R/bench.py --mode fwd --no-cpu-baseline --no-split-line > $O/stats_fwd.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_cfgE.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgC -- python $R/bench.py --config C --no-cpu-baseline --no-split-line > $O/stats_cfgC.log 2>&1
+# HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_E.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_E.log 2>&1
 cd $R
-python tools/track_bench.py 2>/dev/null | tail -1 > $O/track_bench_r01.json
+python tools/track_bench.py 2>/dev/null | tail -1 > $O/track_bench_$RND.json
 F=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv | head -1)
-python tools/pmc_summary.py $F $W $O/pmc_summary.json
-F=$(ls $O/pmc_fetch_split/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write_split/*/*counter_collection.csv | head -1)
-python tools/pmc_summary.py $F $W $O/pmc_summary_split.json
-cp $(ls $O/stats_split/*/*kernel_stats.csv | head -1) $O/bench_train_cfgB_split_kernel_stats.csv
+python tools/pmc_summary.py $F $W $O/pmc_summary.json > /dev/null
+F=$(ls $O/pmc_fetch_E/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write_E/*/*counter_collection.csv | head -1)
+python tools/pmc_summary.py $F $W $O/pmc_summary_cfgE.json > /dev/null
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/bench_train_cfgB_kernel_stats.csv
-rm -rf $O/stats*/*/*kernel_trace.csv $O/pmc_fetch*/*/*kernel_trace.csv $O/pmc_write*/*/*kernel_trace.csv
-head -c 600 $O/bench_r01.json; echo; head -c 300 $O/bench_fwd_r01.json; echo; head -12 $O/bench_train_cfgB_kernel_stats.csv | cut -c1-150
+cp $(ls $O/stats_fwd/*/*kernel_stats.csv | head -1) $O/bench_fwd_cfgB_kernel_stats.csv
+cp $(ls $O/stats_cfgE/*/*kernel_stats.csv | head -1) $O/bench_fwd_cfgE_bf16_kernel_stats.csv
+cp $(ls $O/stats_cfgC/*/*kernel_stats.csv | head -1) $O/bench_train_cfgC_kernel_stats.csv
+rm -rf $O/stats*/ $O/pmc_fetch*/ $O/pmc_write*/
+head -c 500 $O/bench_$RND.json; echo; head -c 300 $O/bench_fwd_$RND.json; echo; head -8 $O/bench_train_cfgB_kernel_stats.csv | cut -c1-150
