@@ -269,7 +269,7 @@ def main():
 
     if prof is not None:
         keep = []
-        chain = bool(lib.mpnhip_edge_chain_active(model.c_model(keep)))
+        chain = int(lib.mpnhip_edge_chain_active(model.c_model(keep)))   # 1: fp32 / split chain kernels, 2: bf16-operand chain
         out.update(rooflines(prof, c, args, N, E, chain, mode))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, W, g, mode == "train")
@@ -322,6 +322,11 @@ def main():
 def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
     tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
+    if cfg_name == "E" and precision == "bf16":
+        try:
+            return json.load(open(os.path.join(REPO, "profiles", "r02", "pmc_summary_cfgE.json"))).get(kernel_key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
     if cfg_name != "B" or precision == "bf16":
         return None
     for rnd in ("r02", "r01"):
@@ -348,7 +353,30 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
     dn, de, he = d, d // 2, 5 * d // 2
     res = {}
     hn, hc = 7 * d // 4, d // 4
-    if gemm_n and chain:
+    if gemm_n and chain == 2:
+        # bf16-operand chain (edge_chain_bf16.hip): all of [e0 | e] is contracted in the kernel (no Q0 hoist: at these widths the
+        # re-read of an [E, he] fp32 table costs more than the MFMAs it saves)
+        macs = 2 * de * he + he * de + de * hc + hc + de * hn + hn * dn
+        flops = 2.0 * E * macs
+        # what the kernel must move at least -- both first-layer inputs and both outputs once, the
+        # per-node projection table once, the edge indices, the logits
+        alg_bytes = E * (2 * de * 4 + de * 4 + dn * 4 + 12 + 4) + N * (2 * he + 2 * hn) * 4
+        ach = alg_bytes / (gemm_us * 1e-6) / 1e9
+        traffic = pmc_traffic("edge_chain_bf16", args.config, args.precision)
+        res["roofline"] = {"bound": "hbm",
+                           "kernel": "edge_chain_bf16_kernel<20,4,14,8,2>: fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
+                                     "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers; bound by the per-edge "
+                                     "gathers of the projection table (%d B per edge from a %d MB table, uniformly random columns)"
+                                     % ((2 * he + hn) * 4, N * (2 * he + 2 * hn) * 4 // 1000000),
+                           "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                           "algorithmic_bytes": alg_bytes, "avg_us": gemm_us, "empty_event_pair_us": empty_us, "launches": gemm_n,
+                           "algorithmic_flops": flops, "mfma_tflops": flops / (gemm_us * 1e-6) / 1e12,
+                           "mfma_frac_of_bf16_peak": flops / (gemm_us * 1e-6) / 1e12 / 2516.6,
+                           "ms_per_step": gemm_us * c["L"] / 1e3}
+        if traffic:
+            res["roofline"]["traffic_over_algorithmic"] = traffic / alg_bytes
+            res["roofline"]["traffic_rate_gbs"] = traffic / (gemm_us * 1e-6) / 1e9
+    elif gemm_n and chain:
         # fused per-edge chain (edge MLP e-part + classifier + flow MLP e-part): MACs per edge, DESIGN.md section 4
         # the re-attached e0's share of the first layer is computed once per forward (Q0, one GEMM) when de >= 32: the
         # kernel then contracts de, not 2 de, columns there -- EXECUTED flops are what the MFMA fraction is quoted on

@@ -351,7 +351,8 @@ int mpnhip_average_preds(const float* overall_preds, const float* overall_num, i
  * The empty-pair cost applies to the default (NULL) stream the calibration pairs are recorded on. */
 int mpnhip_profile_enable(int on);   /* 0 = off, 1 = time every launch of the two kernels, n > 1 = every n-th launch */
 /* 1 when mpnhip_forward evaluates the per-edge chain (edge MLP + classifier + flow MLPs) of this model with the
- * fused edge_chain kernel (then THAT kernel is the one bracketed as "gemm" by the profile hooks), else 0. */
+ * fused edge_chain kernel (then THAT kernel is the one bracketed as "gemm" by the profile hooks), 2 when it does so with
+ * the bf16-operand chain kernel (MPNHIP_PREC_BF16, edge_chain_bf16.hip), else 0. */
 int mpnhip_edge_chain_active(const mpnhip_model* model);
 int mpnhip_profile_read(float* gemm_avg_us, int* gemm_launches, float* agg_avg_us, int* agg_launches,
                         float* empty_pair_us /* cost of an event pair with nothing between, for calibration */);

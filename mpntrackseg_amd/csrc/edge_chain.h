@@ -105,4 +105,41 @@ int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols
 int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
                 int dst_c0, hipStream_t s);
 
+
+// ---- bf16-operand forward chain (edge_chain_bf16.hip): N-tiled hidden layers, widths up to BASELINE.json configs[4] (256-d)
+struct EdgeChainBf16Args {
+    int E, N;
+    int he, de, hn, dn, hc;   // real widths (multiples of 4; hc any)
+    const int* header;        // graph header: [1] = E_out, [2] = E_in
+    const int* srow;
+    const int* scol;
+    const int* perm;
+    const float* xa;          // first-layer input segments [e0 | e]: xa [E, de] (ld ldxa), xb [E, de] (ld ldxb)
+    const float* xb;
+    int64_t ldxa, ldxb;
+    const float* P;           // [N, pw] per-node projections: [Pr (he) | Pc (he) | Pf_out (hn) | Pf_in (hn)]
+    int pw;
+    const void* img_edge;     // pair images (pack_chain_bf16)
+    const void* img_cls;
+    const void* img_flow[2];  // 0: flow_out, 1: flow_in
+    const float* b2;          // [de]
+    const float* bc1;         // [hc]
+    const float* wc2;         // [hc]
+    const float* bc2;         // [1]
+    const float* bf2_out;     // [dn]
+    const float* bf2_in;
+    float* e_new;             // [E, de]  sorted edge order
+    float* msg;               // [E, dn]
+    float* logits;            // [E] ORIGINAL order (through perm)
+};
+bool edge_chain_bf16_supported(int he, int de, int hn, int dn, int hc, int ef);
+// bytes of the four pair images (edge | classifier | flow_out | flow_in) and the offsets of the last three
+size_t chain_bf16_image_bytes(int he, int de, int hn, int dn, int hc, int ef, size_t* off_cls, size_t* off_flow0, size_t* off_flow1);
+// w_edge0: edge MLP layer 0 [he][ld_edge0], its e columns start at col0_edge (ef segments of de); w_edge1 [de][he];
+// w_cls0 [hc][de]; w_flow0[q] [hn][ld_flow0], e' columns from col0_flow; w_flow1[q] [dn][hn]
+int pack_chain_bf16(const float* w_edge0, int ld_edge0, int col0_edge, int ef, const float* w_edge1, const float* w_cls0,
+                    const float* const w_flow0[2], int ld_flow0, int col0_flow, const float* const w_flow1[2],
+                    int he, int de, int hn, int dn, int hc, void* image, hipStream_t s);
+int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s);
+
 }  // namespace mpnhip

@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -298,6 +298,15 @@ static int pack_chain_weights(const mpnhip_model& m, const Dims& d, ChainWeights
     return MPNHIP_OK;
 }
 
+static int pack_chain_bf16_weights(const mpnhip_model& m, const Dims& d, ChainBf16& cb, hipStream_t s) {
+    cb.ok = cb.img && chain_bf16_ok(m, d);
+    if (!cb.ok) return MPNHIP_OK;
+    const float* f0[2] = {m.flow_out.weight[0], m.flow_in.weight[0]};
+    const float* f1[2] = {m.flow_out.weight[1], m.flow_in.weight[1]};
+    return pack_chain_bf16(m.edge.weight[0], m.edge.in_dim, 2 * d.kx, d.ef, m.edge.weight[1], m.classifier.weight[0], f0, m.flow_out.in_dim,
+                           d.kx, f1, d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], cb.img, s);
+}
+
 struct StepIO {
     // node features as one or two K segments (x0 | x) -- together kx columns
     const float* xa; int64_t ldxa; const float* xb; int64_t ldxb; int kxa;
@@ -319,7 +328,7 @@ struct StepIO {
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
 static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, const float* Wnode, const float* bnode,
                     const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s, const ChainWeights* cw = nullptr,
-                    bool save_acts = false) {
+                    bool save_acts = false, const ChainBf16* cb = nullptr) {
     const int64_t N = g.N, E = g.E;
     const int he = d.he, hn = d.hn;
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
@@ -343,7 +352,22 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
     const bool chain = cw && cw->ok && E > 0 && io.logits && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
-    if (chain) {
+    const bool chain_bf16 = !chain && cb && cb->ok && !save_acts && E > 0 && io.logits && io.eb && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
+    if (chain_bf16) {
+        // (2)-(4) fused, bf16 operands / fp32 accumulation (edge_chain_bf16.hip)
+        EdgeChainBf16Args a = {};
+        a.E = (int)E; a.N = (int)N; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm;
+        a.he = d.he; a.de = d.de; a.hn = d.hn; a.dn = d.dn; a.hc = m.classifier.out_dims[0];
+        a.xa = io.ea; a.ldxa = io.ldea; a.xb = io.eb; a.ldxb = io.ldeb;
+        a.P = b.P; a.pw = d.pw;
+        a.img_edge = cb->img; a.img_cls = cb->img + cb->off_cls; a.img_flow[0] = cb->img + cb->off_flow[0]; a.img_flow[1] = cb->img + cb->off_flow[1];
+        a.b2 = m.edge.bias[1]; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
+        a.bf2_out = m.flow_out.bias[1]; a.bf2_in = m.flow_in.bias[1];
+        a.e_new = io.e_new; a.msg = b.M; a.logits = io.logits;
+        prof_begin(PROF_GEMM, s);
+        MPN_TRY(launch_edge_chain_bf16(a, s));
+        prof_end(PROF_GEMM, s);
+    } else if (chain) {
         // (2)-(4) fused: edge MLP, classifier and both flow MLPs in one kernel (edge_chain.hip)
         EdgeChainArgs a = {};
         a.E = (int)E; a.N = (int)N; a.header = g.header; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm; a.split = cw->split ? 1 : 0;
@@ -596,12 +620,14 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     if (m.weights_prepacked && !save) {
         p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace
         p.cw.split = chain_split(m);
+        p.cb.ok = p.cb.img && chain_bf16_ok(m, d);
     } else {
         count_path(PC_WEIGHT_PACK);
         PackBatch pb;
         pack_batch_begin(&pb);   // (the fp32 images' copies / transposes are recorded and run as one launch)
         int rc = pack_node_weights(m, d, p.Wnode, p.bnode, s);
         if (rc == MPNHIP_OK) rc = pack_chain_weights(m, d, p.cw, s);
+        if (rc == MPNHIP_OK) rc = pack_chain_bf16_weights(m, d, p.cb, s);
         const int rf = pack_batch_flush(s);
         MPN_TRY(rc);
         MPN_TRY(rf);
@@ -674,7 +700,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.p_ready = fuse_node && step > 0 ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
-        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0));
+        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb));
         prev = cur;
     }
     if (d.L == 0 && E > 0) {
@@ -874,7 +900,7 @@ extern "C" int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_b
 extern "C" int mpnhip_edge_chain_active(const mpnhip_model* model) {
     Dims d;
     if (!model || check_full(*model, &d, false) != MPNHIP_OK) return 0;
-    return chain_shapes_ok(*model, d) ? 1 : 0;
+    return chain_shapes_ok(*model, d) ? 1 : (chain_bf16_ok(*model, d) ? 2 : 0);
 }
 
 extern "C" int mpnhip_profile_enable(int on) {

@@ -119,10 +119,18 @@ struct ChainWeights {
     bool split;       // the images are three-piece bf16 split images (edge_chain.hip), 3/2 the size, same logical layout
 };
 
+// pair images of the bf16-operand chain kernel (edge_chain_bf16.hip)
+struct ChainBf16 {
+    char* img;        // [edge | classifier | flow_out | flow_in]
+    size_t off_cls, off_flow[2];
+    bool ok;          // the model's shapes are covered and mpnhip_model.precision == MPNHIP_PREC_BF16
+};
+
 struct FwdPlan {
     float* Wnode;  // [pw, kx]
     float* bnode;  // [pw]
     ChainWeights cw;
+    ChainBf16 cb;
     float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
     float* Q0;     // [E, he] step-invariant share of the edge MLP's first layer: e0 W1[:, e0 columns]^T (fused chain only)
     float* enc_n[2];
@@ -185,6 +193,14 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
         }
         p.cw.ok = false;
     }
+    {
+        const int hc = m.classifier.n_layers >= 1 ? m.classifier.out_dims[0] : 0;
+        p.cb = {};
+        if (edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, hc, d.ef)) {
+            const size_t bytes = chain_bf16_image_bytes(d.he, d.de, d.hn, d.dn, hc, d.ef, &p.cb.off_cls, &p.cb.off_flow[0], &p.cb.off_flow[1]);
+            p.cb.img = reinterpret_cast<char*>(a.f(bytes / 4));
+        }
+    }
     p.P0 = a.f((size_t)N * d.pw);
     p.Q0 = a.f((size_t)E * d.he);
     int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
@@ -241,6 +257,13 @@ static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
     if (m.precision == MPNHIP_PREC_BF16) return false;  // the fused chain kernels compute fp32 results (FP32 / FP32_SPLIT)
     return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
            edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
+}
+
+// the bf16-operand chain kernel (edge_chain_bf16.hip) covers this model's per-edge modules
+static inline bool chain_bf16_ok(const mpnhip_model& m, const Dims& d) {
+    if (getenv("MPNHIP_NO_CHAIN") || getenv("MPNHIP_NO_CHAIN_BF16")) return false;
+    return m.precision == MPNHIP_PREC_BF16 && m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 &&
+           m.classifier.out_dims[1] == 1 && edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.ef);
 }
 
 // split (three-piece bf16) weight images and six-product MFMAs in the fused chain kernels: mpnhip_model.precision ==

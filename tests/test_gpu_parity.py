@@ -400,6 +400,38 @@ def test_bf16_operand_mode_matches_bf16_oracle(d, N, E, L, agg):
     assert rel_err(got, want) < rel_err(fp32, want)
 
 
+@pytest.mark.parametrize("d,L,agg", [(256, 2, "sum"), (128, 3, "mean"), (64, 3, "max"), (32, 4, "sum")])
+def test_bf16_fused_chain_runs_and_agrees_with_the_unfused_products(d, L, agg, monkeypatch):
+    """The bf16-operand chain kernel (edge_chain_bf16.hip: N-tiled hidden layers, 256 edges per block) on a batch of sub-graphs
+    with self loops, interleaved direction halves and ragged 32- / 256-edge tiles: it must be the path taken (counter), agree
+    with the bf16 oracle, and agree with the unfused bf16 GEMM path (MPNHIP_NO_CHAIN_BF16=1) far below the oracle tolerance --
+    both round the same operands; only the fp32 summation order differs."""
+    gs = [synth.make_graph(n, e, T=6, seed=40 + i, node_in_dim=48) for i, (n, e) in enumerate([(70, 1500), (45, 302), (33, 150)])]
+    g = synth.batch_graphs(gs)
+    ei = g["edge_index"].copy()
+    ei[:, 5] = [9, 9]
+    ei[:, 700] = [100, 100]
+    g["edge_index"] = ei
+    params = synth.model_params(d, L, agg, node_in_dim=48)
+    W = synth.make_weights(params, seed=5, gain=0.7)
+    model = make_model(params, W)
+    model.gemm_precision = 'bf16'
+    capi.path_counters(reset=True)
+    got, xg, eg = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    counts = capi.path_counters(reset=True)
+    assert counts["edge_chain_fwd_bf16"] == L, counts
+    want, xw, ew = _oracle_logits(params, W, g, "bf16")
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < 2e-2 and rel_err(xg, xw) < 2e-2 and rel_err(eg, ew) < 2e-2
+    monkeypatch.setenv("MPNHIP_NO_CHAIN_BF16", "1")
+    model.invalidate_packed_weights()
+    ref, xr, er = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    counts = capi.path_counters(reset=True)
+    assert counts["edge_chain_fwd_bf16"] == 0 and counts["gemm_bf16"] > 0, counts
+    print("fused vs unfused bf16: logits %.2e, x %.2e, e %.2e" % (rel_err(got, ref), rel_err(xg, xr), rel_err(eg, er)))
+    assert rel_err(got, ref) < 5e-3 and rel_err(xg, xr) < 5e-3 and rel_err(eg, er) < 5e-3
+
+
 def test_bf16_mode_refuses_training():
     g = synth.make_graph(60, 400, seed=3, node_in_dim=64)
     params = synth.model_params(32, 2, "sum", node_in_dim=64)
@@ -422,7 +454,9 @@ def test_cfgE_bf16_size_properties():
     params = synth.model_params(c["d"], 2, "mean")
     model = make_model(params, synth.make_weights(params, seed=7))
     model.gemm_precision = 'bf16'
+    capi.path_counters(reset=True)
     a, xa, _ = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert capi.path_counters()["edge_chain_fwd_bf16"] == 2
     assert np.isfinite(a).all() and np.isfinite(xa).all()
     p = np.argsort(synth.uniform01(8, c["E"]), kind="stable")
     b, xb, _ = run_hot(model, g["x"], g["edge_index"][:, p], g["edge_attr"][p])

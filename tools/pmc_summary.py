@@ -16,6 +16,7 @@ import sys
 KEYS = {  # json key -> substring of the kernel name (+ optional grid filter)
     "gemm_edge_l1": "gemm_kernel<4, 1, 5, 0>",
     "edge_chain": "edge_chain_kernel",
+    "edge_chain_bf16": "edge_chain_bf16_kernel",
     "edge_chain_bwd": "edge_chain_bwd_kernel",
     "k_aggregate": "k_aggregate",
     "gemm_tn": "gemm_tn_kernel",
