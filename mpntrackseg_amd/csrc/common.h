@@ -122,6 +122,8 @@ struct TnArgs {
     int tiles, ny8;        // filled by launch_gemm_tn: output tiles, row chunks x batches padded to a multiple of 8 (XCD mapping)
 };
 void tn_plan(TnArgs& a);
+// pitch of a slab image's rows: k_in weight columns + the bias column, padded to whole 16-byte columns
+__host__ __device__ static inline int tn_kpad(int k_in) { return (k_in + 4) & ~3; }
 size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);
 int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 

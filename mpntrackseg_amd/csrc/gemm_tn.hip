@@ -3,7 +3,7 @@
 // i.e. a GEMM whose reduction runs over the EDGES (or nodes): tens of thousands of rows against a
 // small [n_out, k_in] output.  Parallelism comes from splitting the row range: grid.y enumerates row
 // chunks, every block reduces its chunk with fp32 MFMAs (v_mfma_f32_32x32x2_f32) into a private slab
-// [n_out][k_in + 4] (column k_in carries the bias partial), and a second kernel sums the slabs in a
+// [n_out][tn_kpad(k_in)] (column k_in carries the bias partial), and a second kernel sums the slabs in a
 // fixed order into the caller's gradient buffers -- deterministic, no float atomics.
 //
 // Both operands are read exactly as stored (row-major, rows = reduction index), 16 bytes per lane,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(TnArgs args) {
         __syncthreads();
     }
     // ---- write the partial tile into this chunk's slab --------------------------------------------
-    const int kpad = k_in + 4;
+    const int kpad = tn_kpad(k_in);
     float* slab = TN_GG(grp, slab) + (size_t)by * n_out * kpad;
 #pragma unroll
     for (int tj = 0; tj < TW; ++tj) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     tot += __shfl_xor(tot, 1, 64);
     tot += __shfl_xor(tot, 2, 64);
     tot += __shfl_xor(tot, 4, 64);
-    if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * (args.k_in + 4) + c] = tot;
+    if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * tn_kpad(args.k_in) + c] = tot;
 }
 
 // Narrow outputs (n_out <= 32, k_in <= 32: the reference's 18-wide edge encoder, the [1 x hc] classifier output layer): the
@@ -284,19 +284,20 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(TnArgs args) {
         }
         __syncthreads();
     }
-    float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * (k_in + 4);
+    float* slab = TN_G(slab) + (size_t)blockIdx.y * n_out * tn_kpad(k_in);
 #pragma unroll
     for (int q = 0; q < 5; ++q)
-        if (threadIdx.x + 256 * q < nout_total) slab[(size_t)oo[q] * (k_in + 4) + cc[q]] = acc[q];
+        if (threadIdx.x + 256 * q < nout_total) slab[(size_t)oo[q] * tn_kpad(k_in) + cc[q]] = acc[q];
 }
 
 // grad_w[o * ldw + c] += sum_s slab[s][o][c];  grad_b[o] += sum_s slab[s][o][k_in]  over the non-empty chunks.
 // Block = 32 x 16-byte columns of the padded slab image x 8 slab groups: a wave reads 512 contiguous bytes of one
 // slab, four slabs in flight per lane; the eight groups' partial sums meet in LDS in a fixed order (deterministic).
-// Needs k_in % 4 == 0 (then the slab pitch k_in + 4 is a multiple of 4 floats); otherwise the scalar kernel below.
+// The slab pitch (tn_kpad: k_in + 1 columns padded to whole 16-byte columns) is a multiple of 4 floats for every k_in; pad
+// columns hold whatever the buffer held and are summed but never stored.  The scalar kernel below serves unaligned slab bases.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
     __shared__ float4 part[8][32];
-    const int kpad = args.k_in + 4;
+    const int kpad = tn_kpad(args.k_in);
     const int64_t total4 = (int64_t)args.n_out * kpad / 4;
     const int64_t q = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
     const int grp = threadIdx.x >> 5;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(TnArgs args) {
 
 // scalar variant (k_in % 4 != 0): 8 lanes share one output element
 __global__ __launch_bounds__(256) void slab_reduce_scalar_kernel(TnArgs args) {
-    const int kpad = args.k_in + 4;
+    const int kpad = tn_kpad(args.k_in);
     const int64_t total = (int64_t)args.n_out * (args.k_in + 1);
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int l = threadIdx.x & 7;
@@ -403,7 +404,7 @@ size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch) {
     a.m_upper = m_upper;
     a.nbatch = nbatch;
     tn_plan(a);
-    return (size_t)a.nbatch * a.nsplit * n_out * (k_in + 4);
+    return (size_t)a.nbatch * a.nsplit * n_out * tn_kpad(k_in);
 }
 
 void tn_plan(TnArgs& a) {
@@ -418,10 +419,16 @@ void tn_plan(TnArgs& a) {
     const int blocks_wanted = blocks_env ? blocks_env : (a.m_upper * a.nbatch >= 100000 ? 1024 : 1536);
     int target = blocks_wanted / (tiles > 0 ? tiles : 1);
     if (target < 1) target = 1;
-    if (target > 128) target = 128;
+    // narrow outputs (the reference's 18-wide edge encoder, the classifier's output layer): one block per 64-row staging round.
+    // A block's rounds are serial and each is two dependent global-load latencies long (row index -> row), so 128 blocks x 10
+    // rounds took 45-52 us per product at cfg-C's 77.8k edges; the slabs stay small (n_out (k_in + 4) floats each)
+    const bool narrow = a.n_out <= 32 && a.k_in <= 32;
+    const int cap = narrow ? 2048 : 128;
+    if (target > cap) target = cap;
     int64_t chunk = (a.m_upper + target - 1) / target;
     chunk = (chunk + TBK - 1) / TBK * TBK;
-    if (chunk < 128) chunk = 128;
+    const int min_chunk = narrow ? 64 : 128;
+    if (chunk < min_chunk) chunk = min_chunk;
     a.chunk = (int)chunk;
     a.nsplit = (int)((a.m_upper + chunk - 1) / chunk);
     if (a.nsplit < 1) a.nsplit = 1;
@@ -467,10 +474,10 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
                            dim3(256), 0, s, a);
     }
     MPN_LAUNCH_CHECK();
-    bool slab16 = a.k_in % 4 == 0;
+    bool slab16 = true;   // (the slab pitch tn_kpad is a multiple of 4 floats for every k_in)
     for (int i = 0; i < a.ngroups; ++i) slab16 = slab16 && al16t(a.g[i].slab);
     if (slab16) {
-        const int64_t total4 = (int64_t)a.n_out * (a.k_in + 4) / 4;
+        const int64_t total4 = (int64_t)a.n_out * tn_kpad(a.k_in) / 4;
         const unsigned bx = (unsigned)((total4 + 31) / 32);
         const int nslab_upper = a.nsplit * a.nbatch;
         a.red_ny = 1;
