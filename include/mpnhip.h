@@ -36,12 +36,16 @@ extern "C" {
 /* FP32_SPLIT: fp32 results from bf16 matrix instructions.  In the fused per-edge chain kernels (forward and backward) every
  * fp32 operand is taken as the exact sum of three bfloat16 pieces (x = h + m + l, each the RNE rounding of the remainder)
  * and a product is accumulated in fp32 from the six piece products whose weight is at least 2^-16 of the leading one; the
- * three dropped products are below 2^-24 |a b|, i.e. below fp32 rounding.  Nothing is rounded to bf16: the error against
- * float64 is that of the FP32 mode (tests/test_gpu_split.py measures both), at 3/8 of the fp32 MFMA's cycles.  The
- * larger K-contiguous GEMMs (node projections, encoders) use the same six products; the remaining products (small GEMMs,
- * weight gradients) stay fp32 MFMAs.  Forward and backward.  Operands must be finite and below 3.3e38 in magnitude: an
- * infinite operand gives NaN (inf - inf in the split) where the FP32 mode gives +-inf; pieces below the bf16 normal range
- * (|x| < 1e-33) may be flushed. */
+ * three dropped products are below 2^-26 |a b|.  Nothing is rounded to bf16: measured against float64 the logits' error is the
+ * FP32 mode's (3 ... 7e-7 relative at cfg-B, 12 steps) and every gradient's is too (decision-pinned comparison, tests/
+ * test_gpu_pinned.py: <= 5e-6, the FP32 mode's bound), at 3/8 of the fp32 MFMA's cycles.  One hardware property is handled in the
+ * backward kernel: v_mfma_f32_32x32x16_bf16 adds its products to the accumulator with a small bias toward -infinity (mean error
+ * -0.06 ... -0.11 of the rms error of a six-product result; tools/micro/mfma_bias.hip), which the backward's sums over edges
+ * and steps would add up coherently -- the kernel keeps the gradients of every other edge negated in its registers, so the
+ * bias cancels in every sum.  (The forward keeps it: a common offset of ~4e-7 of the logits' scale.)  The larger K-contiguous
+ * GEMMs (node projections, encoders) use the same six products; the remaining products (small GEMMs, weight gradients) stay
+ * fp32 MFMAs.  Forward and backward.  Operands must be finite and below 3.3e38 in magnitude: an infinite operand gives NaN
+ * (inf - inf in the split) where the FP32 mode gives +-inf; pieces below the bf16 normal range (|x| < 1e-33) may be flushed. */
 #define MPNHIP_PREC_FP32_SPLIT 2
 
 #define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
@@ -123,6 +127,16 @@ const char* mpnhip_debug_counter_name(int index);
 int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_buf, int n_nodes, int64_t n_edges, const void* fwd_workspace,
                        size_t fwd_workspace_bytes, int what, int step, int layer, float* out, int64_t* rows, int* width,
                        void* stream);
+/* The same for mpnhip_backward: one [rows, width] block of the pre-activation gradients it keeps per step in its workspace
+ * (for the batched weight-gradient products), in the order it is stored (edges: sorted order).  step = 1 .. num_enc_steps. */
+#define MPNHIP_BWD_SAVED_DZ_NODE 0 /* [N, dn]   gradient of the node update's pre-activation */
+#define MPNHIP_BWD_SAVED_DP 1      /* [N, pw]   gradient of the per-node projections */
+#define MPNHIP_BWD_SAVED_DZ_FLOW 2 /* layer i of the flow MLPs (last layer: the masked message gradient) */
+#define MPNHIP_BWD_SAVED_DZ_EDGE 3 /* layer i of the edge MLP */
+#define MPNHIP_BWD_SAVED_DZ_CLS 4  /* hidden layer i of the classifier */
+int mpnhip_debug_backward_saved(const mpnhip_model* model, int n_nodes, int64_t n_edges, const void* bwd_workspace,
+                                size_t bwd_workspace_bytes, int what, int step, int layer, float* out, int64_t* rows,
+                                int* width, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph preparation -- replaces the six boolean-mask indexings per step of

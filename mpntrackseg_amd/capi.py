@@ -56,6 +56,7 @@ SIGNATURES = {
     "mpnhip_debug_counters": (_I, [C.POINTER(C.c_int64), _I, _I]),
     "mpnhip_debug_counter_name": (C.c_char_p, [_I]),
     "mpnhip_debug_saved": (_I, [C.POINTER(Model), _P, _I, _L, _P, _Z, _I, _I, _I, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int), _P]),
+    "mpnhip_debug_backward_saved": (_I, [C.POINTER(Model), _I, _L, _P, _Z, _I, _I, _I, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int), _P]),
     "mpnhip_graph_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep_workspace_bytes": (_Z, [_I, _L]),
     "mpnhip_graph_prep": (_I, [_P, _I, _L, _P, _Z, _P, _Z, _P]),
@@ -158,6 +159,24 @@ def saved_activation(model, graph, fwd_ws, what, step=0, layer=0):
         out = torch.empty((rows.value, width.value), dtype=torch.float32, device=graph.device)
         check(lib.mpnhip_debug_saved(m, ptr(graph.buf), graph.N, graph.E, ptr(fwd_ws), fwd_ws.numel(), SAVED[what], int(step), int(layer),
                                      ptr(out), C.byref(rows), C.byref(width), stream_ptr()), "mpnhip_debug_saved")
+    return out
+
+
+BWD_SAVED = {"dz_node": 0, "dp": 1, "dz_flow": 2, "dz_edge": 3, "dz_cls": 4}
+
+
+def backward_saved(model, graph, bwd_ws, what, step, layer=0):
+    """One block of pre-activation gradients ``mpnhip_backward`` left in its workspace (``mpnhip_debug_backward_saved``);
+    edges in sorted order.  Test / diagnosis instrumentation."""
+    lib = load()
+    m = model.c_model([])
+    rows, width = C.c_int64(0), C.c_int(0)
+    with torch.cuda.device(graph.device):
+        check(lib.mpnhip_debug_backward_saved(m, graph.N, graph.E, ptr(bwd_ws), bwd_ws.numel(), BWD_SAVED[what], int(step), int(layer), None,
+                                              C.byref(rows), C.byref(width), stream_ptr()), "mpnhip_debug_backward_saved")
+        out = torch.empty((rows.value, width.value), dtype=torch.float32, device=graph.device)
+        check(lib.mpnhip_debug_backward_saved(m, graph.N, graph.E, ptr(bwd_ws), bwd_ws.numel(), BWD_SAVED[what], int(step), int(layer), ptr(out),
+                                              C.byref(rows), C.byref(width), stream_ptr()), "mpnhip_debug_backward_saved")
     return out
 
 

@@ -1048,3 +1048,49 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     }
     return MPNHIP_OK;
 }
+
+// Test / diagnosis instrumentation: one block of pre-activation gradients mpnhip_backward left in its workspace (sorted edge
+// order / node order as stored; include/mpnhip.h).
+extern "C" int mpnhip_debug_backward_saved(const mpnhip_model* model, int n_nodes, int64_t n_edges, const void* bwd_workspace,
+                                           size_t bwd_workspace_bytes, int what, int step, int layer, float* out, int64_t* rows_out,
+                                           int* width_out, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(model && bwd_workspace, "debug_backward_saved: null argument");
+    const mpnhip_model& m = *model;
+    Dims d;
+    MPN_TRY(check_full(m, &d));
+    const int64_t N = n_nodes, E = n_edges;
+    BwdPlan p;
+    const size_t need = plan_backward(m, d, N, E, const_cast<void*>(bwd_workspace), &p);
+    if (bwd_workspace_bytes < need) {
+        set_error("debug_backward_saved: workspace %zu < %zu", bwd_workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    MPN_CHECK_ARG(step >= 1 && step <= (d.L > 0 ? d.L : 1), "debug_backward_saved: step %d", step);
+    const size_t b = (size_t)(step - 1);
+    const float* src = nullptr;
+    int64_t rows = 0;
+    int width = 0;
+    switch (what) {
+        case MPNHIP_BWD_SAVED_DZ_NODE: src = p.dZn + b * N * d.dn; rows = N; width = d.dn; break;
+        case MPNHIP_BWD_SAVED_DP: src = p.dP + b * N * d.pw; rows = N; width = d.pw; break;
+        case MPNHIP_BWD_SAVED_DZ_FLOW:
+            if (layer >= 0 && layer < m.flow_in.n_layers) { width = m.flow_in.out_dims[layer]; src = p.dZfl[layer] + b * E * width; rows = E; }
+            break;
+        case MPNHIP_BWD_SAVED_DZ_EDGE:
+            if (layer >= 0 && layer < m.edge.n_layers) { width = m.edge.out_dims[layer]; src = p.dZed[layer] + b * E * width; rows = E; }
+            break;
+        case MPNHIP_BWD_SAVED_DZ_CLS:
+            if (layer >= 0 && layer + 1 < m.classifier.n_layers) { width = m.classifier.out_dims[layer]; src = p.dZcl[layer] + b * E * width; rows = E; }
+            break;
+        default: break;
+    }
+    if (!src) {
+        set_error("debug_backward_saved: nothing kept for what = %d, step = %d, layer = %d", what, step, layer);
+        return MPNHIP_ERR_ARG;
+    }
+    if (rows_out) *rows_out = rows;
+    if (width_out) *width_out = width;
+    if (out && rows > 0) MPN_HIP(hipMemcpyAsync(out, src, (size_t)rows * width * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return MPNHIP_OK;
+}

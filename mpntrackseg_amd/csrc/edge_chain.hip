@@ -130,6 +130,14 @@ __device__ __forceinline__ void add4(f32x16& a, int g, float4 v) {
 __device__ __forceinline__ float4 get4(const f32x16& a, int g) {
     return make_float4(a[4 * g + 0], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
 }
+// sign flips by XOR (sx = 0x80000000 or 0): the split backward kernel keeps the gradients of every other edge NEGATED in its
+// registers (see edge_chain_bwd_kernel)
+__device__ __forceinline__ float fxor(float x, unsigned sx) { return __uint_as_float(__float_as_uint(x) ^ sx); }
+__device__ __forceinline__ float4 flip4(float4 v, unsigned sx) { return make_float4(fxor(v.x, sx), fxor(v.y, sx), fxor(v.z, sx), fxor(v.w, sx)); }
+__device__ __forceinline__ void flip16(f32x16& a, unsigned sx) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float x = a[r]; a[r] = fxor(x, sx); }
+}
 
 // ReLU masks travel from the forward to the backward chain kernel as bits: bit r of a tile's 16-bit mask = accumulator
 // register r of that lane is > 0.  Both kernels map (block, wave, lane) to the same edge and feature rows, so the
@@ -738,6 +746,15 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     const bool edge_ok = edge_raw < end;
     const int edge = edge_ok ? edge_raw : end - 1;
     const bool flow = grp < 2;
+    // Split operands: v_mfma_f32_32x32x16_bf16 adds its products to the accumulator with a small bias toward -infinity
+    // (tools/micro/mfma_bias.hip: mean error -0.06 ... -0.11 of the rms error of a six-product fp32 result, the fp32 MFMA
+    // +-0.002; negating an operand and the result flips it).  Unbiased rounding noise averages out in the sums the backward
+    // takes over edges and steps (bias and weight gradients, segment sums); a bias adds up coherently and is amplified by the
+    // step recursion: measured 5e-5 on the cfg-B parameter gradients after 12 steps against 1e-6 in the fp32 mode.  The chain is
+    // LINEAR in the gradients (the ReLU masks are bits), so the kernel keeps the gradients of every other edge negated in its
+    // registers -- inputs are negated as they are loaded, outputs as they are stored -- and the bias enters neighbouring edges
+    // with opposite signs: zero mean over any sum.
+    const unsigned sx = SP && (lj & 1) ? 0x80000000u : 0u;
     const int KEp = A.cat_two ? 2 * DE : DE;  // padded columns of [e0 | e_{s-1}] (each half padded to DE)
     const int npass6 = KEp / 64 > 0 ? KEp / 64 : 1;
     const int ncol6 = KEp < 64 ? KEp : 64;    // columns per B6 pass
@@ -818,6 +835,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
                 apply_mask(dzm[t], mk[W_M + (t >> 1)], 16 * (t & 1));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, dn, get4(dzm[t], g), edge_ok);
+                if (SP) flip16(dzm[t], sx);
             }
         }
         TS(2);
@@ -847,11 +865,15 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             for (int t = 0; t < TF; ++t) {
                 apply_mask(dzf[t], mk[W_HF + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, hn, get4(dzf[t], g), edge_ok);
+                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, hn, flip4(get4(dzf[t], g), sx), edge_ok);
             }
         }
         TS(4);
         // ---- B3: dE' += Wfe^T dZF -------------------------------------------------------------------------------
+        if (SP) {
+#pragma unroll
+            for (int t = 0; t < T2; ++t) flip16(dE[t], sx);   // (the incoming gradient joins the registers' sign convention)
+        }
 #pragma unroll
         for (int i = 0; i < NCH3; ++i) {
             const bool more = i + 1 < NCH3;
@@ -875,17 +897,22 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     TS(5);
     // ---- B4: classifier: dZc = (dlog wc2) (.) [HC > 0];  dE' += Wc1^T dZc ----------------------------------------
     {
+        if (SP && !flow) {
+#pragma unroll
+            for (int t = 0; t < T2; ++t) flip16(dE[t], sx);
+        }
         f32x16 dzc;
+        const float dls = fxor(dl, sx);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 w = *reinterpret_cast<const float4*>(swc2 + 8 * g + 4 * lh);
-            set4(dzc, g, make_float4(dl * w.x, dl * w.y, dl * w.z, dl * w.w));
+            set4(dzc, g, make_float4(dls * w.x, dls * w.y, dls * w.z, dls * w.w));
         }
         apply_mask(dzc, mk[W_HC], 0);
         {
             float* o2 = A.dZc + (int64_t)edge * hc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 8 * g + 4 * lh, hc, get4(dzc, g), edge_ok);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 8 * g + 4 * lh, hc, flip4(get4(dzc, g), sx), edge_ok);
         }
         chunk_fetch<chunk_q(N4_5), SP>(A.w2, N4_5, tid, wbuf_at(c + 1));
         if constexpr (SP) chain_units<T2, 2>(dzc, 0, dE, lds_addr(wbuf_at(c)) + lane * 16, T2, 0, 0);
@@ -900,7 +927,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         for (int t = 0; t < T2; ++t) {
             apply_mask(dE[t], mk[W_E + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, de, get4(dE[t], g), edge_ok);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, de, flip4(get4(dE[t], g), sx), edge_ok);
         }
     }
 
@@ -938,7 +965,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         for (int t = 0; t < T1; ++t) {
             apply_mask(dz1[t], mk[W_H1 + (t >> 1)], 16 * (t & 1));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, he, get4(dz1[t], g), edge_ok);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, he, flip4(get4(dz1[t], g), sx), edge_ok);
         }
     }
 
@@ -965,7 +992,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             for (int g = 0; g < 4; ++g) {
                 const int n = 8 * g + 4 * lh;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live[t] && to_e0 && !second_of_same) v = ldrow<EXACT>(dst[t], n, de - 32 * tin);
+                if (live[t] && to_e0 && !second_of_same) v = flip4(ldrow<EXACT>(dst[t], n, de - 32 * tin), sx);
                 set4(dc[t], g, v);
             }
         }
@@ -1015,7 +1042,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             if (!live[t]) break;
             const int tin = (pass * 2 + t) % T2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(dst[t], 8 * g + 4 * lh, de - 32 * tin, get4(dc[t], g), edge_ok);
+            for (int g = 0; g < 4; ++g) strow<EXACT>(dst[t], 8 * g + 4 * lh, de - 32 * tin, flip4(get4(dc[t], g), sx), edge_ok);
         }
     }
     TS(9);

@@ -57,9 +57,34 @@ int main() {
     for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = (i & 1 ? -1.f : 1.f) * 0.3125f * u; }
     b[0] = 0.8125f * u;
     show("c=+1.5, mixed signs, sum +0.5+0.3125 ulp", a, b, 1.5f);
-    // a large product beside small ones, c = 0: are the small ones kept relative to the LARGE product?
-    for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = 0.1875f * u; }
-    b[0] = 1.5f;
-    show("c=0 -> measured against 1.5: 1.5 + 15 x 0.1875 ulp", a, b, 0.f);
+    // many small products: is each aligned to the accumulator (and cut) on its own, or is their sum formed first?
+    for (int n : {2, 3, 4, 8, 16}) {
+        for (float sgn : {1.f, -1.f}) {
+            for (float cc : {1.5f, -1.5f}) {
+                memset(a, 0, 64); memset(b, 0, 64);
+                for (int i = 0; i < n; ++i) { a[i] = 1.f; b[i] = sgn * 0.1875f * u; }
+                char w[96];
+                snprintf(w, sizeof w, "c=%+.1f, %2d products of %+.4f ulp at k=0..", cc, n, sgn * 0.1875);
+                show(w, a, b, cc);
+            }
+        }
+    }
+    for (float x : {0.3125f, 0.4375f, 0.0625f}) {
+        memset(a, 0, 64); memset(b, 0, 64);
+        for (int i = 0; i < 16; i += 2) { a[i] = 1.f; b[i] = x * u; }
+        char w[96];
+        snprintf(w, sizeof w, "c=+1.5, 8 products of %+.4f ulp at even k", x);
+        show(w, a, b, 1.5f);
+        for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = -x * u; }
+        snprintf(w, sizeof w, "c=+1.5, 16 products of %+.4f ulp", -x);
+        show(w, a, b, 1.5f);
+    }
+    // products far below the accumulator's ulp individually, large in number x value: 2^-4 ulp each
+    for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = 0.0625f * u; }
+    show("c=+1.5, 16 products of +1/16 ulp (sum 1 ulp)", a, b, 1.5f);
+    for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = -0.0625f * u; }
+    show("c=+1.5, 16 products of -1/16 ulp (sum -1 ulp)", a, b, 1.5f);
+    for (int i = 0; i < 16; ++i) { a[i] = 1.f; b[i] = 0.0625f * u; }
+    show("c=-1.5, 16 products of +1/16 ulp (sum 1 ulp)", a, b, -1.5f);
     return 0;
 }
