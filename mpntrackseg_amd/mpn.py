@@ -396,14 +396,31 @@ class MOTMPNet(nn.Module):
         # operand precision of the Linear products (include/mpnhip.h MPNHIP_PREC_*): 'fp32' (fp32 MFMAs), 'fp32_split'
         # (fp32 results from three-piece bf16 operands in the fused chain kernels: same accuracy, fewer MFMA cycles) or
         # 'bf16' (inference only: operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs" mode)
-        prec = getattr(self, 'gemm_precision', 'fp32')
-        if prec not in capi.PRECISIONS:
-            raise capi.MpnhipError("gemm_precision must be one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
-        m.precision = capi.PRECISIONS[prec]
+        m.precision = capi.PRECISIONS[self.operand_precision()]
         m.enc_node = self.encoder.node_model.c_struct(keep, grads)
         m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
         m.classifier = self.classifier.edge_model.c_struct(keep, grads)
         return m
+
+    # Operand precision of the Linear products: 'auto' (default), 'fp32', 'fp32_split', 'bf16' (see c_model / include/mpnhip.h)
+    gemm_precision = 'auto'
+
+    def operand_precision(self):
+        """``gemm_precision`` with 'auto' resolved.  'auto' = 'fp32_split' where the fused chain kernels are bound by MFMA cycles
+        (first hidden width of the edge MLP >= 256: the 128-d class of BASELINE.json's configs[1] -- cfg-B training step 6.6 ->
+        5.75 ms, inference 2.05 -> 1.53 ms, logits and every gradient as close to a float64 oracle as with fp32 MFMAs,
+        DESIGN.md section 4b), 'fp32' (fp32 MFMAs) at the reference's widths, where those kernels are latency-bound and the
+        split images only add packing work."""
+        prec = getattr(self, 'gemm_precision', 'auto')
+        if prec == 'auto':
+            try:
+                he = int(self.MPNet.edge_model.edge_model.linears()[0].weight.shape[0])
+            except Exception:
+                he = 0
+            prec = 'fp32_split' if he >= 256 else 'fp32'
+        if prec not in capi.PRECISIONS:
+            raise capi.MpnhipError("gemm_precision must be 'auto' or one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
+        return prec
 
     @contextlib.contextmanager
     def frozen_weights(self):
@@ -494,7 +511,7 @@ class MOTMPNet(nn.Module):
         between calls inside ``frozen_weights()``), and the model crosses as the cached (spec, weights) pair."""
         c = getattr(self, '_ops_cache', None)
         ptrs = tuple(p_.data_ptr() for p_ in self._hp_params())
-        prec = getattr(self, 'gemm_precision', 'fp32')
+        prec = self.operand_precision()
         folded = not all(m_.fast_path for m_ in self.modules() if isinstance(m_, MLP))   # BatchNorm: fold afresh every call
         if c is None or c[0] != ptrs or c[1] != prec or c[2] != int(self.num_enc_steps) or folded:
             spec, weights = torch_ops.model_spec(self)

@@ -55,9 +55,7 @@ def call(name, *args):
 
 def model_spec(model):
     """(spec, weights) of a MOTMPNet for the ops: see csrc/torch_ops.cpp."""
-    prec = getattr(model, 'gemm_precision', 'fp32')
-    if prec not in capi.PRECISIONS:
-        raise capi.MpnhipError("gemm_precision must be one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
+    prec = model.operand_precision()
     nm = model.MPNet.node_model
     lin = nm.node_model[0]
     spec = [int(lin.weight.shape[0]), 0, int(bool(model.reattach_initial_nodes)), int(bool(model.reattach_initial_edges)),

@@ -44,6 +44,22 @@ def test_state_dict_keys_and_shapes_match_reference():
     assert sum(v.numel() for v in sd.values()) == 296293  # hot-path parameter count
 
 
+def test_operand_precision_policy():
+    """MOTMPNet.gemm_precision: 'auto' (default) = fp32 results from three-piece bf16 operands where the chain kernels are MFMA-bound
+    (128-d class), fp32 MFMAs at the reference's widths; explicit choices pass through; anything else raises."""
+    from mpntrackseg_amd import capi
+    ref = MOTMPNet(default_params())
+    assert ref.gemm_precision == "auto" and ref.operand_precision() == "fp32"
+    wide = MOTMPNet(synth.model_params(128, 2, "sum", node_in_dim=64))
+    assert wide.operand_precision() == "fp32_split"
+    for prec in ("fp32", "fp32_split", "bf16"):
+        wide.gemm_precision = prec
+        assert wide.operand_precision() == prec
+    wide.gemm_precision = "fp16"
+    with pytest.raises(capi.MpnhipError):
+        wide.operand_precision()
+
+
 def test_attributes_like_reference():
     m = MOTMPNet(default_params())
     assert m.num_enc_steps == 4 and m.num_class_steps == 3

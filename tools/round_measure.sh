@@ -15,22 +15,26 @@ python $R/bench.py --config D --mode train --no-cpu-baseline 2>&1 | tail -1 > $O
 python $R/bench.py --config D --mode fwd --steps 300 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgD_fwd_$RND.json
 python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 2>&1 | tail -1 > $O/bench_cfgE_bf16_fwd_$RND.json
 python $R/bench.py --config E --precision fp32 --mode fwd --steps 6 --warmup 2 --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_cfgE_fp32_fwd_$RND.json
-# MPNHIP_PREC_FP32_SPLIT (opt-in): own bench lines
-python $R/bench.py --precision fp32_split --no-cpu-baseline 2>&1 | tail -1 > $O/bench_split_$RND.json
-python $R/bench.py --precision fp32_split --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_split_$RND.json
+# the default precision is 'auto' (cfg-B: MPNHIP_PREC_FP32_SPLIT, cfg-C / D: fp32 MFMAs); fp32 MFMAs everywhere: own bench lines
+python $R/bench.py --precision fp32 --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_fp32mfma_$RND.json
+python $R/bench.py --precision fp32 --mode fwd --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_fwd_fp32mfma_$RND.json
 # kernel stats of the default command and of the cfg-E line
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-split-line > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd -- python $R/bench.py --mode fwd --no-cpu-baseline --no-split-line > $O/stats_fwd.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_cfgE.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgC -- python $R/bench.py --config C --no-cpu-baseline --no-split-line > $O/stats_cfgC.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-split-line > $O/stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd -- python $R/bench.py --mode fwd --no-cpu-baseline --no-split-line > $O/stats_fwd.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_cfgE.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgC -- python $R/bench.py --config C --no-cpu-baseline --no-split-line > $O/stats_cfgC.log 2>&1
 # HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_E.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_E.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_E.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_E.log 2>&1
 cd $R
 python tools/track_bench.py 2>/dev/null | tail -1 > $O/track_bench_$RND.json
 F=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv | head -1)
+python tools/pmc_summary.py $F $W $O/pmc_summary_split.json > /dev/null
+F=$(ls $O/pmc_fetch32/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write32/*/*counter_collection.csv | head -1)
 python tools/pmc_summary.py $F $W $O/pmc_summary.json > /dev/null
 F=$(ls $O/pmc_fetch_E/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write_E/*/*counter_collection.csv | head -1)
 python tools/pmc_summary.py $F $W $O/pmc_summary_cfgE.json > /dev/null
