@@ -543,7 +543,10 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         const mpnhip_mlp* fl[2] = {&m.flow_out, &m.flow_in};
         const int ncol6 = KEp < 64 ? KEp : 64;
         if (bwd_split) {
-            // the same logical images (rows = contraction index n, columns = k) as split images (edge_chain.hip, split8)
+            // the same logical images (rows = contraction index n, columns = k) as split images (edge_chain.hip, split8);
+            // recorded and packed by one launch (pack_split cannot fail once its sizes are valid: nothing returns before the flush)
+            SplitBatch sb;
+            split_batch_begin(&sb);
             for (int q = 0; q < 2; ++q) {
                 MPN_TRY(pack_split(fl[q]->weight[1], hn, 1, dn, hn, DN, HN, p.wf2p[q], s));
                 MPN_TRY(pack_split(fl[q]->weight[0] + kx, fl[q]->in_dim, 1, hn, de, HN, DE, p.wfep[q], s));
@@ -555,6 +558,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 MPN_TRY(pack_split(m.edge.weight[0] + 2 * kx + hlf * de, m.edge.in_dim, 1, he, de, HE, DE,
                                    p.w1ep + (int64_t)(col0 / 64) * HE * ncol6 * 3 / 2, s, ncol6 / 32, (col0 % 64) / 32));
             }
+            MPN_TRY(split_batch_flush(s));
         } else {
             PackBatch pb;
             pack_batch_begin(&pb);   // (the eight images as one launch; nothing below returns before the flush)

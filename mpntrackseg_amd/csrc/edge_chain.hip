@@ -1068,24 +1068,53 @@ __global__ void k_transpose_padded(const float* __restrict__ W, int64_t ldw, int
 }
 
 // Split image (see the comment at split8): thread = one element of one unit; writes its three pieces.
-__global__ void k_pack_split(const float* __restrict__ src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np,
-                             unsigned short* __restrict__ dst, int ntr_image, int t0) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ntr = Np / 32;
-    if (idx >= (int64_t)(Kp / 16) * ntr * 512) return;
+__device__ __forceinline__ void pack_split_one(const SplitOp& o, int64_t idx) {
+    const int ntr = o.Np / 32;
+    if (idx >= (int64_t)(o.Kp / 16) * ntr * 512) return;
     const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
     const int64_t unit = idx >> 9;
     const int t = (int)(unit % ntr), kb = (int)(unit / ntr);
     const int k = 16 * kb + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), n = 32 * t + (lane & 31);
-    const float x = (k < K && n < N) ? src[k * sk + n * sn] : 0.f;
+    const float x = (k < o.K && n < o.N) ? o.src[k * o.sk + n * o.sn] : 0.f;
     const __bf16 h = (__bf16)x;
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)m);
-    unsigned short* o = dst + ((int64_t)kb * ntr_image + t0 + t) * 3 * 512 + lane * 8 + i;
-    o[0] = __builtin_bit_cast(unsigned short, h);
-    o[512] = __builtin_bit_cast(unsigned short, m);
-    o[1024] = __builtin_bit_cast(unsigned short, l);
+    unsigned short* q = o.dst + ((int64_t)kb * o.ntr_image + o.t0 + t) * 3 * 512 + lane * 8 + i;
+    q[0] = __builtin_bit_cast(unsigned short, h);
+    q[512] = __builtin_bit_cast(unsigned short, m);
+    q[1024] = __builtin_bit_cast(unsigned short, l);
+}
+__global__ void k_pack_split(SplitOp o) { pack_split_one(o, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+// blockIdx.y = op (static indices into the by-value table: a dynamic one would move it to scratch memory)
+__global__ __launch_bounds__(256) void k_pack_split_multi(SplitBatch b) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    switch (blockIdx.y) {
+#define MPN_SPLIT_CASE(k) case k: pack_split_one(b.op[k], i); break;
+        MPN_SPLIT_CASE(0) MPN_SPLIT_CASE(1) MPN_SPLIT_CASE(2) MPN_SPLIT_CASE(3) MPN_SPLIT_CASE(4) MPN_SPLIT_CASE(5) MPN_SPLIT_CASE(6) MPN_SPLIT_CASE(7)
+        MPN_SPLIT_CASE(8) MPN_SPLIT_CASE(9) MPN_SPLIT_CASE(10) MPN_SPLIT_CASE(11) MPN_SPLIT_CASE(12) MPN_SPLIT_CASE(13) MPN_SPLIT_CASE(14) MPN_SPLIT_CASE(15)
+#undef MPN_SPLIT_CASE
+        default: break;
+    }
+}
+
+static thread_local SplitBatch* g_split_batch = nullptr;
+void split_batch_begin(SplitBatch* b) {
+    b->n = 0;
+    g_split_batch = getenv("MPNHIP_NO_PACK_BATCH") ? nullptr : b;
+}
+int split_batch_flush(hipStream_t s) {
+    SplitBatch* b = g_split_batch;
+    g_split_batch = nullptr;
+    if (!b || b->n == 0) return MPNHIP_OK;
+    int64_t mx = 0;
+    for (int i = 0; i < b->n; ++i) {
+        const int64_t n = (int64_t)(b->op[i].Kp / 16) * (b->op[i].Np / 32) * 512;
+        mx = n > mx ? n : mx;
+    }
+    hipLaunchKernelGGL(k_pack_split_multi, dim3((unsigned)((mx + 255) / 256), b->n), dim3(256), 0, s, *b);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
 }
 
 int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, int Np, float* dst, hipStream_t s, int ntr_image, int t0) {
@@ -1093,8 +1122,12 @@ int pack_split(const float* src, int64_t sk, int64_t sn, int K, int N, int Kp, i
     const int64_t n = (int64_t)(Kp / 16) * (Np / 32) * 512;
     if (n <= 0) return MPNHIP_OK;
     if (Kp % 16 != 0 || Np % 32 != 0) { set_error("pack_split: padded sizes must be multiples of 16 x 32"); return MPNHIP_ERR_ARG; }
-    hipLaunchKernelGGL(k_pack_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sk, sn, K, N, Kp, Np,
-                       reinterpret_cast<unsigned short*>(dst), ntr_image, t0);
+    const SplitOp o = {src, sk, sn, K, N, Kp, Np, reinterpret_cast<unsigned short*>(dst), ntr_image, t0};
+    if (g_split_batch && g_split_batch->n < SplitBatch::MAX) {
+        g_split_batch->op[g_split_batch->n++] = o;
+        return MPNHIP_OK;
+    }
+    hipLaunchKernelGGL(k_pack_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -624,13 +624,17 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     } else {
         count_path(PC_WEIGHT_PACK);
         PackBatch pb;
-        pack_batch_begin(&pb);   // (the fp32 images' copies / transposes are recorded and run as one launch)
+        SplitBatch sb;
+        pack_batch_begin(&pb);   // (the fp32 images' copies / transposes are recorded and run as one launch,
+        split_batch_begin(&sb);  //  the split images as another)
         int rc = pack_node_weights(m, d, p.Wnode, p.bnode, s);
         if (rc == MPNHIP_OK) rc = pack_chain_weights(m, d, p.cw, s);
         if (rc == MPNHIP_OK) rc = pack_chain_bf16_weights(m, d, p.cb, s);
         const int rf = pack_batch_flush(s);
+        const int rs = split_batch_flush(s);
         MPN_TRY(rc);
         MPN_TRY(rf);
+        MPN_TRY(rs);
     }
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
