@@ -166,8 +166,8 @@ def main():
         raise SystemExit("--precision bf16 is an inference mode")
     model.gemm_precision = args.precision
     # 'auto' (the library's default, MOTMPNet.operand_precision): fp32 results from three-piece bf16 operands where the fused chain
-    # kernels are MFMA-bound (cfg-B / cfg-E widths), fp32 MFMAs at the reference's widths (cfg-C / cfg-D)
-    args.precision = model.operand_precision()
+    # kernels have the MFMA work for it (cfg-B / cfg-E widths; the reference's widths from ~32k edges: cfg-C), fp32 MFMAs on small graphs (cfg-D)
+    args.precision = model.operand_precision(E)
     if mode == "train" and not have_bwd:
         raise SystemExit("--mode train needs mpnhip_backward")
 
@@ -273,7 +273,7 @@ def main():
 
     if prof is not None:
         keep = []
-        chain = int(lib.mpnhip_edge_chain_active(model.c_model(keep)))   # 1: fp32 / split chain kernels, 2: bf16-operand chain
+        chain = int(lib.mpnhip_edge_chain_active(model.c_model(keep, n_edges=E)))   # 1: fp32 / split chain kernels, 2: bf16-operand chain
         out.update(rooflines(prof, c, args, N, E, chain, mode))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, W, g, mode == "train")

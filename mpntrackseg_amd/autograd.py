@@ -21,8 +21,8 @@ def native_forward_saved(model, g, x, ea, logits):
     """mpnhip_forward(save_for_backward=1) into a private workspace; returns that workspace."""
     lib = capi.load()
     keep = []
-    m = model.c_model(keep)
     N, E = x.shape[0], ea.shape[0]
+    m = model.c_model(keep, n_edges=E)
     with torch.cuda.device(x.device):
         ws = torch.empty(max(lib.mpnhip_forward_workspace_bytes(m, N, E, 1), 256), dtype=torch.uint8, device=x.device)
         capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits), None, None,
@@ -35,8 +35,8 @@ def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, 
     ``defer_side_join``: MPNHIP_BWD_DEFER_SIDE_JOIN (include/mpnhip.h) -- the caller joins the side stream itself."""
     lib = capi.load()
     keep = []
-    m = model.c_model(keep, grads=grads)
     N, E = x.shape[0], ea.shape[0]
+    m = model.c_model(keep, grads=grads, n_edges=E)
     gx = torch.empty_like(x) if need_gx else None
     gea = torch.empty_like(ea) if need_gea else None
     gl = capi.f32c(grad_logits)
@@ -57,7 +57,7 @@ class _HotPath(torch.autograd.Function):
         ctx.via_ops = torch_ops.available()
         if ctx.via_ops:
             # through the dispatcher (csrc/torch_ops.cpp): the same C-ABI calls, outputs allocated by the op
-            ctx.spec, _ = torch_ops.model_spec(model)
+            ctx.spec, _ = torch_ops.model_spec(model, n_edges=ead.shape[0])
             with torch.cuda.device(xd.device):
                 logits, ctx.fwd_ws = torch_ops.call("forward", g.buf, xd, ead, [p.detach() for p in params], ctx.spec, 1, None, False)
         else:

@@ -386,7 +386,7 @@ class MOTMPNet(nn.Module):
             out += [l.weight, l.bias]
         return out
 
-    def c_model(self, keep, grads=None):
+    def c_model(self, keep, grads=None, n_edges=None):
         if self.encoder.node_model is None or self.encoder.edge_model is None or self.classifier.edge_model is None:
             raise capi.MpnhipError("MOTMPNet needs node and edge encoders and an edge classifier")
         m = self.MPNet.core_struct(keep, grads=grads)
@@ -396,7 +396,7 @@ class MOTMPNet(nn.Module):
         # operand precision of the Linear products (include/mpnhip.h MPNHIP_PREC_*): 'fp32' (fp32 MFMAs), 'fp32_split'
         # (fp32 results from three-piece bf16 operands in the fused chain kernels: same accuracy, fewer MFMA cycles) or
         # 'bf16' (inference only: operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs" mode)
-        m.precision = capi.PRECISIONS[self.operand_precision()]
+        m.precision = capi.PRECISIONS[self.operand_precision(n_edges)]
         m.enc_node = self.encoder.node_model.c_struct(keep, grads)
         m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
         m.classifier = self.classifier.edge_model.c_struct(keep, grads)
@@ -405,19 +405,26 @@ class MOTMPNet(nn.Module):
     # Operand precision of the Linear products: 'auto' (default), 'fp32', 'fp32_split', 'bf16' (see c_model / include/mpnhip.h)
     gemm_precision = 'auto'
 
-    def operand_precision(self):
-        """``gemm_precision`` with 'auto' resolved.  'auto' = 'fp32_split' where the fused chain kernels are bound by MFMA cycles
-        (first hidden width of the edge MLP >= 256: the 128-d class of BASELINE.json's configs[1] -- cfg-B training step 6.6 ->
-        5.75 ms, inference 2.05 -> 1.53 ms, logits and every gradient as close to a float64 oracle as with fp32 MFMAs,
-        DESIGN.md section 4b), 'fp32' (fp32 MFMAs) at the reference's widths, where those kernels are latency-bound and the
-        split images only add packing work."""
+    AUTO_SPLIT_MIN_HIDDEN = 256     # first hidden width of the edge MLP from which 'auto' means 'fp32_split' whatever the graph
+    AUTO_SPLIT_MIN_EDGES = 32768    # ... and the graph size from which it does at narrower widths
+
+    def operand_precision(self, n_edges=None):
+        """``gemm_precision`` with 'auto' resolved for a graph of ``n_edges`` edges (None: unknown).  'auto' = 'fp32_split' where
+        the fused chain kernels have enough MFMA work for the cheaper matrix instruction to show -- the 128-d class of BASELINE.json's
+        configs[1] at any size (cfg-B training step 6.6 -> 5.7 ms, inference 2.05 -> 1.53 ms), the reference's 32-d widths from
+        ~32k edges (cfg-C stand-in, 77.8k edges: 2.15 -> 2.07 ms / 0.47 -> 0.43 ms) -- and 'fp32' (fp32 MFMAs) on small graphs at
+        narrow widths, where a launch is one wave per SIMD and the operand splitting sits on its critical path (cfg-D stand-in
+        forward, 14.4k edges: 0.112 ms against 0.143).  Logits and every gradient are as close to a float64 oracle in one mode as
+        in the other.  The forward and the backward of one call see the same edge count, hence one mode."""
         prec = getattr(self, 'gemm_precision', 'auto')
         if prec == 'auto':
             try:
                 he = int(self.MPNet.edge_model.edge_model.linears()[0].weight.shape[0])
             except Exception:
                 he = 0
-            prec = 'fp32_split' if he >= 256 else 'fp32'
+            wide = he >= self.AUTO_SPLIT_MIN_HIDDEN
+            big = n_edges is not None and int(n_edges) >= self.AUTO_SPLIT_MIN_EDGES
+            prec = 'fp32_split' if (wide or big) else 'fp32'
         if prec not in capi.PRECISIONS:
             raise capi.MpnhipError("gemm_precision must be 'auto' or one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
         return prec
@@ -476,10 +483,10 @@ class MOTMPNet(nn.Module):
             return self._hot_path_ops(x, edge_index, edge_attr, holder, validate, torch_ops)
         lib = capi.load()
         keep = []
-        m = self.c_model(keep)
         x = capi.f32c(x)
         ea = capi.f32c(edge_attr)
         N, E = x.shape[0], ea.shape[0]
+        m = self.c_model(keep, n_edges=E)
         g = _prepared(edge_index, N, holder, full=False)   # inference: the primary order is all mpnhip_forward reads
         check_hot_path_inputs(m, g, x, ea)
         L = max(int(self.num_enc_steps), 1)
@@ -511,10 +518,10 @@ class MOTMPNet(nn.Module):
         between calls inside ``frozen_weights()``), and the model crosses as the cached (spec, weights) pair."""
         c = getattr(self, '_ops_cache', None)
         ptrs = tuple(p_.data_ptr() for p_ in self._hp_params())
-        prec = self.operand_precision()
+        prec = self.operand_precision(edge_attr.shape[0])
         folded = not all(m_.fast_path for m_ in self.modules() if isinstance(m_, MLP))   # BatchNorm: fold afresh every call
         if c is None or c[0] != ptrs or c[1] != prec or c[2] != int(self.num_enc_steps) or folded:
-            spec, weights = torch_ops.model_spec(self)
+            spec, weights = torch_ops.model_spec(self, n_edges=edge_attr.shape[0])
             c = self._ops_cache = (ptrs, prec, int(self.num_enc_steps), spec, weights, spec[8], spec[9 + spec[7] + 1])
         spec, weights = c[3], c[4]
         x = capi.f32c(x)

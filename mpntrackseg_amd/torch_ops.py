@@ -53,9 +53,9 @@ def call(name, *args):
         raise capi.MpnhipError(str(exc).split("\n")[0]) from None
 
 
-def model_spec(model):
-    """(spec, weights) of a MOTMPNet for the ops: see csrc/torch_ops.cpp."""
-    prec = model.operand_precision()
+def model_spec(model, n_edges=None):
+    """(spec, weights) of a MOTMPNet for the ops: see csrc/torch_ops.cpp.  ``n_edges``: the graph the spec is for ('auto' precision)."""
+    prec = model.operand_precision(n_edges)
     nm = model.MPNet.node_model
     lin = nm.node_model[0]
     spec = [int(lin.weight.shape[0]), 0, int(bool(model.reattach_initial_nodes)), int(bool(model.reattach_initial_edges)),

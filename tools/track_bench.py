@@ -50,14 +50,18 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = tracker.evaluate_graph_in_batches(*args, windows_per_launch=wpl, **kw)
         torch.cuda.synchronize(); res[wpl] = time.perf_counter() - t0
-    # the same with the fused chain kernels in MPNHIP_PREC_FP32_SPLIT
-    model.gemm_precision = "fp32_split"
-    tracker.evaluate_graph_in_batches(*args, windows_per_launch=8, **kw)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out_split = tracker.evaluate_graph_in_batches(*args, windows_per_launch=8, **kw)
-    torch.cuda.synchronize(); res["split8"] = time.perf_counter() - t0
-    model.gemm_precision = "fp32"
-    split_dev = float((out_split - out).abs().max())
+    # (the runs above are in the default 'auto' precision: per launch, by its edge count -- MOTMPNet.operand_precision)
+    # the same, eight windows per launch, pinned to each fp32 mode
+    outs = {}
+    for prec in ("fp32", "fp32_split"):
+        model.gemm_precision = prec
+        tracker.evaluate_graph_in_batches(*args, windows_per_launch=8, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        outs[prec] = tracker.evaluate_graph_in_batches(*args, windows_per_launch=8, **kw)
+        torch.cuda.synchronize(); res[prec] = time.perf_counter() - t0
+    model.gemm_precision = "auto"
+    res["split8"] = res["fp32_split"]
+    split_dev = float((outs["fp32_split"] - outs["fp32"]).abs().max())
     # CPU oracle: the first few windows only (bounded sample), same weights
     Wt = O.to_tensors(W)
     def fwd(xs, ei, ea):
@@ -78,7 +82,7 @@ def main():
         "construct_graph_ms": {"mi355x": 1e3 * t_build, "cpu_oracle": 1e3 * t_build_cpu},
         "sliding_window_s": {"windows_per_launch_1": res[1], "windows_per_launch_8": res[8]},
         "windows_per_s": {"windows_per_launch_1": nwin / res[1], "windows_per_launch_8": nwin / res[8],
-                          "windows_per_launch_8_fp32_split": nwin / res["split8"], "fp32_split_max_abs_dev_of_probabilities": split_dev,
+                          "windows_per_launch_8_fp32_split": nwin / res["split8"], "windows_per_launch_8_fp32_mfma": nwin / res["fp32"], "fp32_split_max_abs_dev_of_probabilities": split_dev,
                           "cpu_oracle": n_cpu_win / t_cpu, "cpu_threads": torch.get_num_threads(), "cpu_sample_windows": n_cpu_win},
         "max_pred": float(out.max())}))
 
