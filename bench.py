@@ -367,12 +367,14 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         flops = 2.0 * E * macs
         # what the kernel must move at least -- both first-layer inputs and both outputs once, the
         # per-node projection table once, the edge indices, the logits
-        alg_bytes = E * (2 * de * 4 + de * 4 + dn * 4 + 12 + 4) + N * (2 * he + 2 * hn) * 4
+        # (the kernel aggregates the messages itself -- they never reach HBM -- unless MPNHIP_NO_AGG_FUSION is set: then M is written)
+        fused_agg = not os.environ.get("MPNHIP_NO_AGG_FUSION")
+        alg_bytes = E * (2 * de * 4 + de * 4 + 12 + 4) + N * (2 * he + 2 * hn) * 4 + (N * 2 * dn * 4 if fused_agg else E * dn * 4)
         ach = alg_bytes / (gemm_us * 1e-6) / 1e9
         traffic = pmc_traffic("edge_chain_bf16", args.config, args.precision)
         res["roofline"] = {"bound": "hbm",
                            "kernel": "edge_chain_bf16_kernel<20,4,14,8,2>: fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
-                                     "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers; bound by the per-edge "
+                                     "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers, node_agg_fn in the kernel; bound by the per-edge "
                                      "gathers of the projection table (%d B per edge from a %d MB table, uniformly random columns)"
                                      % ((2 * he + hn) * 4, N * (2 * he + 2 * hn) * 4 // 1000000),
                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,

@@ -137,7 +137,17 @@ struct EdgeChainBf16Args {
     float* e_new;             // [E, de]  sorted edge order
     float* msg;               // [E, dn]
     float* logits;            // [E] ORIGINAL order (through perm)
+    // fused aggregation (agg_out != nullptr: msg is not written): the kernel sums / averages / maximises the messages of every
+    // (direction, row) segment itself -- whole segments into agg_out [N, 2 dn] = [flow_in | flow_out] (zero-initialised by the
+    // caller: empty segments), pieces of segments that cross wave tiles into `piece`, added up by k_agg_fixup
+    const int* seg_ptr;       // graph CSR over keys dir * N + row
+    float* agg_out;
+    float* piece;             // chain_bf16_agg_scratch_floats()
+    int* start_row;
+    int agg;                  // MPNHIP_AGG_*
 };
+// floats of the fused aggregation's scratch: piece [tiles][2][pad32(dn)] followed by start_row [tiles] (ints)
+size_t chain_bf16_agg_scratch_floats(int64_t E, int dn, size_t* off_start_row);
 bool edge_chain_bf16_supported(int he, int de, int hn, int dn, int hc, int ef);
 // bytes of the four pair images (edge | classifier | flow_out | flow_in) and the offsets of the last three
 size_t chain_bf16_image_bytes(int he, int de, int hn, int dn, int hc, int ef, size_t* off_cls, size_t* off_flow0, size_t* off_flow1);

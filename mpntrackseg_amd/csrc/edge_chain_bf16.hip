@@ -160,8 +160,11 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
     constexpr int NCH1 = (T1 + CT - 1) / CT, NCHF = (TF + CT - 1) / CT;
     constexpr int CHU = bmax(bmax(CT * SEC1, CT * SECF), TC * SECC);   // KiB per chunk buffer
     // one LDS object: two chunk buffers, then the biases [b2 (DE) | bc1 (HC) | wc2 (HC) | bf2 (DN)], zero-padded
-    __shared__ __attribute__((aligned(16))) char smem[2 * CHU * 1024 + (DE + 2 * HC + DN) * 4];
-    float* const sbias = reinterpret_cast<float*>(smem + 2 * CHU * 1024);
+    // (the fused aggregation's per-wave slabs reuse the chunk buffers after the last chunk: 8 x [32 edges][32 RT + 1] floats)
+    constexpr int AGG_RT = TD >= 2 ? 2 : 1, AGG_BYTES = 8 * (32 * AGG_RT) * 36 * 4;
+    constexpr int WB_BYTES = bmax(2 * CHU * 1024, (AGG_BYTES + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(16))) char smem[WB_BYTES + (DE + 2 * HC + DN) * 4];
+    float* const sbias = reinterpret_cast<float*>(smem + WB_BYTES);
 #define WBUF(i) (smem + ((i) & 1) * (CHU * 1024))
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
             ++c;
         }
     }
-    {
+    if (!A.agg_out) {
         const unsigned mo = (unsigned)edge * (unsigned)dn;
 #pragma unroll
         for (int o = 0; o < TD; ++o) {
@@ -362,8 +365,112 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
                 strow<EXACT>(A.msg, mo, 32 * o + 8 * g + 4 * lh, dn, v, edge_ok);
             }
         }
+    } else {
+        // ---- aggregation in the kernel (node_agg_fn, mpn.py:89,96): the messages never reach HBM --------------------------------
+        // The edges of a (direction, row) segment are consecutive, so a wave's 32 edges are a few whole segments plus at most
+        // one that began in an earlier wave tile and one that goes on into the next.  Per round of RT M tiles the wave
+        // transposes them through its own LDS slab ([edge][feature], the chunk buffers are free now), then lane = feature walks
+        // the 32 edges IN ORDER (the walk's control flow is wave-uniform: tail bits from a ballot) and emits at every segment
+        // end: whole segments straight into agg_out, the partial pieces into piece[tile][0 | 1] (0: the segment began earlier,
+        // 1: it begins here and goes on), which k_agg_fixup adds up in tile order -- deterministic, no float atomics.
+        // slab layout [feature][edge], 36 floats per feature row: the writes of one accumulator register are two runs of 32
+        // consecutive floats, the walk reads a lane's row with eight conflict-free ds_read_b128
+        constexpr int RT = AGG_RT, FR = 32 * RT, LP = 36, ROUNDS = TD / RT;
+        static_assert(TD % RT == 0 && 8 * FR * LP * 4 <= WB_BYTES, "aggregation slabs do not fit the chunk buffers");
+        __syncthreads();   // every wave has consumed the last weight chunk
+        float* const wl = reinterpret_cast<float*>(smem) + wave * (FR * LP);
+        const int wt = blockIdx.x * 8 + wave;
+        const int tile_first = tile0 + wave * 32;
+        const int key = grp * A.N + row;
+        const int s0 = A.seg_ptr[key], s1 = A.seg_ptr[key + 1];
+        const bool tail = edge_ok && (lj == 31 || edge_raw + 1 >= s1);
+        const bool starts_here = s0 >= tile_first, ends_here = s1 <= tile_first + 32;
+        const unsigned tailm = (unsigned)__ballot(tail);                       // (lanes 32..63 repeat lanes 0..31)
+        const unsigned directm = (unsigned)__ballot(starts_here && ends_here);
+        const unsigned slot1m = (unsigned)__ballot(starts_here && !ends_here);
+        const int cnt = s1 - s0;
+        const int doff = grp == 0 ? dn : 0;       // torch.cat((flow_in, flow_out)) (mpn.py:97)
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) {
+#pragma unroll
+            for (int tt = 0; tt < RT; ++tt) {
+                const int t = RT * q + tt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int fo = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = fmaxf(mm[t][r] + sbias[DE + 2 * HC + 32 * t + fo], 0.f);
+                    wl[(32 * tt + fo) * LP + lj] = edge_ok ? v : 0.f;
+                }
+            }
+            const int f = FR * q + lane;
+            const bool fok = lane < FR && f < dn;
+            float acc = 0.f;
+            float4 rowv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const float4*>(wl + (lane < FR ? lane : 0) * LP + 4 * k);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float4 q4 = rowv[j >> 2];
+                const float v = (j & 3) == 0 ? q4.x : ((j & 3) == 1 ? q4.y : ((j & 3) == 2 ? q4.z : q4.w));
+                acc = A.agg == MPNHIP_AGG_MAX ? fmaxf(acc, v) : acc + v;   // (messages are post-ReLU: 0 is the identity of max too)
+                if ((tailm >> j) & 1) {
+                    const int rj = __builtin_amdgcn_readlane(row, j);
+                    if ((directm >> j) & 1) {
+                        float o = acc;
+                        if (A.agg == MPNHIP_AGG_MEAN) { const int cj = __builtin_amdgcn_readlane(cnt, j); o /= (float)(cj > 0 ? cj : 1); }
+                        if (fok) A.agg_out[(int64_t)rj * 2 * dn + doff + f] = o;
+                    } else if (fok) {
+                        A.piece[((int64_t)wt * 2 + ((slot1m >> j) & 1)) * DN + f] = acc;
+                    }
+                    acc = 0.f;
+                }
+            }
+        }
+        // the segment that begins in this tile and goes on (necessarily the tile's last): where k_agg_fixup starts
+        if (lane == 0) {
+            int r1 = -1;
+            if (tailm) {
+                const int jl = 31 - __builtin_clz(tailm);
+                if ((slot1m >> jl) & 1) r1 = __builtin_amdgcn_readlane(row, jl);
+            }
+            A.start_row[wt] = r1;
+        }
     }
 #undef WBUF
+}
+
+// Adds up the pieces of the segments that cross wave tiles (edge_chain_bf16_kernel's fused aggregation): block = the tile in
+// which such a segment BEGINS; it walks the following tiles' continuation pieces in order until the segment ends.
+__global__ __launch_bounds__(64) void k_agg_fixup(const int* __restrict__ header, const int* __restrict__ seg_ptr,
+                                                  const int* __restrict__ start_row, const float* __restrict__ piece,
+                                                  float* __restrict__ agg_out, int N, int dn, int DN, int agg) {
+    const int wt = blockIdx.x, blk = wt >> 3, wave = wt & 7;
+    const int e_out = header[1], e_in = header[2];
+    const int nb0 = (e_out + 255) >> 8, nb1 = (e_in + 255) >> 8;
+    int grp, beg, end, bl;
+    if (blk < nb0) { grp = 0; beg = 0; end = e_out; bl = blk; }
+    else if (blk < nb0 + nb1) { grp = 1; beg = e_out; end = e_out + e_in; bl = blk - nb0; }
+    else return;
+    const int first = beg + bl * 256 + wave * 32;
+    if (first >= end) return;
+    const int r = start_row[wt];
+    if (r < 0) return;
+    const int key = grp * N + r;
+    const int s0 = seg_ptr[key], s1 = seg_ptr[key + 1];
+    const int doff = grp == 0 ? dn : 0;
+    for (int f = threadIdx.x; f < dn; f += 64) {
+        float acc = piece[((int64_t)wt * 2 + 1) * DN + f];
+        int u = wt + 1, fe = first + 32;
+        while (true) {
+            const float v = piece[((int64_t)u * 2) * DN + f];
+            acc = agg == MPNHIP_AGG_MAX ? fmaxf(acc, v) : acc + v;
+            if (s1 <= fe + 32) break;
+            fe += 32;
+            ++u;
+        }
+        if (agg == MPNHIP_AGG_MEAN) acc /= (float)(s1 - s0);
+        agg_out[(int64_t)r * 2 * dn + doff + f] = acc;
+    }
 }
 
 // ---- pair images -------------------------------------------------------------------------------------------------------
@@ -470,7 +577,18 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s) {
         default: set_error("edge_chain_bf16: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
     MPN_LAUNCH_CHECK();
+    if (a.agg_out) {
+        hipLaunchKernelGGL(k_agg_fixup, dim3(blocks * 8), dim3(64), 0, s, a.header, a.seg_ptr, a.start_row, a.piece, a.agg_out, a.N, a.dn,
+                           (a.dn + 31) / 32 * 32, a.agg);
+        MPN_LAUNCH_CHECK();
+    }
     return MPNHIP_OK;
+}
+
+size_t chain_bf16_agg_scratch_floats(int64_t E, int dn, size_t* off_start_row) {
+    const size_t tiles = (size_t)((E + 255) / 256 + 3) * 8, DN = (size_t)(dn + 31) / 32 * 32;
+    if (off_start_row) *off_start_row = tiles * 2 * DN;
+    return tiles * 2 * DN + tiles;
 }
 
 }  // namespace mpnhip

@@ -352,6 +352,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         MPN_TRY(launch_gemm(a, A_KCONTIG, B_KCONTIG, s));
     }
     const bool chain = cw && cw->ok && E > 0 && io.logits && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
+    bool agg_done = false;   // the chain kernel aggregated the messages itself
     const bool chain_bf16 = !chain && cb && cb->ok && !save_acts && E > 0 && io.logits && io.eb && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
     if (chain_bf16) {
         // (2)-(4) fused, bf16 operands / fp32 accumulation (edge_chain_bf16.hip)
@@ -364,6 +365,12 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         a.b2 = m.edge.bias[1]; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
         a.bf2_out = m.flow_out.bias[1]; a.bf2_in = m.flow_in.bias[1];
         a.e_new = io.e_new; a.msg = b.M; a.logits = io.logits;
+        // the aggregation of the messages inside the kernel (they never reach HBM); MPNHIP_NO_AGG_FUSION=1: k_aggregate as before
+        agg_done = cb->piece && !io.fuse_node && !getenv("MPNHIP_NO_AGG_FUSION");
+        if (agg_done) {
+            a.seg_ptr = g.seg_ptr; a.agg_out = b.AGG; a.piece = cb->piece; a.start_row = cb->start_row; a.agg = m.agg;
+            MPN_HIP(hipMemsetAsync(b.AGG, 0, (size_t)N * 2 * d.dn * sizeof(float), s));   // (empty segments)
+        }
         prof_begin(PROF_GEMM, s);
         MPN_TRY(launch_edge_chain_bf16(a, s));
         prof_end(PROF_GEMM, s);
@@ -455,9 +462,11 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
                             io.P0, io.last ? nullptr : io.P_next, d.pw, s));
         return MPNHIP_OK;
     }
-    prof_begin(PROF_AGG, s);
-    MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
-    prof_end(PROF_AGG, s);
+    if (!agg_done) {
+        prof_begin(PROF_AGG, s);
+        MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
+        prof_end(PROF_AGG, s);
+    }
     MPN_TRY(linear(b.AGG, 2 * d.dn, m.node.weight[0], m.node.bias[0], io.x_new, d.dn, N, d.dn, 2 * d.dn, 1, s));
     return MPNHIP_OK;
 }

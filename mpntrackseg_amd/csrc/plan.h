@@ -124,6 +124,8 @@ struct ChainBf16 {
     char* img;        // [edge | classifier | flow_out | flow_in]
     size_t off_cls, off_flow[2];
     bool ok;          // the model's shapes are covered and mpnhip_model.precision == MPNHIP_PREC_BF16
+    float* piece;     // scratch of the kernel's fused aggregation (depends on E: carved at the END of the plan)
+    int* start_row;
 };
 
 struct FwdPlan {
@@ -193,10 +195,12 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
         }
         p.cw.ok = false;
     }
+    bool cb_shapes = false;   // (not p.cb.img: the sizing pass runs without a base pointer)
     {
         const int hc = m.classifier.n_layers >= 1 ? m.classifier.out_dims[0] : 0;
         p.cb = {};
-        if (edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, hc, d.ef)) {
+        cb_shapes = edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, hc, d.ef);
+        if (cb_shapes) {
             const size_t bytes = chain_bf16_image_bytes(d.he, d.de, d.hn, d.dn, hc, d.ef, &p.cb.off_cls, &p.cb.off_flow[0], &p.cb.off_flow[1]);
             p.cb.img = reinterpret_cast<char*>(a.f(bytes / 4));
         }
@@ -233,6 +237,12 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
         }
         p.splitk_floats = sk;
         p.splitk = sk ? a.f(sk) : nullptr;
+    }
+    if (cb_shapes && !save) {
+        size_t off = 0;
+        const size_t fl = chain_bf16_agg_scratch_floats(E, d.dn, &off);
+        p.cb.piece = a.f(fl);
+        p.cb.start_row = p.cb.piece ? reinterpret_cast<int*>(p.cb.piece + off) : nullptr;
     }
     p.total = a.off;
     if (out) *out = p;
