@@ -258,3 +258,53 @@ def test_backward_is_bitwise_reproducible():
         assert np.array_equal(lg, runs[0][0]) and np.array_equal(gx, runs[0][1]) and np.array_equal(gea, runs[0][2])
         for k in pg:
             assert np.array_equal(pg[k], runs[0][3][k]), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
+def test_kept_dz_blocks_add_up_to_the_bias_gradients(precision):
+    """mpnhip_debug_backward_saved (the per-step pre-activation gradients mpnhip_backward keeps for the batched weight-gradient
+    products): the bias gradient of a layer is the sum of its dZ over rows and steps -- checked for the edge MLP, the flow MLPs
+    (the two directions share the blocks: edges sorted by direction group), the classifier's hidden layer and the node update."""
+    from mpntrackseg_amd.autograd import native_backward, native_forward_saved
+    c = synth.CONFIGS["A"]
+    L = 3
+    g = synth.make_graph(c["N"], c["E"], seed=4)
+    params = synth.model_params(128, L, "sum", node_in_dim=64)
+    g["x"] = synth.normal(9, (c["N"], 64))
+    model = make_model(params, synth.make_weights(params, seed=7, gain=0.7))
+    model.gemm_precision = precision
+    x = torch.from_numpy(g["x"]).to(dev())
+    ea = torch.from_numpy(g["edge_attr"]).to(dev())
+    ei = torch.from_numpy(g["edge_index"]).to(dev())
+    N, E = x.shape[0], ea.shape[0]
+    pg = capi.PreparedGraph(ei, N, validate=True)
+    logits = torch.empty((L, E), dtype=torch.float32, device=dev())
+    ws = native_forward_saved(model, pg, x, ea, logits)
+    prm = model.hot_path_parameters()
+    grads = {id(p): torch.zeros_like(p) for p in prm}
+    r = torch.from_numpy(synth.normal(11, (L, E))).to(dev())
+    native_backward(model, pg, x, ea, r, ws, grads)
+    torch.cuda.synchronize()
+    lib = capi.load()
+    bws = capi.workspace(lib.mpnhip_backward_workspace_bytes(model.c_model([], n_edges=E), N, E), dev(), "bwd")
+    names = {k: grads[id(p)].double().cpu().numpy() for k, p in model.named_parameters() if id(p) in grads}
+
+    def col_sums(what, layer):
+        return sum(capi.backward_saved(model, pg, bws, what, s, layer).double().sum(0).cpu().numpy() for s in range(1, L + 1))
+
+    checks = [("MPNet.edge_model.edge_model.fc_layers.0.bias", col_sums("dz_edge", 0)),
+              ("MPNet.edge_model.edge_model.fc_layers.2.bias", col_sums("dz_edge", 1)),
+              ("classifier.edge_model.fc_layers.0.bias", col_sums("dz_cls", 0)),
+              ("MPNet.node_model.node_model.0.bias", col_sums("dz_node", 0))]
+    for name, want in checks:
+        got = names[name]
+        assert nerr(got, want) < 2e-5, (name, nerr(got, want))
+    # flow MLPs: flow_out's rows are the first E_out sorted edges, flow_in's the next E_in
+    hdr = pg.buf[:8 * 4].view(torch.int32).cpu().numpy()
+    e_out, e_in = int(hdr[1]), int(hdr[2])
+    for layer, key in ((0, "fc_layers.0.bias"), (1, "fc_layers.2.bias")):
+        blocks = [capi.backward_saved(model, pg, bws, "dz_flow", s, layer).double().cpu().numpy() for s in range(1, L + 1)]
+        out_sum = sum(b[:e_out].sum(0) for b in blocks)
+        in_sum = sum(b[e_out:e_out + e_in].sum(0) for b in blocks)
+        assert nerr(names["MPNet.node_model.flow_out_model." + key], out_sum) < 2e-5
+        assert nerr(names["MPNet.node_model.flow_in_model." + key], in_sum) < 2e-5
