@@ -128,8 +128,11 @@ size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);
 int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 
 // few rows, long K (node encoder at the reference's graph sizes): split-K into `scratch`, then a fixed-order sum (gemm.hip)
+// `next` (optional): the Linear layer that follows ([next->n x n] weights, output next->y): evaluated in the summing launch when it is
+// narrow enough (next->done is set); otherwise untouched
+struct SplitkNext { const float* w; const float* b; int n; int relu; float* y; int64_t ldy; bool done; };
 bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k, int relu,
-                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status);
+                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status, SplitkNext* next = nullptr);
 size_t linear_splitk_scratch_floats(int64_t m, int n, int k);
 // Convenience: y = act(x W^T + b)
 int linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k,

@@ -642,21 +642,74 @@ __global__ __launch_bounds__(256) void k_gemm_splitk(const float* __restrict__ x
     }
 }
 
+// (four partial sums over the chunks z = 0, 1, 2, 3 (mod 4), combined as (s0 + s1) + (s2 + s3): a fixed order, and four loads in
+// flight per thread instead of a serial chain -- at 140 x 128 outputs the kernel is pure latency)
+__device__ __forceinline__ float splitk_total(const float* __restrict__ part, int64_t mn, int S, int64_t i) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < S; z += 4) {
+        s0 += part[(int64_t)z * mn + i];
+        s1 += part[(int64_t)(z + 1) * mn + i];
+        s2 += part[(int64_t)(z + 2) * mn + i];
+        s3 += part[(int64_t)(z + 3) * mn + i];
+    }
+    if (z < S) s0 += part[(int64_t)z * mn + i];
+    if (z + 1 < S) s1 += part[(int64_t)(z + 1) * mn + i];
+    if (z + 2 < S) s2 += part[(int64_t)(z + 2) * mn + i];
+    return (s0 + s1) + (s2 + s3);
+}
+
 __global__ void k_splitk_sum(const float* __restrict__ part, int64_t mn, int S, const float* __restrict__ bias, int N, int relu,
                              float* __restrict__ y, int64_t ldy) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= mn) return;
-    float s = part[i];
-    for (int z = 1; z < S; ++z) s += part[(int64_t)z * mn + i];
+    float s = splitk_total(part, mn, S, i);
     const int n = (int)(i % N);
     if (bias) s += bias[n];
     if (relu) s = fmaxf(s, 0.f);
     y[(i / N) * ldy + n] = s;
 }
 
+// The same followed by the NEXT (last, narrow) Linear layer of the MLP: block = one row; its n1 <= 256 summed activations go to
+// y1 (the backward's saved activation) and, through LDS, into y2[row] = act(W2 h + b2) -- the reference's node encoder
+// (2048 -> 128 -> 32) on a few hundred nodes: two launches instead of three, and no 8 us GEMM launch for a 140 x 32 output.
+__global__ __launch_bounds__(256) void k_splitk_sum_l2(const float* __restrict__ part, int64_t mn, int S, const float* __restrict__ b1,
+                                                      int n1, int relu1, float* __restrict__ y1, int64_t ldy1,
+                                                      const float* __restrict__ W2, const float* __restrict__ b2, int n2, int relu2,
+                                                      float* __restrict__ y2, int64_t ldy2) {
+    __shared__ __attribute__((aligned(16))) float h[256];
+    const int row = blockIdx.x, t = threadIdx.x;
+    if (t < n1) {
+        float s = splitk_total(part, mn, S, (int64_t)row * n1 + t);
+        if (b1) s += b1[t];
+        if (relu1) s = fmaxf(s, 0.f);
+        h[t] = s;
+        y1[(int64_t)row * ldy1 + t] = s;
+    }
+    __syncthreads();
+    // four lanes per output (k = q, q + 4, ... in float4 steps of 16), reduced by two shuffles: fixed order
+    const int o = t >> 2, q = t & 3;
+    float acc = 0.f;
+    if (o < n2) {
+        const float* w = W2 + (int64_t)o * n1;
+        for (int k = 4 * q; k + 3 < n1; k += 16) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + k);
+            const float4 hv = *reinterpret_cast<const float4*>(h + k);
+            acc = fmaf(wv.x, hv.x, acc); acc = fmaf(wv.y, hv.y, acc); acc = fmaf(wv.z, hv.z, acc); acc = fmaf(wv.w, hv.w, acc);
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (o < n2 && q == 0) {
+        if (b2) acc += b2[o];
+        if (relu2) acc = fmaxf(acc, 0.f);
+        y2[(int64_t)row * ldy2 + o] = acc;
+    }
+}
+
 // true (and launched) when the shape calls for it and the scratch suffices; false: the caller takes the tiled kernel
 bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k, int relu,
-                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status) {
+                   float* scratch, size_t scratch_floats, hipStream_t stream, int* status, SplitkNext* next) {
     *status = MPNHIP_OK;
     if (g_precision != 0 || getenv("MPNHIP_NO_SPLITK")) return false;
     const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
@@ -670,7 +723,14 @@ bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, 
     count_path(PC_GEMM_SPLITK);
     hipLaunchKernelGGL(k_gemm_splitk, dim3((n + 63) / 64, (unsigned)((m + 63) / 64), S), dim3(256), 0, stream, x, ldx, w, (int)m, n, k, kc, scratch);
     const int64_t mn = m * n;
-    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, mn, S, b, n, relu, y, ldy);
+    if (next && next->w && n % 4 == 0 && n <= 256 && ldy == n && next->n >= 1 && next->n <= 64 && ((uintptr_t)next->w & 15) == 0) {
+        // ... and the following (last, narrow) layer in the same launch
+        hipLaunchKernelGGL(k_splitk_sum_l2, dim3((unsigned)m), dim3(256), 0, stream, scratch, mn, S, b, n, relu, y, ldy, next->w, next->b,
+                           next->n, next->relu, next->y, next->ldy);
+        next->done = true;
+    } else {
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, mn, S, b, n, relu, y, ldy);
+    }
     if (hipGetLastError() != hipSuccess) { set_error("split-K linear: launch failed"); *status = MPNHIP_ERR_HIP; }
     return true;
 }

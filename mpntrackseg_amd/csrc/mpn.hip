@@ -307,6 +307,29 @@ static int pack_chain_bf16_weights(const mpnhip_model& m, const Dims& d, ChainBf
                            d.kx, f1, d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], cb.img, s);
 }
 
+// Reference widths, few nodes: the hoisted projections P0 = x0 Wnode[:, :dn]^T + bnode AND the first step's P = P0 + x0 Wnode[:, dn:]^T
+// (x_0 IS the re-attached x0 there) in one launch, one thread per output -- two 5 us GEMM launches for 140 x 272 outputs otherwise.
+__global__ __launch_bounds__(256) void k_proj_hoist32(const float* __restrict__ x0, const float* __restrict__ Wnode,
+                                                     const float* __restrict__ bnode, float* __restrict__ P0, float* __restrict__ P,
+                                                     int64_t total, int pw, int dn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t n = i / pw;
+    const int p = (int)(i - n * pw);
+    const float* w = Wnode + (int64_t)p * 2 * dn;
+    const float* x = x0 + n * dn;
+    float s0 = bnode[p], s1 = 0.f;
+    for (int k = 0; k < dn; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        const float4 wa = *reinterpret_cast<const float4*>(w + k);
+        const float4 wb = *reinterpret_cast<const float4*>(w + dn + k);
+        s0 = fmaf(xv.x, wa.x, s0); s0 = fmaf(xv.y, wa.y, s0); s0 = fmaf(xv.z, wa.z, s0); s0 = fmaf(xv.w, wa.w, s0);
+        s1 = fmaf(xv.x, wb.x, s1); s1 = fmaf(xv.y, wb.y, s1); s1 = fmaf(xv.z, wb.z, s1); s1 = fmaf(xv.w, wb.w, s1);
+    }
+    P0[i] = s0;
+    P[i] = s0 + s1;
+}
+
 struct StepIO {
     // node features as one or two K segments (x0 | x) -- together kx columns
     const float* xa; int64_t ldxa; const float* xb; int64_t ldxb; int kxa;
@@ -545,9 +568,15 @@ static int mlp_forward(const mpnhip_mlp& m, const float* x, int64_t ldx, const i
         if (splitk && !a_idx) {
             int st = MPNHIP_OK;
             const int k_in = i == 0 ? m.in_dim : m.out_dims[i - 1];
+            // (the layer after it rides along when it is the MLP's last and narrow: the reference's 2048 -> 128 -> 32 node encoder)
+            SplitkNext nx = {};
+            const bool has_next = i + 2 == m.n_layers;
+            if (has_next) nx = {m.weight[i + 1], m.bias[i + 1], m.out_dims[i + 1], m.out_dims[i + 1] != 1, y, m.out_dims[i + 1], false};
             if (linear_splitk(i == 0 ? x : hidden[i - 1], i == 0 ? ldx : k_in, m.weight[i], m.bias[i], i == m.n_layers - 1 ? y : hidden[i],
-                              m.out_dims[i], rows, m.out_dims[i], k_in, m.out_dims[i] != 1, splitk, splitk_floats, s, &st)) {
+                              m.out_dims[i], rows, m.out_dims[i], k_in, m.out_dims[i] != 1, splitk, splitk_floats, s, &st,
+                              has_next ? &nx : nullptr)) {
                 if (st != MPNHIP_OK) return st;
+                if (nx.done) ++i;   // both layers are evaluated
                 continue;
             }
         }
@@ -663,7 +692,10 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
     const bool hoist = d.nf == 2 && d.L > 1;
-    if (hoist) {  // P0 = x0 Wnode[:, :dn]^T + bnode, once per forward
+    // few nodes at the reference's width: P0 and the first step's projections by one small kernel (decided with fuse_node below)
+    const bool proj_small = hoist && d.dn == 32 && N > 0 && N <= 4096 && d.kx == 2 * d.dn && m.precision != MPNHIP_PREC_BF16 &&
+                            ((((uintptr_t)p.Wnode) | ((uintptr_t)p.P0) | ((uintptr_t)x0)) & 15) == 0 && !getenv("MPNHIP_NO_NODE_FUSION");
+    if (hoist && !proj_small) {  // P0 = x0 Wnode[:, :dn]^T + bnode, once per forward
         GemmArgs a = {};
         a.ngroups = 1; a.N = d.pw; a.K = d.dn; a.ksplit = d.dn; a.m_upper = N;
         GemmGroup& G = a.g[0];
@@ -693,6 +725,12 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     const bool fuse_node = (!save || m.agg != MPNHIP_AGG_MAX) && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && N <= 4096 && m.precision != MPNHIP_PREC_BF16 &&
                            ((((uintptr_t)m.node.weight[0]) | ((uintptr_t)p.P0) | ((uintptr_t)p.Wnode)) & 15) == 0 &&
                            !getenv("MPNHIP_NO_NODE_FUSION");
+    if (proj_small) {
+        const int64_t total = N * d.pw;
+        hipLaunchKernelGGL(k_proj_hoist32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x0, p.Wnode, p.bnode, p.P0, step_at(p, 0).P,
+                           total, d.pw, d.dn);
+        MPN_LAUNCH_CHECK();
+    }
     int prev = 0;
     for (int step = 0; step < d.L; ++step) {
         int cur = save ? step + 1 : 1 + (step & 1);
@@ -710,7 +748,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.P0 = hoist ? p.P0 : nullptr;
         io.Q0 = hoist_e ? p.Q0 : nullptr;
         io.fuse_node = fuse_node ? 1 : 0;
-        io.p_ready = fuse_node && step > 0 ? 1 : 0;
+        io.p_ready = (fuse_node && step > 0) || (proj_small && step == 0) ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb));
