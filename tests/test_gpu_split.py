@@ -148,3 +148,56 @@ def test_split_ragged_and_degenerate_graphs(case):
     params = synth.model_params(128, 3, "mean", node_in_dim=48)
     W = synth.make_weights(params, seed=17)
     check_against_oracle(params, W, gg, precision="fp32_split")
+
+
+def test_split_backward_is_unbiased_against_the_fp32_backward():
+    """v_mfma_f32_32x32x16_bf16 adds its products to the accumulator with a small bias toward -infinity (tools/micro/mfma_bias.hip:
+    mean error -0.06 ... -0.11 of the rms error of a six-product result).  The split BACKWARD chain kernel cancels it by keeping
+    the gradients of every other edge negated in its registers; without that the bias adds up coherently in every sum the
+    backward takes (measured before the fix: mean / rms of the difference to the fp32 kernel -0.06 ... -0.14 per dZ block,
+    parameter gradients 5e-5 apart after 12 steps).  Here: ONE fp32 forward, mpnhip_backward twice on it (fp32 / split chain
+    kernels): every kept dZ block's difference has no mean beyond noise, does not grow with the steps, and the parameter
+    gradients of the two runs agree to rounding."""
+    from mpntrackseg_amd.autograd import native_backward, native_forward_saved
+    c = synth.CONFIGS["B"]
+    L = 6
+    g = synth.make_graph(c["N"] // 2, c["E"] // 2, seed=1, node_in_dim=64)
+    params = synth.model_params(c["d"], L, "sum", node_in_dim=64)
+    model = make_train_model(params, synth.make_weights(params, seed=7, gain=0.7))
+    dev = torch.device("cuda:0")
+    x, ea, ei = (torch.from_numpy(g[k]).to(dev) for k in ("x", "edge_attr", "edge_index"))
+    N, E = x.shape[0], ea.shape[0]
+    pg = capi.PreparedGraph(ei, N, validate=True)
+    logits = torch.empty((L, E), dtype=torch.float32, device=dev)
+    model.gemm_precision = "fp32"
+    ws = native_forward_saved(model, pg, x, ea, logits)
+    r = torch.from_numpy(synth.normal(11, (L, E))).to(dev)
+    lib = capi.load()
+
+    def run(prec):
+        model.gemm_precision = prec
+        grads = {id(p): torch.zeros_like(p) for p in model.hot_path_parameters()}
+        native_backward(model, pg, x, ea, r, ws, grads)
+        torch.cuda.synchronize()
+        bws = capi.workspace(lib.mpnhip_backward_workspace_bytes(model.c_model([], n_edges=E), N, E), dev, "bwd")
+        blocks = {(s, what, ly): capi.backward_saved(model, pg, bws, what, s, ly).double().cpu().numpy()
+                  for s in (1, L // 2, L) for what, ly in (("dz_flow", 0), ("dz_flow", 1), ("dz_edge", 0), ("dz_edge", 1), ("dp", 0))}
+        names = {id(p): k for k, p in model.named_parameters()}
+        return blocks, {names[i]: t.double().cpu().numpy() for i, t in grads.items()}
+
+    a, ga = run("fp32")
+    b, gb = run("fp32_split")
+    for k in a:
+        na = np.linalg.norm(a[k])
+        if na == 0.0:
+            continue   # (no flow gradient reaches the last step)
+        dlt = (b[k] - a[k]).ravel()
+        rms = float(np.sqrt((dlt * dlt).mean()))
+        rel = float(np.linalg.norm(dlt) / na)
+        bias = float(dlt.mean() / rms) if rms > 0 else 0.0
+        print("step %d %-8s layer %d: split - fp32 rel %.2e, mean / rms %+.4f" % (k[0], k[1], k[2], rel, bias))
+        assert rel < 2e-6, (k, rel)                     # (5e-6 at step 1 of 12 before the fix, growing)
+        assert abs(bias) < 0.02, (k, bias)              # (-0.06 ... -0.14 before the fix; noise level 1 / sqrt(n) ~ 0.001)
+    for k in ga:
+        d = float(np.linalg.norm(gb[k] - ga[k]) / max(np.linalg.norm(ga[k]), 1e-30))
+        assert d < 3e-6, (k, d)                         # (3e-5 ... 5e-5 before the fix)
