@@ -546,6 +546,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             // the same logical images (rows = contraction index n, columns = k) as split images (edge_chain.hip, split8);
             // recorded and packed by one launch (pack_split cannot fail once its sizes are valid: nothing returns before the flush)
             SplitBatch sb;
+            SplitBatchGuard sbg;
             split_batch_begin(&sb);
             for (int q = 0; q < 2; ++q) {
                 MPN_TRY(pack_split(fl[q]->weight[1], hn, 1, dn, hn, DN, HN, p.wf2p[q], s));
@@ -561,7 +562,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             MPN_TRY(split_batch_flush(s));
         } else {
             PackBatch pb;
-            pack_batch_begin(&pb);   // (the eight images as one launch; nothing below returns before the flush)
+            PackBatchGuard pbg;
+            pack_batch_begin(&pb);   // (the eight images as one launch)
             for (int q = 0; q < 2; ++q) {
                 MPN_TRY(pack_padded(fl[q]->weight[1], hn, 0, dn, hn, p.wf2p[q], DN, HN, HN, 0, s));
                 MPN_TRY(pack_padded(fl[q]->weight[0], fl[q]->in_dim, kx, hn, de, p.wfep[q], HN, DE, DE, 0, s));

@@ -220,6 +220,8 @@ struct PackBatch {
 void pack_batch_begin(PackBatch* b);            // opens `b` for the calling thread (n = 0)
 bool pack_batch_add(const PackOp& op);          // true: recorded (a batch is open and has room)
 int pack_batch_flush(hipStream_t stream);       // launches what was recorded, closes the batch
+void pack_batch_abort();                        // closes an open batch without launching it
+struct PackBatchGuard { ~PackBatchGuard() { pack_batch_abort(); } };   // declare beside the batch (error returns before the flush)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -107,6 +107,10 @@ struct SplitOp { const float* src; int64_t sk, sn; int K, N, Kp, Np; unsigned sh
 struct SplitBatch { static constexpr int MAX = 16; SplitOp op[MAX]; int n; };
 void split_batch_begin(SplitBatch* b);
 int split_batch_flush(hipStream_t s);
+void split_batch_abort();                                              // closes an open batch without launching it
+struct SplitBatchGuard { ~SplitBatchGuard() { split_batch_abort(); } }; // declare beside the batch: an error return between
+                                                                       // begin and flush must not leave the thread's batch
+                                                                       // pointer on a dead stack frame
 int transpose_padded(const float* W, int64_t ldw, int k0, int n_rows, int k_cols, float* WT, int n_pad, int k_pad, hipStream_t s);
 int pack_padded(const float* src, int64_t lds, int c0, int rows, int cols, float* dst, int rows_pad, int cols_pad, int ldd,
                 int dst_c0, hipStream_t s);

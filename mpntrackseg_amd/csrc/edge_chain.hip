@@ -1103,6 +1103,7 @@ void split_batch_begin(SplitBatch* b) {
     b->n = 0;
     g_split_batch = getenv("MPNHIP_NO_PACK_BATCH") ? nullptr : b;
 }
+void split_batch_abort() { g_split_batch = nullptr; }
 int split_batch_flush(hipStream_t s) {
     SplitBatch* b = g_split_batch;
     g_split_batch = nullptr;

@@ -171,6 +171,7 @@ bool pack_batch_add(const PackOp& op) {
     return true;
 }
 
+void pack_batch_abort() { g_pack_batch = nullptr; }
 int pack_batch_flush(hipStream_t s) {
     PackBatch* b = g_pack_batch;
     g_pack_batch = nullptr;
@@ -663,6 +664,8 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         count_path(PC_WEIGHT_PACK);
         PackBatch pb;
         SplitBatch sb;
+        PackBatchGuard pbg;
+        SplitBatchGuard sbg;
         pack_batch_begin(&pb);   // (the fp32 images' copies / transposes are recorded and run as one launch,
         split_batch_begin(&sb);  //  the split images as another)
         int rc = pack_node_weights(m, d, p.Wnode, p.bnode, s);
