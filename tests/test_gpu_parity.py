@@ -469,6 +469,24 @@ def test_bf16_chain_fused_aggregation_matches_the_separate_kernel(graph, agg, mo
     assert rel_err(got, want) < 2e-2 and rel_err(xg, xw) < 2e-2
 
 
+@pytest.mark.parametrize("d,top_k", [(32, 60), (64, 150), (256, 30)])
+def test_bf16_chain_fused_aggregation_is_exact_for_max_at_every_width(d, top_k, monkeypatch):
+    """The segment logic of the in-kernel aggregation (whole segments, first / middle / last pieces across 32-edge tiles and
+    256-edge blocks, k_agg_fixup) at the other template widths: with max there is no rounding, so fused and separate aggregation
+    must agree bit for bit on dense kNN graphs (segments of 15 ... 80 edges per direction)."""
+    g = synth.make_knn_graph(frames=12, dets=30, top_k=top_k, seed=9, node_in_dim=64)
+    params = synth.model_params(d, 3, "max", node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=5, gain=0.6))
+    model.gemm_precision = 'bf16'
+    capi.path_counters(reset=True)
+    got, xg, eg = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert capi.path_counters(reset=True)["edge_chain_fwd_bf16"] == 3
+    monkeypatch.setenv("MPNHIP_NO_AGG_FUSION", "1")
+    ref, xr, er = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref) and np.array_equal(xg, xr) and np.array_equal(eg, er)
+
+
 def test_bf16_mode_refuses_training():
     g = synth.make_graph(60, 400, seed=3, node_in_dim=64)
     params = synth.model_params(32, 2, "sum", node_in_dim=64)
