@@ -27,7 +27,15 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# stand-alone micro-benchmarks / diagnostics (tools/micro/*.hip); outputs go to build/micro/ (git-ignored)
+MICRO := $(patsubst tools/micro/%.hip,build/micro/%,$(wildcard tools/micro/*.hip))
+micro: $(MICRO)
+build/micro/%: tools/micro/%.hip
+	@mkdir -p build/micro
+	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+
 clean:
 	rm -f $(OBJS) $(LIB) $(TORCH_LIB)
+	rm -rf build/micro
 
-.PHONY: all clean
+.PHONY: all clean micro

@@ -1,7 +1,7 @@
 // Is the fp32-from-three-bf16-pieces product (six v_mfma_f32_32x32x16_bf16, edge_chain.hip mfma6) BIASED?  D = A B for random
 // A [32 x K], B [K x 32] with the six-product scheme and with the fp32 MFMA, against float64 on the host: rms and MEAN of the
 // error in units of the result's rms (a mean far from 0 +- 1/sqrt(n) is a bias).  Also with B negated and the result negated back.
-// build: hipcc --offload-arch=gfx950 -O2 tools/micro/mfma_bias.hip -o tools/micro/mfma_bias
+// build: make micro   (-> build/micro/mfma_bias)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

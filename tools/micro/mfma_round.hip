@@ -1,6 +1,6 @@
 // How does v_mfma_f32_32x32x16_bf16 round when it adds its 16 products to the fp32 accumulator?  (the fp32 MFMA is an fmaf
 // chain: MI355X guide.)  One wave; A[i][k] = a_k for every row, B[k][j] = b_k for every column, C = c: every output = c + sum a_k b_k.
-// build: hipcc --offload-arch=gfx950 -O2 tools/micro/mfma_round.hip -o /tmp/mfma_round
+// build: make micro   (-> build/micro/mfma_round)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

@@ -1,6 +1,6 @@
 // Micro-benchmark: the chained-product core of the fused edge kernel (weights in LDS, activations in accumulator
 // registers) with native fp32 MFMAs vs the 3-way bf16 split (6 products, fp32 accumulate).  Standalone:
-//   hipcc -O3 --offload-arch=gfx950 tools/micro/split_core_bench.hip -o /tmp/split_core_bench && /tmp/split_core_bench
+//   make micro && build/micro/split_core_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
