@@ -236,6 +236,11 @@ int mpnhip_linear(const float* x, int64_t ldx, const float* w, const float* b, f
 size_t mpnhip_weight_grad_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch);
 int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the operand form chosen: MPNHIP_PREC_FP32 (fp32 MFMAs; what mpnhip_weight_grad does) or MPNHIP_PREC_FP32_SPLIT
+ * (every fp32 operand as the exact sum of three bf16 pieces, six piece products with fp32 accumulate: the same accuracy class;
+ * what mpnhip_backward uses for a model in that precision). */
+int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision, float* grad_w,
+                            float* grad_b, void* workspace, size_t workspace_bytes, void* stream);
 
 /* MLP.forward (models/mlp.py:27-28): all layers; scratch [2, M, max(out_dims)] floats. */
 size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m);
@@ -389,6 +394,8 @@ int mpnhip_time_aggregate(const void* graph_buf, int n_nodes, int64_t n_edges, c
 /* Average duration (us) of `iters` back-to-back mpnhip_weight_grad calls (product + slab sum). */
 int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
                             void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream);
+int mpnhip_time_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision, float* grad_w,
+                                 float* grad_b, void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream);
 /* Average duration (us) of `iters` launches of y = relu(x W^T + b). */
 int mpnhip_time_linear(const float* x, const float* w, const float* b, float* y, int64_t m, int n, int k, int iters,
                        float* avg_us, void* stream);

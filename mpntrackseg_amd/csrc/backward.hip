@@ -198,6 +198,8 @@ struct BwdPlan {
     float* slab;                        // split partials of the weight-gradient products (2 groups)
     float* slab_side;                   // the same for the products issued on the side stream
     size_t slab_floats_per_group;
+    float* slab_wp;                     // slabs of a batch of row-panel products (all jobs of one group of steps)
+    size_t slab_wp_floats;
     size_t total;
 };
 
@@ -263,9 +265,32 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     upd(mlp_slab(m.classifier, d.de, E, (int)L));
     upd(tn_slab_floats(d.dn, 2 * d.dn, N, (int)L));
     upd(tn_slab_floats(d.pw, d.kx, N, (int)L));
+    // the same products in the row-panel form (MPNHIP_PREC_FP32_SPLIT): alone on the caller's stream ...
+    auto updw = [&](int n_out, int k_in, int64_t rows, int nb) { if (rows > 0) upd((wp_slab_floats(n_out, k_in, rows, nb, false) + 1) / 2); };
+    for (int i = 0; i < m.enc_node.n_layers; ++i) updw(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N, 1);
+    for (int i = 0; i < m.enc_edge.n_layers; ++i) updw(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E, 1);
+    updw(d.he, d.de, E, 1);
+    updw(d.pw, d.dn, N, 1);
+    for (int i = 0; i < m.classifier.n_layers; ++i) updw(m.classifier.out_dims[i], i == 0 ? d.de : m.classifier.out_dims[i - 1], E, 1);
     p.slab_floats_per_group = sl;
     p.slab = a.f(2 * sl);
     p.slab_side = a.f(2 * sl);
+    // ... and all products of a group of nb steps in one batch (mp_weight_grads): every job has its own slabs
+    size_t wpmax = 0;
+    for (int nb = 1; nb <= (int)L; ++nb) {
+        size_t t = 0;
+        auto addw = [&](int n_out, int k_in, int64_t rows, bool ranged) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, nb, ranged); };
+        addw(d.dn, 2 * d.dn, N, false);
+        for (int i = 1; i < m.flow_in.n_layers; ++i) { addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); }
+        addw(d.hn, d.de, E, true); addw(d.hn, d.de, E, true);
+        for (int i = 0; i < m.classifier.n_layers; ++i) addw(m.classifier.out_dims[i], i == 0 ? d.de : m.classifier.out_dims[i - 1], E, false);
+        for (int i = 1; i < m.edge.n_layers; ++i) addw(m.edge.out_dims[i], m.edge.out_dims[i - 1], E, false);
+        addw(d.he, d.ke > d.de ? d.ke : d.de, E, false);
+        addw(d.pw, d.kx, N, false);
+        wpmax = t > wpmax ? t : wpmax;
+    }
+    p.slab_wp_floats = wpmax;
+    p.slab_wp = a.f(wpmax);
     p.total = a.off;
     if (out) *out = p;
     return p.total;
@@ -283,10 +308,30 @@ struct Operand {        // one side of a (batched) weight-gradient product
     int64_t bstride;    // floats between consecutive batches (0: same block every batch)
 };
 
+// set by mpnhip_backward for a model in MPNHIP_PREC_FP32_SPLIT: weight gradients in the three-piece operand form (wgrad_panel.hip)
+static thread_local bool g_wgrad_split = false;
+
 // dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
                        const int* h_idx, int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2],
                        const RowRange rr[2], int64_t rows, int nbatch, hipStream_t s) {
+    if (g_wgrad_split && !dz_idx && !h_idx && !H2.p && rows > 0) {
+        // MPNHIP_PREC_FP32_SPLIT: the row-panel kernel (wgrad_panel.hip) -- recorded into the open batch (all products of a group of
+        // steps: one product launch + one slab-sum launch), or run as a batch of its own
+        WpProduct wp[2];
+        for (int q = 0; q < ngroups; ++q)
+            wp[q] = {dZ.p, dZ.ld, dZ.bstride, H.p, H.ld, H.bstride, rr ? rr[q].begin : nullptr, rr ? rr[q].end : nullptr, rows, nbatch,
+                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr};
+        if (wp_batch_open()) {
+            if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
+        } else {
+            WpBatch own;
+            WpBatchGuard guard;
+            wp_batch_begin(&own, slab_base, 2 * p.slab_floats_per_group);
+            if (wp_batch_add(wp, ngroups)) return wp_batch_flush(s);
+            wp_batch_abort();
+        }
+    }
     TnArgs a = {};
     a.ngroups = ngroups;
     a.n_out = n_out;
@@ -496,6 +541,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             for (int i = 0; i < q->n_layers; ++i)
                 MPN_CHECK_ARG(q->grad_weight[i] && q->grad_bias[i], "backward: null gradient buffer");
     }
+    struct WgradScope {
+        bool old;
+        explicit WgradScope(bool v) : old(g_wgrad_split) { g_wgrad_split = v; }
+        ~WgradScope() { g_wgrad_split = old; }
+    } wgrad_scope(m.precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL"));
     FwdPlan f;
     size_t fneed = plan_forward(m, d, N, E, 1, fwd_workspace, &f);
     if (!fwd_workspace || fwd_workspace_bytes < fneed) {
@@ -613,6 +663,12 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     auto mp_weight_grads = [&](int b0, int nb, hipStream_t st, float* slab) -> int {
         if (nb <= 0) return MPNHIP_OK;
         const int64_t zb = b0;  // first batch
+        // MPNHIP_PREC_FP32_SPLIT: the products below are recorded and run as ONE product launch + ONE slab-sum launch at the end
+        // (calls are serialised on `st`, so successive groups may share the slab region)
+        WpBatch wpb;
+        WpBatchGuard wpg;
+        if (g_wgrad_split) wp_batch_begin(&wpb, p.slab_wp, p.slab_wp_floats);
+        auto finish = [&]() -> int { return wp_batch_open() ? wp_batch_flush(st) : MPNHIP_OK; };
         {   // node update Linear
             float* gw[2] = {m.node.grad_weight[0], nullptr};
             float* gb[2] = {m.node.grad_bias[0], nullptr};
@@ -667,7 +723,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 float* gw[2] = {p.gWnode + dn, nullptr};
                 MPN_TRY(weight_grad(p, slab, 1, {p.dP + zb * N * pw, pw, (int64_t)N * pw}, nullptr, {f.x_hist + xs * zb, dn, (int64_t)xs},
                                     {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr, N, nb, st));
-                return MPNHIP_OK;
+                return finish();
             }
             float* gw[2] = {p.gWnode, nullptr};
             const bool two = d.nf == 2;
@@ -676,7 +732,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             MPN_TRY(weight_grad(p, slab, 1, {p.dP + zb * N * pw, pw, (int64_t)N * pw}, nullptr, h1, h2, dn, nullptr, pw, kx, gw, kx, nullptr,
                                 nullptr, N, nb, st));
         }
-        return MPNHIP_OK;
+        return finish();
     };
     // The steps are finished from L down to 1.  Their weight gradients go in groups: as soon as a group's steps are done
     // its batched products run on a side stream UNDER the remaining steps' chain kernels (which leave 120 of the 256

@@ -127,6 +127,44 @@ __host__ __device__ static inline int tn_kpad(int k_in) { return (k_in + 4) & ~3
 size_t tn_slab_floats(int n_out, int k_in, int64_t m_upper, int nbatch);
 int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 
+// ---- three-piece operand form, row-panel blocks, all products of a group of steps in one launch (wgrad_panel.hip) ----
+struct WpJob {             // one product (one direction group of it), as the kernels see it
+    const float* dZ;       // [rows, n_out], leading dim ldz; batch b at dZ + b * z_bstride
+    const float* H;        // [rows, k_in], leading dim ldh
+    const int* row_begin;  // device ints (nullptr -> 0 / m_static)
+    const int* row_end;
+    float* slab;           // [nbatch * nsplit][n_out][tn_kpad(k_in)]
+    float* grad_w;         // += ; leading dim ldw
+    float* grad_b;         // += ; may be nullptr
+    int64_t ldz, ldh, z_bstride, h_bstride, ldw, m_static;
+    int n_out, k_in, nbatch;
+    int chunk, nsplit;     // rows per chunk, chunks per batch
+    int variant;           // block tile shape (wgrad_panel.hip kVariants)
+    int tiles_o, tiles_c;  // output tiles of that shape
+    int block0;            // first block of the job in the product launch
+    int red_block0;        // ... in the slab-sum launch
+};
+constexpr int WP_MAX_JOBS = 16;
+struct WpTable { WpJob job[WP_MAX_JOBS]; int njobs; };
+struct WpProduct {         // host-side description of one product
+    const float* dZ; int64_t ldz, z_bstride;
+    const float* H; int64_t ldh, h_bstride;
+    const int* row_begin; const int* row_end;   // device-side row range (a direction group) or nullptr
+    int64_t rows;          // rows of one batch (upper bound when ranged)
+    int nbatch, n_out, k_in;
+    float* grad_w; int64_t ldw; float* grad_b;
+};
+struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops; int nblocks, nred; };
+bool wp_eligible(const WpProduct& p);
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged);
+void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats);   // opens b for the calling thread
+bool wp_batch_open();
+bool wp_batch_add(const WpProduct& p);       // true: recorded (a batch is open, the product is eligible, table and slab space suffice)
+bool wp_batch_add(const WpProduct* ps, int n);   // all n (the direction groups of one product) or none
+int wp_batch_flush(hipStream_t stream);      // product launch + slab-sum launch; closes the batch
+void wp_batch_abort();
+struct WpBatchGuard { ~WpBatchGuard() { wp_batch_abort(); } };
+
 // few rows, long K (node encoder at the reference's graph sizes): split-K into `scratch`, then a fixed-order sum (gemm.hip)
 // `next` (optional): the Linear layer that follows ([next->n x n] weights, output next->y): evaluated in the summing launch when it is
 // narrow enough (next->done is set); otherwise untouched
@@ -230,7 +268,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_COUNT
 };
 void count_path(int id);
 

@@ -509,7 +509,9 @@ using namespace mpnhip;
 
 extern "C" size_t mpnhip_weight_grad_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch) {
     if (n_out < 1 || k_in < 1 || rows < 0) return 0;
-    return align_up(tn_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch) * sizeof(float), 256) + 256;
+    const size_t a = tn_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch);
+    const size_t b = rows > 0 ? wp_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch, false) : 0;   // (MPNHIP_PREC_FP32_SPLIT form)
+    return align_up((a > b ? a : b) * sizeof(float), 256) + 256;
 }
 
 static int weight_grad_args(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w, float* grad_b,
@@ -534,26 +536,49 @@ static int weight_grad_args(const float* dZ, const float* H, int64_t rows, int n
     return MPNHIP_OK;
 }
 
-extern "C" int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
-                                  float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
+// precision MPNHIP_PREC_FP32_SPLIT: the row-panel kernel with three-piece bf16 operands (wgrad_panel.hip) where the shape allows it
+static int weight_grad_run(const TnArgs& a, int precision, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL")) {
+        const TnGroup& g = a.g[0];
+        WpProduct p = {g.dZ, g.ldz, g.z_bstride, g.H, g.ldh, g.h_bstride, nullptr, nullptr, a.m_upper, a.nbatch, a.n_out, a.k_in,
+                       g.grad_w, g.ldw, g.grad_b};
+        WpBatch b;
+        WpBatchGuard guard;
+        wp_batch_begin(&b, g.slab, (workspace_bytes - 256) / sizeof(float));
+        if (wp_batch_add(p)) return wp_batch_flush(s);
+        wp_batch_abort();
+    }
+    return launch_gemm_tn(a, s);
+}
+
+extern "C" int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision,
+                                       float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
+    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT, "weight_grad: precision %d", precision);
     TnArgs a;
     MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
     if (rows == 0) return MPNHIP_OK;
-    return launch_gemm_tn(a, static_cast<hipStream_t>(stream));
+    return weight_grad_run(a, precision, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
-                                       float* grad_b, void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream_) {
+extern "C" int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
+                                  float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
+    return mpnhip_weight_grad_prec(dZ, H, rows, n_out, k_in, nbatch, MPNHIP_PREC_FP32, grad_w, grad_b, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mpnhip_time_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision,
+                                            float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes, int iters, float* avg_us,
+                                            void* stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     MPN_CHECK_ARG(avg_us && iters > 0 && rows > 0, "time_weight_grad: bad argument");
+    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT, "time_weight_grad: precision %d", precision);
     TnArgs a;
     MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
     hipEvent_t t0, t1;
     MPN_HIP(hipEventCreate(&t0));
     MPN_HIP(hipEventCreate(&t1));
-    MPN_TRY(launch_gemm_tn(a, s));
+    MPN_TRY(weight_grad_run(a, precision, workspace, workspace_bytes, s));
     MPN_HIP(hipEventRecord(t0, s));
-    for (int i = 0; i < iters; ++i) MPN_TRY(launch_gemm_tn(a, s));
+    for (int i = 0; i < iters; ++i) MPN_TRY(weight_grad_run(a, precision, workspace, workspace_bytes, s));
     MPN_HIP(hipEventRecord(t1, s));
     MPN_HIP(hipEventSynchronize(t1));
     float ms = 0.f;
@@ -564,3 +589,8 @@ extern "C" int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t 
     return MPNHIP_OK;
 }
 
+extern "C" int mpnhip_time_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
+                                       float* grad_b, void* workspace, size_t workspace_bytes, int iters, float* avg_us, void* stream_) {
+    return mpnhip_time_weight_grad_prec(dZ, H, rows, n_out, k_in, nbatch, MPNHIP_PREC_FP32, grad_w, grad_b, workspace, workspace_bytes, iters,
+                                        avg_us, stream_);
+}

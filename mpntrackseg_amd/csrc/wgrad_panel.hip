@@ -1,0 +1,533 @@
+// Weight-gradient products in the three-piece operand form (MPNHIP_PREC_FP32_SPLIT), SURVEY.md section 3.4 / mlp.py:27-28 under autograd:
+//   dW[o, c] += sum_m dZ[m, o] * H[m, c]        db[o] += sum_m dZ[m, o]
+// The reduction runs over the rows (edges or nodes) and both operands are stored with the reduction index as the ROW: an HBM
+// stream of (n_out + k_in) floats per row against a small [n_out, k_in] output -- 27 flop per byte for the chain's skinny
+// layers.  What this kernel is built around:
+//   * every operand row is fetched ONCE: a block owns a ROW PANEL (a chunk of rows) and the whole output [n_out, k_in] (or one of
+//     a few large output tiles when n_out x k_in exceeds a block's accumulators), not a 64 x 128 tile that re-reads rows 2-5 times;
+//   * fp32 operands are split into three bf16 pieces ONCE, as a 16-row stage passes through the loader's registers
+//     (x = h + m + l exactly, edge_chain.hip), and written row-major into LDS (ds_write_b64 per piece: 4 columns of one row);
+//   * the MFMA operands need the reduction index along the lane's 8 elements, i.e. the transpose of that image:
+//     ds_read_b64_tr_b16 delivers it (4 rows x 16 columns per 16-lane group, column-major) -- no transposing store, no shuffles;
+//     the row pitch is 64 (mod 256) bytes, so a half-wave's 4 rows x 64 bytes cover the 64 banks once;
+//   * six piece products per k block on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) = 3/8 of the fp32 MFMA's cycles, which puts
+//     the product under the operand stream: the kernel is HBM-bound by design;
+//   * all products of one group of steps go in ONE launch (job table: block -> (product, output tile, row chunk)) and their slabs
+//     are summed by ONE launch (fixed order: deterministic, no float atomics).  Chunks with an odd index carry NEGATED dZ and
+//     are subtracted: the bf16 MFMA's accumulate is biased toward -inf, and the alternation cancels the
+//     bias across neighbouring chunks instead of adding it up over all rows.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace mpnhip {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define WP_LDS __attribute__((address_space(3)))
+
+constexpr int WP_NT = 256;   // threads per block: 4 waves as 2 (output rows) x 2 (output columns)
+constexpr int WP_KB = 16;    // operand rows per stage = one k block of the bf16 MFMA
+
+// loader passes for an operand of at most B columns: B / 4 threads cover a row, 256 / (B / 4) rows per pass (at most 16)
+constexpr int wp_passes(int B) {
+    int rp = WP_NT / (B / 4);
+    rp = rp > WP_KB ? WP_KB : rp;
+    return (WP_KB + rp - 1) / rp;
+}
+constexpr int wp_pitch(int BO, int BC) { return 2 * (BO + BC) + 64; }   // bytes; BO + BC is a multiple of 64 -> pitch = 64 or 192 (mod 256)
+
+__device__ __forceinline__ float fneg_if(float x, unsigned sx) { return __uint_as_float(__float_as_uint(x) ^ sx); }
+
+struct Pk3 { uint2 p[3]; };
+// x = h + m + l, each piece a bf16 (round to nearest even; the residuals are exact in fp32).  Written pair-wise: one
+// v_cvt_pk_bf16_f32 per piece and pair, the piece back as two floats by a shift and a mask, one packed subtraction.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 hv = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(unsigned, hv);
+    const float a0 = x0 - __uint_as_float(h << 16), a1 = x1 - __uint_as_float(h & 0xffff0000u);
+    const bf16x2 mv = {(__bf16)a0, (__bf16)a1};
+    m = __builtin_bit_cast(unsigned, mv);
+    const float c0 = a0 - __uint_as_float(m << 16), c1 = a1 - __uint_as_float(m & 0xffff0000u);
+    const bf16x2 lv = {(__bf16)c0, (__bf16)c1};
+    l = __builtin_bit_cast(unsigned, lv);
+}
+__device__ __forceinline__ Pk3 split4(float4 v) {
+    Pk3 o;
+    split2(v.x, v.y, o.p[0].x, o.p[1].x, o.p[2].x);
+    split2(v.z, v.w, o.p[0].y, o.p[1].y, o.p[2].y);
+    return o;
+}
+
+// one MFMA operand piece: rows 8h .. 8h+7 of the stage, column (col0 + lane % 32), as 8 bf16 along k (two transposing reads)
+template <int P>
+__device__ __forceinline__ bf16x8 tr_read(const char* base) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WP_LDS s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WP_LDS s16x4*)(base + 4 * P));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    // smallest products first (edge_chain.hip mfma6)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// One block: output tile (tile_o, tile_c) of BO = 64 TM x BC = 64 TN, row chunk `by` of job J.
+template <int TM, int TN>
+__device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const int by, char* lds) {
+    constexpr int BO = 64 * TM, BC = 64 * TN;
+    constexpr int P = wp_pitch(BO, BC), PIECE = WP_KB * P;
+    constexpr int PZ = wp_passes(BO), PH = wp_passes(BC);
+    constexpr bool NEG_Z = BO <= BC;   // the sign of odd chunks goes onto the narrower operand (fewer XORs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int rb = J.row_begin ? *J.row_begin : 0;
+    const int re = J.row_end ? *J.row_end : (int)J.m_static;
+    const int batch = by / J.nsplit, ci = by - batch * J.nsplit;
+    const int r0 = rb + ci * J.chunk;
+    int r1 = r0 + J.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;   // empty chunk: the slab sum skips it too
+    const unsigned sx = (ci & 1) ? 0x80000000u : 0u;   // odd chunks: one operand negated (see the header)
+
+    const int tile_o = tile / J.tiles_c, tile_c = tile - tile_o * J.tiles_c;
+    const int o0 = tile_o * BO, c0 = tile_c * BC;
+    const int wo = J.n_out - o0 < BO ? J.n_out - o0 : BO;   // live columns of the dZ / H panels (multiples of 4)
+    const int wc = J.k_in - c0 < BC ? J.k_in - c0 : BC;
+
+    // loader geometry: T threads per row, RP rows per pass; thread (row, col) of pass j reads row + RP j
+    const int tz = wo >> 2, th = wc >> 2;
+    int rpz = WP_NT / tz; rpz = rpz > WP_KB ? WP_KB : rpz;
+    int rph = WP_NT / th; rph = rph > WP_KB ? WP_KB : rph;
+    const int zrow = tid / tz, zcol = (tid - zrow * tz) * 4;
+    const int hrow = tid / th, hcol = (tid - hrow * th) * 4;
+    const bool zact = zrow < rpz, hact = hrow < rph;
+    const int64_t ldz = J.ldz, ldh = J.ldh;
+    // uniform bases (SGPRs) + 32-bit per-thread byte offsets: the row of pass j clamped into the stage (clamped lanes do not store)
+    const char* zbase = reinterpret_cast<const char*>(J.dZ + (int64_t)batch * J.z_bstride + o0);
+    const char* hbase = reinterpret_cast<const char*>(J.H + (int64_t)batch * J.h_bstride + c0);
+    unsigned zoff[PZ], hoff[PH];
+#pragma unroll
+    for (int j = 0; j < PZ; ++j) {
+        int r = zrow + rpz * j;
+        r = (zact && r < WP_KB) ? r : WP_KB - 1;
+        zoff[j] = (unsigned)(((int64_t)r * ldz + (zact ? zcol : 0)) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+        int r = hrow + rph * j;
+        r = (hact && r < WP_KB) ? r : WP_KB - 1;
+        hoff[j] = (unsigned)(((int64_t)r * ldh + (hact ? hcol : 0)) * 4);
+    }
+    char* zdst = lds + zrow * P + zcol * 2;
+    char* hdst = lds + hrow * P + (BO + hcol) * 2;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 zreg[2][PZ], hreg[2][PH];   // two stages in flight
+
+    // full stages: rows m0 .. m0 + 15 all inside the chunk.  Inline assembly on purpose: hipcc's own s_waitcnt placement drains
+    // EVERY outstanding load before the first use of a stage (vmcnt(0) at the loop head), which would turn the two stages in flight
+    // into one; these loads are invisible to it and the waits are counted by hand (wait_stage: vector-memory operations of a
+    // wave complete in issue order, every thread issues all NLD loads of a stage)
+    constexpr int NLD = PZ + PH;
+    f32x4(&z0)[PZ] = zreg[0]; f32x4(&z1)[PZ] = zreg[1];
+    f32x4(&h0)[PH] = hreg[0]; f32x4(&h1)[PH] = hreg[1];
+#define WP_LOAD(ZR, HR, m0)                                                                                              \
+    do {                                                                                                                 \
+        const char* zb_ = zbase + (int64_t)(m0) * ldz * 4;                                                               \
+        const char* hb_ = hbase + (int64_t)(m0) * ldh * 4;                                                               \
+        _Pragma("unroll") for (int j = 0; j < PZ; ++j)                                                                   \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ZR[j]) : "v"(zoff[j]), "s"(zb_));                       \
+        _Pragma("unroll") for (int j = 0; j < PH; ++j)                                                                   \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(HR[j]) : "v"(hoff[j]), "s"(hb_));                       \
+    } while (0)
+    // a stage buffer has landed when at most NLD later loads are outstanding (the other buffer's stage, if it was issued after it)
+#define WP_WAIT(ZR, HR, other_in_flight)                                                                                 \
+    do {                                                                                                                 \
+        if (other_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");                                  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+        _Pragma("unroll") for (int j = 0; j < PZ; ++j) asm volatile("" : "+v"(ZR[j]));                                   \
+        _Pragma("unroll") for (int j = 0; j < PH; ++j) asm volatile("" : "+v"(HR[j]));                                   \
+    } while (0)
+    auto put = [&](char* d, float4 v, bool negate) {
+        if (negate) { v.x = fneg_if(v.x, sx); v.y = fneg_if(v.y, sx); v.z = fneg_if(v.z, sx); v.w = fneg_if(v.w, sx); }
+        const Pk3 s = split4(v);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PIECE) = s.p[q];
+    };
+    // nrows: live rows of the stage (16 for a full one); rows past it are stored as zeros
+    auto store = [&](auto bsel, int nrows) {
+        constexpr int B = decltype(bsel)::value;
+#pragma unroll
+        for (int j = 0; j < PZ; ++j) {
+            const int row = zrow + rpz * j;
+            if (zact && row < WP_KB) {
+                float4 v = make_float4(zreg[B][j][0], zreg[B][j][1], zreg[B][j][2], zreg[B][j][3]);
+                if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+                put(zdst + rpz * j * P, v, NEG_Z);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PH; ++j) {
+            const int row = hrow + rph * j;
+            if (hact && row < WP_KB) {
+                float4 v = make_float4(hreg[B][j][0], hreg[B][j][1], hreg[B][j][2], hreg[B][j][3]);
+                if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                put(hdst + rph * j * P, v, !NEG_Z);
+            }
+        }
+    };
+
+    // transposing-read lane geometry: lane 4q + p of a 16-lane group supplies row q, columns 4p .. 4p+3 of the group's block
+    const int lh = lane >> 5, gi = (lane >> 4) & 1, lq = (lane & 15) >> 2, lp = lane & 3;
+    const char* rda = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + 32 * (wm * TM) * 2;
+    const char* rdb = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + (BO + 32 * (wn * TN)) * 2;
+    // every tile of the wave is computed (columns past n_out / k_in hold whatever the LDS held: those outputs are never stored);
+    // the operand pieces of the next tile are fetched before the six products of the current one
+    auto products = [&]() {
+        if (TM >= TN) {
+            bf16x8 b[TN][3];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[j][q] = tr_read<P>(rdb + q * PIECE + 64 * j);
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[0][q] = tr_read<P>(rda + q * PIECE);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + 1 < TM)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a[(i + 1) & 1][q] = tr_read<P>(rda + q * PIECE + 64 * (i + 1));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mfma6(acc[i][j], a[i & 1], b[j]);
+            }
+        } else {
+            bf16x8 a[TM][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[i][q] = tr_read<P>(rda + q * PIECE + 64 * i);
+            bf16x8 b[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[0][q] = tr_read<P>(rdb + q * PIECE);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j + 1 < TN)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[(j + 1) & 1][q] = tr_read<P>(rdb + q * PIECE + 64 * (j + 1));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) mfma6(acc[i][j], a[i], b[(j & 1)]);
+            }
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    const int nfull = (r1 - r0) / WP_KB;          // full stages
+    const int tail = (r1 - r0) - nfull * WP_KB;   // rows of the partial last stage (0: none)
+    if (nfull > 0) {
+        WP_LOAD(z0, h0, r0);
+        if (nfull > 1) WP_LOAD(z1, h1, r0 + WP_KB);
+        for (int st = 0; st < nfull; st += 2) {
+            WP_WAIT(z0, h0, st + 1 < nfull);
+            store(B0{}, WP_KB);
+            __syncthreads();
+            if (st + 2 < nfull) WP_LOAD(z0, h0, r0 + (st + 2) * WP_KB);
+            products();
+            __syncthreads();
+            if (st + 1 >= nfull) break;
+            WP_WAIT(z1, h1, st + 2 < nfull);
+            store(B1{}, WP_KB);
+            __syncthreads();
+            if (st + 3 < nfull) WP_LOAD(z1, h1, r0 + (st + 3) * WP_KB);
+            products();
+            __syncthreads();
+        }
+    }
+    if (tail > 0) {
+        // the partial stage: rows clamped to the chunk's last row, zeros stored past it
+        const int m0 = r0 + nfull * WP_KB;
+#pragma unroll
+        for (int j = 0; j < PZ; ++j) {
+            int r = zrow + rpz * j;
+            r = (zact && r < tail) ? r : tail - 1;
+            zreg[0][j] = *reinterpret_cast<const f32x4*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < PH; ++j) {
+            int r = hrow + rph * j;
+            r = (hact && r < tail) ? r : tail - 1;
+            hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + (hact ? hcol : 0)) * 4);
+        }
+        store(B0{}, tail);
+        __syncthreads();
+        products();
+        __syncthreads();
+    }
+
+    // ---- the partial output tile into this chunk's slab (odd chunks negated as a whole: the slab sum subtracts them) ----
+    const int kpad = tn_kpad(J.k_in);
+    float* slab = J.slab + (size_t)by * J.n_out * kpad;
+    const int li = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + 32 * (wn * TN + j) + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * (wm * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < J.n_out && c < J.k_in) slab[(size_t)o * kpad + c] = acc[i][j][r];
+            }
+        }
+    if (tile_c == 0) {
+        // bias partials: the rpz row groups' column sums meet in LDS (free after the loop's last barrier), fixed order; summed
+        // from the dZ values as loaded, so they take the chunk's sign here
+        float* bs = reinterpret_cast<float*>(lds);
+        if (zact) *reinterpret_cast<float4*>(bs + zrow * BO + zcol) = bsum;
+        __syncthreads();
+        for (int t = tid; t < wo; t += WP_NT) {
+            float s = 0.f;
+            for (int r = 0; r < rpz; ++r) s += bs[r * BO + t];
+            slab[(size_t)(o0 + t) * kpad + J.k_in] = sx ? -s : s;
+        }
+    }
+}
+
+#undef WP_LOAD
+#undef WP_WAIT
+
+}  // namespace
+
+__global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char wp_lds[];
+    const int b = blockIdx.x;
+    int j = 0;
+    for (int i = 1; i < tab.njobs; ++i) j = b >= tab.job[i].block0 ? i : j;
+    const WpJob& J = tab.job[j];
+    const int local = b - J.block0;
+    const int ntiles = J.tiles_o * J.tiles_c;
+    const int by = local / ntiles, tile = local - by * ntiles;
+    switch (J.variant) {
+        case 0: wp_block<5, 1>(J, tile, by, wp_lds); break;
+        case 1: wp_block<1, 5>(J, tile, by, wp_lds); break;
+        case 2: wp_block<4, 1>(J, tile, by, wp_lds); break;
+        case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
+        case 4: wp_block<2, 4>(J, tile, by, wp_lds); break;
+        default: wp_block<2, 2>(J, tile, by, wp_lds); break;
+    }
+}
+
+// grad_w[o * ldw + c] += sum_j (-1)^chunk(j) slab_j[o][c];  grad_b[o] += ... slab_j[o][k_in]  over the non-empty chunks of every
+// job of the table.  Block = 32 x 16-byte columns of one job's padded slab image x 8 slab groups (a wave reads 512 contiguous
+// bytes of one slab, four slabs in flight per lane); the groups' partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WpTable tab) {
+    __shared__ float4 part[8][32];
+    const int b = blockIdx.x;
+    int j = 0;
+    for (int i = 1; i < tab.njobs; ++i) j = b >= tab.job[i].red_block0 ? i : j;
+    const WpJob& J = tab.job[j];
+    const int kpad = tn_kpad(J.k_in);
+    const int64_t total4 = (int64_t)J.n_out * kpad / 4;
+    const int64_t q = (int64_t)(b - J.red_block0) * 32 + (threadIdx.x & 31);
+    const int grp = threadIdx.x >> 5;
+    const int rb = J.row_begin ? *J.row_begin : 0;
+    const int re = J.row_end ? *J.row_end : (int)J.m_static;
+    int nvalid = (re - rb + J.chunk - 1) / J.chunk;
+    nvalid = nvalid < 0 ? 0 : (nvalid > J.nsplit ? J.nsplit : nvalid);
+    const int nslab = nvalid * J.nbatch;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)J.n_out * kpad;
+    if (q < total4) {
+        const float* p = J.slab + q * 4;
+        for (int j0 = grp; j0 < nslab; j0 += 32) {
+            float4 v[4];
+            float sg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int jj = j0 + 8 * u;
+                const bool ok = jj < nslab;
+                jj = ok ? jj : j0;   // clamped, unconditional loads
+                const int bb = jj / nvalid, ci = jj - bb * nvalid;
+                sg[u] = ok ? ((ci & 1) ? -1.f : 1.f) : 0.f;
+                v[u] = *reinterpret_cast<const float4*>(p + ((size_t)bb * J.nsplit + ci) * stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(sg[u], v[u].x, acc.x); acc.y = fmaf(sg[u], v[u].y, acc.y);
+                acc.z = fmaf(sg[u], v[u].z, acc.z); acc.w = fmaf(sg[u], v[u].w, acc.w);
+            }
+        }
+    }
+    part[grp][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (grp == 0 && q < total4) {
+        float4 s = part[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+            const float4 o = part[g][threadIdx.x];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t t = q * 4 + e;
+            const int o = (int)(t / kpad), c = (int)(t - (int64_t)o * kpad);
+            if (c < J.k_in) { if (J.grad_w) J.grad_w[(int64_t)o * J.ldw + c] += sv[e]; }
+            else if (c == J.k_in) { if (J.grad_b) J.grad_b[o] += sv[e]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+namespace {
+
+struct WpVariant { int tm, tn; };
+const WpVariant kVariants[6] = {{5, 1}, {1, 5}, {4, 1}, {1, 1}, {2, 4}, {2, 2}};
+
+// the variant whose tiles cover [n_out, k_in] with the fewest staged columns per operand row (ties: fewer tiles)
+void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
+    long best = -1;
+    for (int v = 0; v < 6; ++v) {
+        const int bo = 64 * kVariants[v].tm, bc = 64 * kVariants[v].tn;
+        const int to = (n_out + bo - 1) / bo, tc = (k_in + bc - 1) / bc;
+        const long cost = (long)to * tc * (bo + bc) * 64 + to * tc;
+        if (best < 0 || cost < best) { best = cost; *variant = v; *tiles_o = to; *tiles_c = tc; }
+    }
+}
+
+int wp_target_blocks() {
+    static const int v = [] { const char* e = getenv("MPNHIP_WP_BLOCKS"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 512; }();
+    return v;
+}
+
+// rows per chunk / chunks per batch of one job: ~wp_target_blocks() blocks per job, chunks of at least 256 rows
+void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, int* chunk, int* nsplit) {
+    if (rows_expected < 1) rows_expected = 1;
+    int want = wp_target_blocks() / (nbatch * tiles);
+    if (want < 1) want = 1;
+    int64_t c = (rows_expected + want - 1) / want;
+    if (c < 256) c = 256;
+    c = (c + WP_KB - 1) / WP_KB * WP_KB;
+    *chunk = (int)c;
+    *nsplit = (int)((rows_upper + c - 1) / c);
+    if (*nsplit < 1) *nsplit = 1;
+}
+
+thread_local WpBatch* g_wp = nullptr;
+
+size_t wp_lds_bytes() { return 3 * WP_KB * wp_pitch(320, 64); }   // the largest variant image (BO + BC = 384)
+
+}  // namespace
+
+bool wp_eligible(const WpProduct& p) {
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    return p.n_out >= 4 && p.k_in >= 4 && p.n_out % 4 == 0 && p.k_in % 4 == 0 && p.rows > 0 && p.rows < (int64_t)1 << 31 && p.nbatch >= 1 &&
+           al16(p.dZ) && al16(p.H) && p.ldz % 4 == 0 && p.ldh % 4 == 0 && p.z_bstride % 4 == 0 && p.h_bstride % 4 == 0 &&
+           // narrow products stay with gemm_tn_small_kernel (their rows are 16-72 bytes: nothing to stream)
+           !(p.n_out <= 32 && p.k_in <= 32);
+}
+
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged) {
+    int v, to, tc, chunk, nsplit;
+    wp_choose(n_out, k_in, &v, &to, &tc);
+    wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, &chunk, &nsplit);
+    return ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
+}
+
+void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats) {
+    b->tab.njobs = 0;
+    b->slab = slab;
+    b->slab_floats = slab_floats;
+    b->used = 0;
+    b->flops = 0.0;
+    b->nblocks = 0;
+    b->nred = 0;
+    g_wp = b;
+}
+bool wp_batch_open() { return g_wp != nullptr; }
+void wp_batch_abort() { g_wp = nullptr; }
+
+// records the n (1 or 2: the direction groups of one product) jobs, or none of them
+bool wp_batch_add(const WpProduct* ps, int n) {
+    WpBatch* b = g_wp;
+    if (!b || b->tab.njobs + n > WP_MAX_JOBS) return false;
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!wp_eligible(ps[i])) return false;
+        need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end);
+    }
+    if (b->used + need > b->slab_floats) return false;
+    for (int i = 0; i < n; ++i) {
+        const WpProduct& p = ps[i];
+        const bool ranged = p.row_begin || p.row_end;
+        WpJob& J = b->tab.job[b->tab.njobs];
+        J = WpJob{};
+        wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c);
+        wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, &J.chunk, &J.nsplit);
+        J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
+        J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows;
+        J.slab = b->slab + b->used;
+        J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
+        J.n_out = p.n_out; J.k_in = p.k_in; J.nbatch = p.nbatch;
+        J.block0 = b->nblocks;
+        J.red_block0 = b->nred;
+        b->nblocks += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
+        b->nred += (int)(((int64_t)p.n_out * tn_kpad(p.k_in) / 4 + 31) / 32);
+        b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged);
+        b->flops += 2.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * p.n_out * p.k_in;
+        ++b->tab.njobs;
+        count_path(PC_TN_PANEL);
+    }
+    return true;
+}
+bool wp_batch_add(const WpProduct& p) { return wp_batch_add(&p, 1); }
+
+int wp_batch_flush(hipStream_t s) {
+    WpBatch* b = g_wp;
+    g_wp = nullptr;
+    if (!b || b->tab.njobs == 0) return MPNHIP_OK;
+    static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)wp_lds_bytes()) == hipSuccess;
+    }();
+    (void)attr_set;
+    prof_begin(PROF_TN, s, b->flops);
+    {
+        hipEvent_t e0, e1;
+        if (prof_launch_events(&e0, &e1))
+            hipExtLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, e0, e1, 0, b->tab);
+        else
+            hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+    }
+    prof_end(PROF_TN, s);
+    MPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b->nred), dim3(256), 0, s, b->tab);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+}  // namespace mpnhip
