@@ -45,6 +45,8 @@ def parse():
                          "share ONE GPU -- a functional run of the N > 1 path where only one GPU is available, not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short labelled measurements of the other BASELINE.json configurations appended to the default line")
     return ap.parse_args()
 
 
@@ -67,50 +69,176 @@ def cpu_baseline(params, W, g, train, budget_s=20.0):
     from oracle import mpn_oracle as O
     nthreads = usable_cores()
     torch.set_num_threads(nthreads)
-    # bounded sample: graphs whose full pass would take minutes on the host (cfg-E: 12.7 TFLOP per forward) run a prefix of the
-    # message-passing steps and the rate is scaled to the full step count (every step costs the same; the encoder is counted once)
+    # bounded sample: graphs whose full pass would take minutes on the host (cfg-E: 12.7 TFLOP per forward) are timed with ONE and
+    # with TWO message-passing steps; every step costs the same, so t(L) = t_fixed + L t_step with t_step = t(2) - t(1) and
+    # t_fixed = t(1) - t_step (encoders, loss, the encoder's backward: counted once, not per step)
     L_full = int(params["num_enc_steps"])
     E_ = int(g["edge_index"].shape[1])
     d_ = int(params["encoder_feats_dict"]["node_out_dim"])
-    L_run = L_full
-    if L_full > 2 and E_ * d_ * d_ * L_full > 1e11:
-        L_run = 2
-        params = dict(params, num_enc_steps=L_run, num_class_steps=min(int(params["num_class_steps"]), L_run))
+    extrapolate = L_full > 2 and E_ * d_ * d_ * L_full > 1e11
+    params_full = params
+    if extrapolate:
+        params = dict(params_full, num_enc_steps=2, num_class_steps=min(int(params_full["num_class_steps"]), 2))
+        params_one = dict(params_full, num_enc_steps=1, num_class_steps=1)
     Wt = O.to_tensors(W, requires_grad=train)
     x, ei, ea = (torch.from_numpy(g[k]) for k in ("x", "edge_index", "edge_attr"))
     E = ei.shape[1]
     labels = (torch.arange(E) % 7 == 0).float()
 
-    def run():
+    def run(prm):
         if not train:
             with torch.no_grad():
-                O.forward(params, Wt, x, ei, ea)
+                O.forward(prm, Wt, x, ei, ea)
             return
-        _, logits, _, _ = O.forward(params, Wt, x, ei, ea, return_state=True)
+        _, logits, _, _ = O.forward(prm, Wt, x, ei, ea, return_state=True)
         lg = torch.stack([l.view(-1) for l in logits])
         pos = labels.sum()
         pw = (E - pos) / pos.clamp(min=1)
         loss = torch.nn.functional.binary_cross_entropy_with_logits(lg, labels.expand_as(lg), pos_weight=pw, reduction="sum") / E
-        torch.autograd.grad(loss, list(Wt.values()))
+        torch.autograd.grad(loss, list(Wt.values()), allow_unused=True)
 
-    times = []
-    t_start = time.time()
-    while len(times) < 3 and (len(times) < 2 or time.time() - t_start < budget_s):
-        t0 = time.perf_counter()
-        run()
-        times.append(time.perf_counter() - t0)
-    while time.time() - t_start < budget_s and len(times) < 11:
-        t0 = time.perf_counter()
-        run()
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
+    def sample(prm, budget):
+        times = []
+        t_start = time.time()
+        while len(times) < 3 and (len(times) < 2 or time.time() - t_start < budget):
+            t0 = time.perf_counter()
+            run(prm)
+            times.append(time.perf_counter() - t0)
+        while time.time() - t_start < budget and len(times) < 11:
+            t0 = time.perf_counter()
+            run(prm)
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times[1:])), len(times) - 1
+
     note = ""
-    if L_run != L_full:
-        note = "; %d of the %d message-passing steps were run and the time scaled by %d/%d" % (L_run, L_full, L_full, L_run)
-        t = t * L_full / L_run
+    if extrapolate:
+        t2, n2 = sample(params, budget_s * 0.6)
+        t1, n1 = sample(params_one, budget_s * 0.4)
+        t_step = max(t2 - t1, 0.0)
+        t_fixed = max(t1 - t_step, 0.0)
+        t = t_fixed + L_full * t_step
+        nruns = n1 + n2
+        note = ("; timed with 1 and 2 of the %d message-passing steps (%.0f / %.0f ms) and extrapolated as t_fixed + L t_step = %.0f + %d x %.0f ms"
+                % (L_full, t1 * 1e3, t2 * 1e3, t_fixed * 1e3, L_full, t_step * 1e3))
+    else:
+        t, nruns = sample(params, budget_s)
     return {"value": E / (t * 1e3), "unit": "edges/ms", "cores": nthreads, "kind": "port",
             "sample": "oracle/mpn_oracle.py %s (torch %s CPU ops, %d threads) on the same cfg graph, median of %d runs after 1 warm-up, %.0f ms each%s"
-                      % ("forward+backward" if train else "forward", torch.__version__, nthreads, len(times) - 1, t * 1e3, note)}
+                      % ("forward+backward" if train else "forward", torch.__version__, nthreads, nruns, t * 1e3, note)}
+
+
+def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=1, env=None, profile=True):
+    """One short, self-contained measurement of another BASELINE.json configuration (own model, own graph): ms per step,
+    edges/ms and the rooflines of its profiled kernels.  Used for the labelled objects appended to the default line; never
+    touches the headline's `value`."""
+    import types
+    from mpntrackseg_amd import capi, synth
+    from mpntrackseg_amd import train as mtrain
+    from mpntrackseg_amd.mpn import MOTMPNet, _prepared
+    old_env = {}
+    for k, v in (env or {}).items():
+        old_env[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        c = dict(synth.CONFIGS[cfg_name])
+        params = synth.model_params(c["d"], c["L"], agg)
+        W = synth.make_weights(params, seed=7)
+        if c.get("knn"):
+            g = synth.make_knn_graph(seed=seed, **c["knn"])
+            c["E"] = int(g["edge_index"].shape[1])
+        else:
+            g = synth.make_graph(c["N"], c["E"], seed=seed)
+        model = MOTMPNet(params)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+        model = model.to(dev)
+        x, ei, ea = (torch.from_numpy(g[k]).to(dev) for k in ("x", "edge_index", "edge_attr"))
+        E, N = c["E"], c["N"]
+        model.gemm_precision = precision
+        prec = model.operand_precision(E)
+
+        class Holder:
+            pass
+        holder = Holder()
+        _prepared(ei, N, holder)
+        if mode == "fwd":
+            model.eval()
+            model.keep_packed_weights = True
+
+            def step():
+                with torch.no_grad():
+                    return model.hot_path(x, ei, ea, holder=holder)
+        else:
+            stepper = mtrain.TrainStep(model, world_size=1)
+
+            def step():
+                return stepper(x, ei, ea, holder=holder)
+        lib = capi.load()
+        for _ in range(warmup):
+            step()
+        if profile:
+            lib.mpnhip_profile_enable(3)
+        capi.path_counters(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        counts = capi.path_counters(reset=True)
+        out = {"workload": "cfg-%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, %s" % (
+                   cfg_name, N, E, c["d"], c["L"], agg, "training step (fwd+bwd+Adam)" if mode == "train" else "inference forward"),
+               "precision": prec, "ms_per_step": ms, "value": E / ms, "unit": "edges/ms", "steps": steps, "warmup": warmup}
+        if profile:
+            extra = {}
+            for name, kind in (("chain_bwd", 2), ("weight_grad", 3)):
+                u, n, w = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_double(0)
+                capi.check(lib.mpnhip_profile_read_kind(kind, ctypes.byref(u), ctypes.byref(n), ctypes.byref(w)), "profile_read_kind")
+                extra[name] = (u.value, n.value, w.value)
+            gu, gc, au, ac, eu = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_float(0), ctypes.c_int(0), ctypes.c_float(0)
+            capi.check(lib.mpnhip_profile_read(ctypes.byref(gu), ctypes.byref(gc), ctypes.byref(au), ctypes.byref(ac), ctypes.byref(eu)), "profile_read")
+            lib.mpnhip_profile_enable(0)
+            prof = (gu.value, gc.value, au.value, ac.value, eu.value, extra, {k: v / float(steps) for k, v in counts.items()})
+            keep = []
+            chain = int(lib.mpnhip_edge_chain_active(model.c_model(keep, n_edges=E)))
+            ns = types.SimpleNamespace(precision=prec, config=cfg_name, agg=agg, steps=steps)
+            rf = rooflines(prof, c, ns, N, E, chain, mode)
+            for k, v in rf.items():
+                out[k] = {kk: vv for kk, vv in v.items() if kk not in ("what", "empty_event_pair_us", "naive_flop_equivalent_tflops")}
+        return out
+    finally:
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        torch.cuda.empty_cache()
+
+
+def extras(dev, budget_s=40.0):
+    """Short labelled measurements of the other BASELINE.json configurations: configs[4] (cfg-E, bf16-operand
+    forward, plus its aggregation kernel as a separate launch -- the HBM-streaming figure), the configs[2] / configs[3] stand-ins
+    (cfg-C / cfg-D training step, cfg-D forward).  Each is its own model and graph; a failure or the time budget drops the rest."""
+    plan = [("cfgD_fwd", ("D", "fwd", "auto", 200, 20), None),
+            ("cfgD_train", ("D", "train", "auto", 40, 10), None),
+            ("cfgC_train", ("C", "train", "auto", 30, 8), None),
+            ("cfgC_fwd", ("C", "fwd", "auto", 60, 10), None),
+            ("cfgE_bf16_fwd", ("E", "fwd", "bf16", 5, 2), None),
+            ("cfgE_bf16_fwd_unfused_aggregation", ("E", "fwd", "bf16", 3, 1), {"MPNHIP_NO_AGG_FUSION": "1"})]
+    res, t_start, cache = {}, time.time(), {}
+    for name, (cfg, mode, prec, steps, warm), env in plan:
+        if time.time() - t_start > budget_s:
+            res[name] = {"skipped": "time budget of the extra measurements (%.0f s) used up" % budget_s}
+            continue
+        try:
+            res[name] = measure_case(cfg, mode, prec, steps, warm, dev, env=env)
+            if env:
+                res[name]["env"] = env
+                # only the separately launched aggregation kernel's line is of interest here
+                res[name] = {k: v for k, v in res[name].items() if k in ("workload", "precision", "ms_per_step", "env", "roofline_aggregation")}
+        except Exception as exc:
+            res[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    res["seconds"] = time.time() - t_start
+    return res
 
 
 def main():
@@ -319,6 +447,47 @@ def main():
         except Exception as exc:   # the headline line above must survive a failure of the extra measurement
             model.gemm_precision = args.precision
             out["fp32_split" if other == "fp32_split" else "fp32_mfma"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if world > 1 and mode == "train":
+        # SURVEY.md section 8e "Reporting": the gradient all-reduce alone -- S bytes of the flat fp32 bucket, all-reduce(sum) as
+        # one collective, HIP events around 20 calls -- and the bus bandwidth 2 (n - 1) / n x S / t it corresponds to (ring
+        # all-reduce over xGMI: 7 links x ~153 GB/s per GPU; at these sizes, 1.2 - 19 MB, the collective is latency-bound)
+        import torch.distributed as dist
+        try:
+            flat = stepper.bucket.flat
+            keepg = flat.clone()
+            for _ in range(3):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = e0.elapsed_time(e1) / 20
+            flat.copy_(keepg)
+            t = torch.tensor([ar_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ar_ms = float(t.item())
+            S = flat.numel() * 4
+            out["allreduce_ms"] = ar_ms
+            out["allreduce_bytes"] = S
+            out["bus_gbs"] = 2.0 * (world - 1) / world * S / (ar_ms * 1e-3) / 1e9
+            out["allreduce_what"] = ("all-reduce(sum) of the flat fp32 gradient bucket alone (%d bytes, %s backend), mean of 20 calls, max over ranks; "
+                                     "in the step it runs as two buckets overlapped with the backward (train.TrainStep.allreduce_buckets)"
+                                     % (S, args.backend))
+        except Exception as exc:
+            out["allreduce_ms"] = None
+            out["allreduce_error"] = "%s: %s" % (type(exc).__name__, exc)
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "B" and not args.graph_file and args.mode == "auto":
+        # the other BASELINE.json configurations, short and clearly labelled (never part of `value`)
+        try:
+            del x, ei, ea
+            torch.cuda.empty_cache()
+            out["other_configs"] = extras(dev)
+        except Exception as exc:
+            out["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -331,12 +500,16 @@ def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
     tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
     if cfg_name == "E" and precision == "bf16":
         try:
-            return json.load(open(os.path.join(REPO, "profiles", "r02", "pmc_summary_cfgE.json"))).get(kernel_key, {}).get("hbm_bytes_per_launch")
+            for rnd in ("r03", "r02"):
+                pth = os.path.join(REPO, "profiles", rnd, "pmc_summary_cfgE.json")
+                if os.path.exists(pth):
+                    return json.load(open(pth)).get(kernel_key, {}).get("hbm_bytes_per_launch")
         except Exception:
-            return None
+            pass
+        return None
     if cfg_name != "B" or precision == "bf16":
         return None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", rnd, "pmc_summary.json" if precision == "fp32" else "pmc_summary_split.json")
         try:
             v = json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
@@ -457,7 +630,24 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                                          "ms_per_step": bu * c["L"] / 1e3}
             cand["roofline_bwd_chain"] = res["roofline_bwd_chain"]["ms_per_step"]
         tu, tn_, tw = extra.get("weight_grad", (0.0, 0, 0.0))
-        if tn_:
+        if tn_ and per_step.get("gemm_tn_panel", 0.0) > 0:
+            # MPNHIP_PREC_FP32_SPLIT: the row-panel kernel (csrc/wgrad_panel.hip): every operand row fetched once, six bf16 piece
+            # products per fp32 multiply-add -- bound by the operand stream.  The profile hook's `work` is the launch's operand
+            # bytes (rows x (n_out + k_in) x 4 over all jobs of the launch); launches differ (groups of 5 / 4 / 3 steps, the tail
+            # batch), so achieved = sum of bytes / sum of durations over the sampled launches.
+            launches = per_step.get("wgrad_panel_launches", 0.0) or float(tn_) / max(args.steps, 1)
+            ach = tw / (tu * 1e-6) / 1e9
+            # the same launches' products as fp32-equivalent flops (12 steps x edge-level + node-level + hoisted + encoder)
+            res["roofline_weight_grad"] = {"bound": "hbm", "kernel": "wgrad_panel_kernel: dW += dZ^T H for all products of a group of steps in one launch "
+                                                                     "(row-panel blocks, three-piece bf16 operands split in the loader, ds_read_b64_tr_b16 "
+                                                                     "operands, v_mfma_f32_32x32x16_bf16), side stream",
+                                           "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": tu, "launches": tn_,
+                                           "traffic": pmc_traffic("wgrad_panel", args.config, args.precision),
+                                           "algorithmic_bytes": tw, "launches_per_step": launches, "ms_per_step": tu * launches / 1e3}
+            if res["roofline_weight_grad"]["traffic"]:
+                res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / tw
+            cand["roofline_weight_grad"] = res["roofline_weight_grad"]["ms_per_step"]
+        elif tn_:
             per = per_step.get("gemm_tn_mfma", 0.0)
             ach = tw / (tu * 1e-6) / 1e12
             res["roofline_weight_grad"] = {"bound": "mfma", "kernel": "gemm_tn_kernel: dW += dZ^T H over the steps of a group (fp32 v_mfma_f32_32x32x2_f32), "

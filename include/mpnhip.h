@@ -292,6 +292,12 @@ int mpnhip_avgpool(const float* x, int64_t rows, int hw, float* y, void* stream)
  * moment buffers (zero before step 1); step = 1, 2, ... counts the calls. */
 int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same, skipped as a whole when *skip_flag (device float, may be NULL) is non-zero.  Data-parallel training (one graph per
+ * rank, scripts/train.py:65-77 executed in space): every rank adds "my graph's edge_index left [0, N)" (the reference's
+ * IndexError, mpn.py:69) to one spare element of the gradient all-reduce; with the reduced element as skip_flag no rank steps
+ * on gradients of a clamped graph, without a host read on the ranks whose own graph is fine. */
+int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, const float* skip_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph construction on the device: what MOTGraph.construct_graph_object

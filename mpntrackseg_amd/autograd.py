@@ -54,7 +54,11 @@ class _HotPath(torch.autograd.Function):
         xd = capi.f32c(x.detach())
         ead = capi.f32c(edge_attr.detach())
         from . import torch_ops
-        ctx.via_ops = torch_ops.available()
+        # eval-mode BatchNorm / Dropout (mlp.py: fast_path False): the dispatcher ops take the parameters as they are, which would
+        # drop the BatchNorm fold -- the ctypes path folds it in the forward (MLP.effective_linears) and refuses the backward
+        from .mlp import MLP
+        plain = all(m_.fast_path for m_ in model.modules() if isinstance(m_, MLP))
+        ctx.via_ops = torch_ops.available() and plain
         if ctx.via_ops:
             # through the dispatcher (csrc/torch_ops.cpp): the same C-ABI calls, outputs allocated by the op
             ctx.spec, _ = torch_ops.model_spec(model, n_edges=ead.shape[0])

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mpnhip_attention_aggregate_backward": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
     "mpnhip_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
+    "mpnhip_adam_step_guarded": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P, _P]),
     "mpnhip_time_valid_conn_workspace_bytes": (_Z, [_I]),
     "mpnhip_time_valid_conn_count": (_I, [_P, _I, _L, _P, _P, _Z, _P]),
     "mpnhip_time_valid_conn_fill": (_I, [_P, _I, _L, _P, _L, _P, _P]),

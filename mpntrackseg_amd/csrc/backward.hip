@@ -190,7 +190,9 @@ struct BwdPlan {
     float* dZfl[MPNHIP_MAX_LAYERS];     // flow MLP layer i:   [L][E, out_i]
     float* dZed[MPNHIP_MAX_LAYERS];     // edge MLP layer i:   [L][E, out_i]  (last layer: the masked dE_s)
     float* dZcl[MPNHIP_MAX_LAYERS];     // classifier layer i: [L][E, out_i]  (i < n-1; the last one is grad_logits)
-    float* T[2];                        // encoder chain scratch [max(E,N), max encoder width]
+    float* T[3];                        // edge-encoder chain scratch [E, max encoder width], rotating (layer i -> buffer (n - 1 - i) % 3)
+    float* Tn[3];                       // node-encoder chain scratch [N, max encoder width]: chains of <= 3 layers never overwrite a
+                                        // dZ block, so their weight-gradient products may run later, on another stream
     int t_width;                        // that width (floats per row)
     // zero-padded copies of the per-edge weights for the fused backward chain (native [n][k] orientation)
     float* wf2p[2]; float* wfep[2]; float* wc1p; float* w2p; float* w1ep;
@@ -200,6 +202,8 @@ struct BwdPlan {
     size_t slab_floats_per_group;
     float* slab_wp;                     // slabs of a batch of row-panel products (all jobs of one group of steps)
     size_t slab_wp_floats;
+    float* slab_tail;                   // slabs of the tail batch (hoisted shares + encoder layers)
+    size_t slab_tail_floats;
     size_t total;
 };
 
@@ -241,9 +245,10 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     for (int i = 0; i < m.flow_in.n_layers; ++i) p.dZfl[i] = a.f(L * E * m.flow_in.out_dims[i]);
     for (int i = 0; i < m.edge.n_layers; ++i) p.dZed[i] = a.f(L * E * m.edge.out_dims[i]);
     for (int i = 0; i + 1 < m.classifier.n_layers; ++i) p.dZcl[i] = a.f(L * E * m.classifier.out_dims[i]);
-    int64_t rows = E > N ? E : N;
     int mw = enc_maxw(m, d);
-    for (int i = 0; i < 2; ++i) p.T[i] = a.f((size_t)rows * mw);
+    if (mw < 52) mw = 52;   // (the fused reference edge encoder keeps dz2 | dz1 | dz0 side by side in T[0])
+    for (int i = 0; i < 3; ++i) p.T[i] = a.f((size_t)E * mw);
+    for (int i = 0; i < 3; ++i) p.Tn[i] = a.f((size_t)N * mw);
     p.t_width = (int)mw;
     {
         const size_t HE = pad32(d.he), DE = pad32(d.de), HN = pad32(d.hn), DN = pad32(d.dn);
@@ -266,7 +271,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     upd(tn_slab_floats(d.dn, 2 * d.dn, N, (int)L));
     upd(tn_slab_floats(d.pw, d.kx, N, (int)L));
     // the same products in the row-panel form (MPNHIP_PREC_FP32_SPLIT): alone on the caller's stream ...
-    auto updw = [&](int n_out, int k_in, int64_t rows, int nb) { if (rows > 0) upd((wp_slab_floats(n_out, k_in, rows, nb, false) + 1) / 2); };
+    auto updw = [&](int n_out, int k_in, int64_t rows, int nb) { if (rows > 0) upd((wp_slab_floats(n_out, k_in, rows, nb, false, false) + 1) / 2); };
     for (int i = 0; i < m.enc_node.n_layers; ++i) updw(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N, 1);
     for (int i = 0; i < m.enc_edge.n_layers; ++i) updw(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E, 1);
     updw(d.he, d.de, E, 1);
@@ -279,7 +284,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     size_t wpmax = 0;
     for (int nb = 1; nb <= (int)L; ++nb) {
         size_t t = 0;
-        auto addw = [&](int n_out, int k_in, int64_t rows, bool ranged) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, nb, ranged); };
+        auto addw = [&](int n_out, int k_in, int64_t rows, bool ranged) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, nb, ranged, true); };
         addw(d.dn, 2 * d.dn, N, false);
         for (int i = 1; i < m.flow_in.n_layers; ++i) { addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); }
         addw(d.hn, d.de, E, true); addw(d.hn, d.de, E, true);
@@ -291,6 +296,16 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     }
     p.slab_wp_floats = wpmax;
     p.slab_wp = a.f(wpmax);
+    {   // the tail batch: hoisted shares + encoder layers
+        size_t t = 0;
+        auto addt = [&](int n_out, int k_in, int64_t rows) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, 1, false, true); };
+        addt(d.pw, d.dn, N);
+        addt(d.he, d.de, E);
+        for (int i = 0; i < m.enc_node.n_layers; ++i) addt(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N);
+        for (int i = 0; i < m.enc_edge.n_layers; ++i) addt(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E);
+        p.slab_tail_floats = t;
+        p.slab_tail = a.f(t);
+    }
     p.total = a.off;
     if (out) *out = p;
     return p.total;
@@ -315,19 +330,19 @@ static thread_local bool g_wgrad_split = false;
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
                        const int* h_idx, int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2],
                        const RowRange rr[2], int64_t rows, int nbatch, hipStream_t s) {
-    if (g_wgrad_split && !dz_idx && !h_idx && !H2.p && rows > 0) {
+    if (g_wgrad_split && (!dz_idx || n_out == 1) && !h_idx && !H2.p && rows > 0) {
         // MPNHIP_PREC_FP32_SPLIT: the row-panel kernel (wgrad_panel.hip) -- recorded into the open batch (all products of a group of
         // steps: one product launch + one slab-sum launch), or run as a batch of its own
         WpProduct wp[2];
         for (int q = 0; q < ngroups; ++q)
             wp[q] = {dZ.p, dZ.ld, dZ.bstride, H.p, H.ld, H.bstride, rr ? rr[q].begin : nullptr, rr ? rr[q].end : nullptr, rows, nbatch,
-                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr};
+                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx};
         if (wp_batch_open()) {
             if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
         } else {
             WpBatch own;
             WpBatchGuard guard;
-            wp_batch_begin(&own, slab_base, 2 * p.slab_floats_per_group);
+            wp_batch_begin(&own, slab_base, 2 * p.slab_floats_per_group, false);
             if (wp_batch_add(wp, ngroups)) return wp_batch_flush(s);
             wp_batch_abort();
         }
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(256) void k_edge_encoder_bwd(const float* __restric
     }
 }
 
-static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, float* const* hidden, const float** dz, int* cur_buf,
+static int mlp_tail_backward(const BwdPlan& p, float* const* T, const mpnhip_mlp& m0, float* const* hidden, const float** dz, int* cur_buf,
                              int64_t rows, hipStream_t s) {
     for (int i = m0.n_layers - 1; i >= 1; --i) {
         const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
@@ -471,10 +486,10 @@ static int mlp_tail_backward(const BwdPlan& p, const mpnhip_mlp& m0, float* cons
         MPN_TRY(weight_grad(p, p.slab, 1, {*dz, n_out, 0}, nullptr, {hidden[i - 1], k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out,
                             k_in, gw, k_in, gb, nullptr, rows, 1, s));
         const float* Wq[2] = {m0.weight[i], nullptr};
-        float* dst = p.T[*cur_buf ^ 1];
+        float* dst = T[(*cur_buf + 1) % 3];
         MPN_TRY(act_grad(1, *dz, n_out, nullptr, Wq, k_in, n_out, k_in, dst, k_in, nullptr,
                          k_in != 1 ? hidden[i - 1] : nullptr, k_in, 0, nullptr, rows, s));
-        *cur_buf ^= 1;
+        *cur_buf = (*cur_buf + 1) % 3;
         *dz = dst;
     }
     return MPNHIP_OK;
@@ -667,7 +682,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         // (calls are serialised on `st`, so successive groups may share the slab region)
         WpBatch wpb;
         WpBatchGuard wpg;
-        if (g_wgrad_split) wp_batch_begin(&wpb, p.slab_wp, p.slab_wp_floats);
+        if (g_wgrad_split) wp_batch_begin(&wpb, p.slab_wp, p.slab_wp_floats, true);
         auto finish = [&]() -> int { return wp_batch_open() ? wp_batch_flush(st) : MPNHIP_OK; };
         {   // node update Linear
             float* gw[2] = {m.node.grad_weight[0], nullptr};
@@ -938,6 +953,32 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         }
     }
 
+    // The last group of steps goes to the side stream as soon as the loop is over (in order behind the earlier groups), under the
+    // sums / products of the hoisted shares and the encoder's backward below.
+    const int last_n = glo(ngroups - 2 < 0 ? -1 : ngroups - 2);
+    if (L > 0 && forked) {
+        MPN_HIP(hipEventRecord(side->ready, s));
+        MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
+        MPN_TRY(mp_weight_grads(0, last_n, side->stream, p.slab_side));
+    }
+    // MPNHIP_PREC_FP32_SPLIT with a side stream: the weight-gradient products of this tail (hoisted shares, encoder layers) are
+    // leaves -- nothing on the caller's stream reads their results -- so they are RECORDED here and run as one batch on the side
+    // stream behind the last group, while the caller's stream goes on with the activation-gradient chain (the encoder chains keep
+    // every dZ block of <= 3 layers: BwdPlan::T / Tn).  With MPNHIP_BWD_DEFER_SIDE_JOIN the encoder's products stay on the caller's
+    // stream: there the side stream's order must end with the message-passing modules' gradients (a trainer puts their all-reduce
+    // behind it while the encoder's backward still runs).
+    WpBatch tailb;
+    WpBatchGuard tail_guard;
+    const bool defer_tail = g_wgrad_split && L > 0 && forked && !getenv("MPNHIP_NO_TAIL_DEFER");
+    const bool defer_encoder = defer_tail && !(flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && m.enc_node.n_layers <= 3 && m.enc_edge.n_layers <= 3;
+    if (defer_tail) wp_batch_begin(&tailb, p.slab_tail, p.slab_tail_floats, true);
+    // runs what was recorded (on the side stream, behind everything the caller's stream has enqueued so far) and closes the batch
+    auto flush_tail = [&]() -> int {
+        if (!wp_batch_open()) return MPNHIP_OK;
+        MPN_HIP(hipEventRecord(side->ready, s));
+        MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
+        return wp_batch_flush(side->stream);
+    };
     if (hoist_x) {
         const int64_t n4 = N * pw / 4;
         hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dP, N * pw, (int)L, n4, p.dPsum);
@@ -976,17 +1017,23 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         }
         return MPNHIP_OK;
     };
+    bool unpack_pending = false;
     if (L > 0) {
-        // the last group of steps.  With a side stream it goes there as well (in order behind the earlier groups) and
-        // runs under the encoder's backward below, which touches none of its buffers; the join is at the very end.
-        const int last_n = glo(ngroups - 2 < 0 ? -1 : ngroups - 2);
         if (forked) {
-            MPN_HIP(hipEventRecord(side->ready, s));
-            MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
-            MPN_TRY(mp_weight_grads(0, last_n, side->stream, p.slab_side));
             // (the unpacking follows on the side stream as well: with it every gradient of the message-passing modules and of
             // the classifier is final IN SIDE-STREAM ORDER, while the caller's stream still runs the encoder's backward)
-            MPN_TRY(unpack_node_grads(side->stream));
+            if (defer_encoder) {
+                unpack_pending = true;   // after the tail batch (the hoisted x0 product adds into gWnode), at the end
+            } else {
+                // the hoisted products: recorded -> run them now on the side stream; run on the caller's stream -> order the
+                // unpacking behind them
+                if (defer_tail) MPN_TRY(flush_tail());
+                else {
+                    MPN_HIP(hipEventRecord(side->ready, s));
+                    MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
+                }
+                MPN_TRY(unpack_node_grads(side->stream));
+            }
         } else {
             MPN_TRY(mp_weight_grads(0, last_n, s, p.slab));
             MPN_TRY(unpack_node_grads(s));
@@ -1027,12 +1074,10 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         int cur = 0;
         if (N > 0) {
             if (en.out_dims[en.n_layers - 1] != 1) {
-                MPN_TRY(relu_mask(p.dX0, x0, p.T[0], (int64_t)xs, s));
-                dz = p.T[0];
-            } else {
-                cur = 1;  // keep T[0] free: the chain below writes T[cur ^ 1] first
+                MPN_TRY(relu_mask(p.dX0, x0, p.Tn[0], (int64_t)xs, s));
+                dz = p.Tn[0];
             }
-            MPN_TRY(mlp_tail_backward(p, en, hid, &dz, &cur, N, s));
+            MPN_TRY(mlp_tail_backward(p, p.Tn, en, hid, &dz, &cur, N, s));
             float* gw[2] = {en.grad_weight[0], nullptr};
             float* gb[2] = {en.grad_bias[0], nullptr};
             MPN_TRY(weight_grad(p, p.slab, 1, {dz, en.out_dims[0], 0}, nullptr, {x, en.in_dim, 0}, {nullptr, 0, 0}, en.in_dim, nullptr,
@@ -1078,10 +1123,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             if (ee.out_dims[ee.n_layers - 1] != 1) {
                 MPN_TRY(relu_mask(p.dE0, e0, p.T[0], (int64_t)es, s));
                 dz = p.T[0];
-            } else {
-                cur = 1;
             }
-            MPN_TRY(mlp_tail_backward(p, ee, hid, &dz, &cur, E, s));
+            MPN_TRY(mlp_tail_backward(p, p.T, ee, hid, &dz, &cur, E, s));
         }
         if (E > 0) {
             float* gw[2] = {ee.grad_weight[0], nullptr};
@@ -1095,6 +1138,16 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                                  ee.in_dim, g.perm, nullptr, 0, 0, nullptr, E, s));
             }
         }
+    }
+    if (unpack_pending) {
+        MPN_TRY(flush_tail());
+        MPN_TRY(unpack_node_grads(side->stream));
+    }
+    if ((flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && !forked && side) {
+        // nothing was forked (no side stream work: few steps, or the fork was not possible), but the caller was promised that the
+        // side stream's order ends with the message-passing modules' gradients: order it behind the caller's stream
+        MPN_HIP(hipEventRecord(side->ready, s));
+        MPN_HIP(hipStreamWaitEvent(side->stream, side->ready, 0));
     }
     if (L > 0 && forked) {
         // join: every "+=" of the side stream's groups (and the unpacking) is in.  MPNHIP_BWD_DEFER_SIDE_JOIN leaves it to the

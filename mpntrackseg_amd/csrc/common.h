@@ -131,6 +131,7 @@ int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 struct WpJob {             // one product (one direction group of it), as the kernels see it
     const float* dZ;       // [rows, n_out], leading dim ldz; batch b at dZ + b * z_bstride
     const float* H;        // [rows, k_in], leading dim ldh
+    const int* dz_idx;     // optional row gather of dZ (n_out == 1 only: wp_block_vec)
     const int* row_begin;  // device ints (nullptr -> 0 / m_static)
     const int* row_end;
     float* slab;           // [nbatch * nsplit][n_out][tn_kpad(k_in)]
@@ -153,11 +154,13 @@ struct WpProduct {         // host-side description of one product
     int64_t rows;          // rows of one batch (upper bound when ranged)
     int nbatch, n_out, k_in;
     float* grad_w; int64_t ldw; float* grad_b;
+    const int* dz_idx;     // optional row gather of dZ; n_out == 1 only
 };
-struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops; int nblocks, nred; };
+struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched; };
 bool wp_eligible(const WpProduct& p);
-size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged);
-void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats);   // opens b for the calling thread
+// (batched: the job shares its launch with the other products of a group of steps -- fewer row chunks per job)
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched);
+void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched);   // opens b for the calling thread
 bool wp_batch_open();
 bool wp_batch_add(const WpProduct& p);       // true: recorded (a batch is open, the product is eligible, table and slab space suffice)
 bool wp_batch_add(const WpProduct* ps, int n);   // all n (the direction groups of one product) or none
@@ -268,7 +271,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_COUNT
 };
 void count_path(int id);
 

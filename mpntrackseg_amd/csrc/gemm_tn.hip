@@ -510,7 +510,7 @@ using namespace mpnhip;
 extern "C" size_t mpnhip_weight_grad_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch) {
     if (n_out < 1 || k_in < 1 || rows < 0) return 0;
     const size_t a = tn_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch);
-    const size_t b = rows > 0 ? wp_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch, false) : 0;   // (MPNHIP_PREC_FP32_SPLIT form)
+    const size_t b = rows > 0 ? wp_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch, false, false) : 0;   // (MPNHIP_PREC_FP32_SPLIT form)
     return align_up((a > b ? a : b) * sizeof(float), 256) + 256;
 }
 
@@ -541,10 +541,10 @@ static int weight_grad_run(const TnArgs& a, int precision, void* workspace, size
     if (precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL")) {
         const TnGroup& g = a.g[0];
         WpProduct p = {g.dZ, g.ldz, g.z_bstride, g.H, g.ldh, g.h_bstride, nullptr, nullptr, a.m_upper, a.nbatch, a.n_out, a.k_in,
-                       g.grad_w, g.ldw, g.grad_b};
+                       g.grad_w, g.ldw, g.grad_b, nullptr};
         WpBatch b;
         WpBatchGuard guard;
-        wp_batch_begin(&b, g.slab, (workspace_bytes - 256) / sizeof(float));
+        wp_batch_begin(&b, g.slab, (workspace_bytes - 256) / sizeof(float), false);
         if (wp_batch_add(p)) return wp_batch_flush(s);
         wp_batch_abort();
     }

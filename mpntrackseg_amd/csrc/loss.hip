@@ -189,9 +189,10 @@ extern "C" int mpnhip_step_metrics(const void* graph_buf, int n_nodes, int64_t n
 namespace mpnhip {
 namespace {
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ skip) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (skip && *skip != 0.f) return;   // (a rank of the job reported an invalid graph: nobody steps -- mpnhip_adam_step_guarded)
     // torch.optim.Adam (not AdamW): L2 decay joins the gradient; m, v exponential averages; bias corrections
     const float pi = p[i];
     const float gi = g[i] + wd * pi;
@@ -205,8 +206,17 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 }  // namespace
 }  // namespace mpnhip
 
+extern "C" int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int step, const float* skip_flag,
+                                        void* stream_);
 extern "C" int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int step, void* stream_) {
+    return mpnhip_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream_);
+}
+
+extern "C" int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int step, const float* skip_flag,
+                                        void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MPN_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size / step");
     if (n == 0) return MPNHIP_OK;
@@ -214,7 +224,7 @@ extern "C" int mpnhip_adam_step(float* params, const float* grads, float* exp_av
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(mpnhip::k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, skip_flag);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -531,11 +531,13 @@ __global__ __launch_bounds__(256) void k_node_step32_bwd(NodeStepBwdArgs a) {
 int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldwx, const float* x_prev, const float* Wu, float* dZn,
                     float* dAGG, hipStream_t stream) {
     if (N <= 0) return MPNHIP_OK;
-    if (pw > 1088) { set_error("node_step32_bwd: projection width too large"); return MPNHIP_ERR_UNSUPPORTED; }
     if ((ldwx & 3) || (((uintptr_t)Wx | (uintptr_t)Wu) & 15)) { set_error("node_step32_bwd: weights must be 16-byte aligned"); return MPNHIP_ERR_ARG; }
+    // projection columns + node-update weights + the block's dP rows: 63.5 KB at the reference's pw = 384; the launch is made
+    // without raising the kernel's dynamic-LDS limit, so anything above 64 KB is refused here (the caller's gate is pw <= 384)
+    const size_t smem = ((size_t)pw * 32 + 32 * 64 + NSB_NODES * (size_t)pw + 2 * 128 + NSB_NODES * 32) * sizeof(float);
+    if (pw < 1 || smem > 65536) { set_error("node_step32_bwd: projection width %d needs %zu bytes of LDS (> 64 KB)", pw, smem); return MPNHIP_ERR_UNSUPPORTED; }
     NodeStepBwdArgs a = {dP, N, pw, Wx, ldwx, x_prev, Wu, dZn, dAGG};
     count_path(PC_NODE_STEP32_BWD);
-    const size_t smem = ((size_t)pw * 32 + 32 * 64 + NSB_NODES * (size_t)pw + 2 * 128 + NSB_NODES * 32) * sizeof(float);   // <= 160 KB at pw = 1088
     hipLaunchKernelGGL(k_node_step32_bwd, dim3((unsigned)((N + NSB_NODES - 1) / NSB_NODES)), dim3(256), smem, stream, a);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;

@@ -320,6 +320,48 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 #undef WP_LOAD
 #undef WP_WAIT
 
+// n_out == 1, dZ rows optionally gathered (the classifier's output layer: dZ = grad_logits, one float per edge in ORIGINAL edge
+// order, read through the sort permutation): out[c] = sum_r z[idx[r]] H[r][c] with plain fp32 FMAs -- k_in / 4 threads per row,
+// 256 / (k_in / 4) row lanes whose partial sums meet in LDS in a fixed order.  Rides in the products' launch instead of three
+// small launches of its own per group of steps.
+__device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char* lds) {
+    const int tid = threadIdx.x;
+    const int rb = J.row_begin ? *J.row_begin : 0;
+    const int re = J.row_end ? *J.row_end : (int)J.m_static;
+    const int batch = by / J.nsplit, ci = by - batch * J.nsplit;
+    const int r0 = rb + ci * J.chunk;
+    int r1 = r0 + J.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;
+    const int kc = J.k_in, ng = kc >> 2, rl = WP_NT / ng;
+    const int rlane = tid / ng, cg = tid - rlane * ng;
+    const float* z = J.dZ + (int64_t)batch * J.z_bstride;
+    const int* zi = J.dz_idx;
+    const float* h = J.H + (int64_t)batch * J.h_bstride + 4 * cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bs = 0.f;
+    if (rlane < rl) {
+        for (int r = r0 + rlane; r < r1; r += rl) {
+            const float zz = z[(int64_t)(zi ? zi[r] : r) * J.ldz];
+            const float4 hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+            acc.x = fmaf(zz, hv.x, acc.x); acc.y = fmaf(zz, hv.y, acc.y); acc.z = fmaf(zz, hv.z, acc.z); acc.w = fmaf(zz, hv.w, acc.w);
+            bs += zz;
+        }
+    }
+    float* part = reinterpret_cast<float*>(lds);   // [rl][kc + 4]
+    const int pitch = kc + 4;
+    if (rlane < rl) {
+        *reinterpret_cast<float4*>(part + rlane * pitch + 4 * cg) = acc;
+        if (cg == 0) part[rlane * pitch + kc] = bs;
+    }
+    __syncthreads();
+    if (tid <= kc) {
+        float sum = 0.f;
+        for (int r = 0; r < rl; ++r) sum += part[r * pitch + tid];
+        J.slab[(size_t)by * tn_kpad(kc) + tid] = (ci & 1) ? -sum : sum;   // (odd chunks are subtracted by the slab sum)
+    }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
@@ -337,6 +379,7 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
         case 2: wp_block<4, 1>(J, tile, by, wp_lds); break;
         case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
         case 4: wp_block<2, 4>(J, tile, by, wp_lds); break;
+        case 6: wp_block_vec(J, by, wp_lds); break;
         default: wp_block<2, 2>(J, tile, by, wp_lds); break;
     }
 }
@@ -410,6 +453,7 @@ const WpVariant kVariants[6] = {{5, 1}, {1, 5}, {4, 1}, {1, 1}, {2, 4}, {2, 2}};
 
 // the variant whose tiles cover [n_out, k_in] with the fewest staged columns per operand row (ties: fewer tiles)
 void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
+    if (n_out == 1) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
     long best = -1;
     for (int v = 0; v < 6; ++v) {
         const int bo = 64 * kVariants[v].tm, bc = 64 * kVariants[v].tn;
@@ -419,15 +463,19 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
     }
 }
 
-int wp_target_blocks() {
-    static const int v = [] { const char* e = getenv("MPNHIP_WP_BLOCKS"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 512; }();
-    return v;
+// blocks wanted per job: a job alone needs enough row chunks to fill the chip (2 blocks per CU); the jobs of a batch run side by
+// side in one launch, and every extra chunk costs a slab (written, then read by the slab sum: at 512 chunks per job the slabs of a
+// cfg-B group were 30 % of the launch's traffic)
+int wp_target_blocks(bool batched) {
+    static const int alone = [] { const char* e = getenv("MPNHIP_WP_BLOCKS"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 512; }();
+    static const int shared = [] { const char* e = getenv("MPNHIP_WP_BLOCKS_BATCH"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 192; }();
+    return batched ? shared : alone;
 }
 
 // rows per chunk / chunks per batch of one job: ~wp_target_blocks() blocks per job, chunks of at least 256 rows
-void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, int* chunk, int* nsplit) {
+void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit) {
     if (rows_expected < 1) rows_expected = 1;
-    int want = wp_target_blocks() / (nbatch * tiles);
+    int want = wp_target_blocks(batched) / (nbatch * tiles);
     if (want < 1) want = 1;
     int64_t c = (rows_expected + want - 1) / want;
     if (c < 256) c = 256;
@@ -445,25 +493,30 @@ size_t wp_lds_bytes() { return 3 * WP_KB * wp_pitch(320, 64); }   // the largest
 
 bool wp_eligible(const WpProduct& p) {
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-    return p.n_out >= 4 && p.k_in >= 4 && p.n_out % 4 == 0 && p.k_in % 4 == 0 && p.rows > 0 && p.rows < (int64_t)1 << 31 && p.nbatch >= 1 &&
+    if (p.rows <= 0 || p.rows >= (int64_t)1 << 31 || p.nbatch < 1 || !p.dZ || !p.H) return false;
+    if (p.n_out == 1)   // wp_block_vec: gathered dZ allowed
+        return p.k_in >= 4 && p.k_in % 4 == 0 && p.k_in <= 64 && al16(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0;
+    return !p.dz_idx && p.n_out >= 4 && p.k_in >= 4 && p.n_out % 4 == 0 && p.k_in % 4 == 0 &&
            al16(p.dZ) && al16(p.H) && p.ldz % 4 == 0 && p.ldh % 4 == 0 && p.z_bstride % 4 == 0 && p.h_bstride % 4 == 0 &&
            // narrow products stay with gemm_tn_small_kernel (their rows are 16-72 bytes: nothing to stream)
            !(p.n_out <= 32 && p.k_in <= 32);
 }
 
-size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged) {
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched) {
     int v, to, tc, chunk, nsplit;
     wp_choose(n_out, k_in, &v, &to, &tc);
-    wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, &chunk, &nsplit);
+    wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit);
     return ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
 }
 
-void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats) {
+void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched) {
+    b->batched = batched;
     b->tab.njobs = 0;
     b->slab = slab;
     b->slab_floats = slab_floats;
     b->used = 0;
     b->flops = 0.0;
+    b->bytes = 0.0;
     b->nblocks = 0;
     b->nred = 0;
     g_wp = b;
@@ -478,7 +531,7 @@ bool wp_batch_add(const WpProduct* ps, int n) {
     size_t need = 0;
     for (int i = 0; i < n; ++i) {
         if (!wp_eligible(ps[i])) return false;
-        need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end);
+        need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end, b->batched);
     }
     if (b->used + need > b->slab_floats) return false;
     for (int i = 0; i < n; ++i) {
@@ -487,9 +540,9 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         WpJob& J = b->tab.job[b->tab.njobs];
         J = WpJob{};
         wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c);
-        wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, &J.chunk, &J.nsplit);
+        wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
-        J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows;
+        J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows; J.dz_idx = p.dz_idx;
         J.slab = b->slab + b->used;
         J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
         J.n_out = p.n_out; J.k_in = p.k_in; J.nbatch = p.nbatch;
@@ -497,8 +550,9 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         J.red_block0 = b->nred;
         b->nblocks += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
         b->nred += (int)(((int64_t)p.n_out * tn_kpad(p.k_in) / 4 + 31) / 32);
-        b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged);
+        b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged, b->batched);
         b->flops += 2.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * p.n_out * p.k_in;
+        b->bytes += 4.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * (p.n_out + p.k_in);
         ++b->tab.njobs;
         count_path(PC_TN_PANEL);
     }
@@ -515,7 +569,8 @@ int wp_batch_flush(hipStream_t s) {
                                    (int)wp_lds_bytes()) == hipSuccess;
     }();
     (void)attr_set;
-    prof_begin(PROF_TN, s, b->flops);
+    count_path(PC_TN_PANEL_LAUNCH);
+    prof_begin(PROF_TN, s, b->bytes);   // (HBM-bound by design: the hook's work figure is the launch's operand bytes)
     {
         hipEvent_t e0, e1;
         if (prof_launch_events(&e0, &e1))

@@ -60,8 +60,10 @@ class FlatBucket:
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_params = torch.zeros(n, dtype=torch.float32, device=dev)
+        # four spare elements behind the gradients: [n] carries a rank's "invalid graph" flag through the all-reduce (TrainStep)
+        self.n = n
+        self.flat = torch.zeros(n + 4, dtype=torch.float32, device=dev)
+        self.flat_params = torch.zeros(n + 4, dtype=torch.float32, device=dev)
         self.views = {}
         self.offsets = dict((id(p), off) for p, off in zip(self.params, offs))
         for p, off in zip(self.params, offs):
@@ -87,15 +89,18 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(bucket.flat_params)
         self.t = 0
 
-    def step(self):
+    def step(self, guarded=False):
+        """``guarded``: skip the update (on the device, no host read) when the bucket's spare element ``flat[n]`` is non-zero."""
         import ctypes as C
         self.t += 1
         capi._weights_epoch[0] += 1   # raw-pointer update: invalidates packed weight images kept by MOTMPNet.hot_path
         b = self.bucket
-        capi.check(capi.load().mpnhip_adam_step(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
-                                                capi.ptr(self.exp_avg_sq), b.flat.numel(), C.c_float(self.lr),
-                                                C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                                                C.c_float(self.weight_decay), self.t, capi.stream_ptr()), "mpnhip_adam_step")
+        skip = C.c_void_p(b.flat.data_ptr() + 4 * b.n) if guarded else None
+        capi.check(capi.load().mpnhip_adam_step_guarded(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
+                                                        capi.ptr(self.exp_avg_sq), b.n, C.c_float(self.lr),
+                                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                                        C.c_float(self.weight_decay), self.t, skip, capi.stream_ptr()),
+                   "mpnhip_adam_step")
 
 
 class TrainStep:
@@ -128,8 +133,14 @@ class TrainStep:
             if side_pending:
                 if self._side is None:
                     self._side = torch.cuda.ExternalStream(capi.load().mpnhip_side_stream(), device=flat.device)
+                # evidence of the overlap (tests, bench): when the side stream reached the message-passing bucket's collective, and
+                # when the caller's stream finished the encoder's backward
+                self.ev_mp_ready = torch.cuda.Event(enable_timing=True)
+                self.ev_main_done = torch.cuda.Event(enable_timing=True)
                 with torch.cuda.stream(self._side):
+                    self.ev_mp_ready.record()
                     w_mp = dist.all_reduce(flat[k:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self.ev_main_done.record()
                 w_enc = dist.all_reduce(flat[:k], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) if k else None
                 w_mp.wait()
                 if w_enc is not None:
@@ -161,9 +172,25 @@ class TrainStep:
         lib = capi.load()
         defer = self.world_size > 1 and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))
         native_backward(model, g, x, ea, glog, ws, self.bucket.views, defer_side_join=defer)
+        # IndexError like the reference's x[row] gather for an edge_index outside [0, N) (graph prep clamps such entries and sets a
+        # flag): read once per graph, BEFORE anything is done with the gradients of the clamped graph -- the prep finished long
+        # before the backward was enqueued, so the read waits for nothing
+        err = None
+        try:
+            g.raise_if_invalid()
+        except IndexError as exc:
+            err = exc
         if self.world_size > 1:
+            # every rank must take part in this step's collectives; the flag rides in a spare element of the bucket, the reduced
+            # element guards the optimizer step on every rank (nobody steps on bad gradients), then the offending rank raises
+            if err is not None:
+                self.bucket.flat[self.bucket.n:].fill_(1.0)
+                torch.cuda.current_stream().synchronize()   # (the bucket's collective may run on the library's side stream)
             self.allreduce_buckets(defer)
+        elif err is not None:
+            raise err
         if optimizer_step:
-            self.opt.step()
-        g.raise_if_invalid()   # IndexError like the reference's x[row] gather for an edge_index outside [0, N): once per graph
+            self.opt.step(guarded=self.world_size > 1)
+        if err is not None:
+            raise err
         return logits

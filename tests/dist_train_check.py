@@ -20,9 +20,14 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    what = sys.argv[3] if len(sys.argv) > 3 else "average"
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo")
+    if what == "overlap":
+        return overlap_check(rank, world, L, d, dev)
+    if what == "badgraph":
+        return bad_graph_check(rank, world, L, d, dev)
     params = synth.model_params(d, L, "sum", node_in_dim=64)
     W = synth.make_weights(params, seed=7, gain=0.6)
 
@@ -58,12 +63,65 @@ def main():
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     same = all(torch.equal(gathered[0], t) for t in gathered[1:])
-    moved = not np.array_equal(mine.cpu().numpy(), np.concatenate([np.pad(W[k].ravel(), (0, (-W[k].size) % 4)) for k in W]).astype(np.float32))
+    moved = not np.array_equal(mine[:step.bucket.n].cpu().numpy(), np.concatenate([np.pad(W[k].ravel(), (0, (-W[k].size) % 4)) for k in W]).astype(np.float32))
     print("RANK %d err %.3e side_stream %d same_params %d moved %d" % (rank, err, uses_side, same, moved), flush=True)
     ok = err < 2e-5 and same and moved and uses_side == (L >= 4)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 3)
+
+
+def overlap_check(rank, world, L, d, dev):
+    """The message-passing bucket's all-reduce is reached on the library's side stream BEFORE the caller's stream has finished the
+    encoder's backward (MPNHIP_BWD_DEFER_SIDE_JOIN): event timestamps of train.TrainStep.allreduce_buckets.  The node encoder
+    reads 2048-d inputs here, as in the reference, so its backward is a real piece of work."""
+    params = synth.model_params(d, L, "sum")
+    W = synth.make_weights(params, seed=7, gain=0.6)
+    m = MOTMPNet(params)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    m = m.to(dev).train()
+    g = synth.make_graph(3000, 24000, seed=60 + rank)
+    x, ei, ea = (torch.from_numpy(g[k]).to(dev) for k in ("x", "edge_index", "edge_attr"))
+    step = TrainStep(m, world_size=world, lr=1e-4)
+    leads = []
+    for _ in range(4):
+        step(x, ei, ea)
+        torch.cuda.synchronize()
+        leads.append(step.ev_mp_ready.elapsed_time(step.ev_main_done) * 1e3)   # us by which the side stream got there first
+    print("RANK %d overlap lead_us %s" % (rank, " ".join("%.0f" % v for v in leads)), flush=True)
+    ok = max(leads[1:]) > 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 4)
+
+
+def bad_graph_check(rank, world, L, d, dev):
+    """One rank's edge_index leaves [0, N): that rank raises IndexError like the reference's gather (mpn.py:69) AFTER taking part
+    in the step's collectives, and NO rank applies the optimizer step (the flag rides in the bucket's spare element; guarded Adam)."""
+    params = synth.model_params(d, L, "sum", node_in_dim=64)
+    W = synth.make_weights(params, seed=7, gain=0.6)
+    m = MOTMPNet(params)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    m = m.to(dev).train()
+    g = synth.make_graph(300, 2400, seed=70 + rank, node_in_dim=64)
+    ei = g["edge_index"].copy()
+    if rank == 1:
+        ei[1, 7] = 300   # one past the last node
+    x, eit, ea = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(ei).to(dev), torch.from_numpy(g["edge_attr"]).to(dev)
+    step = TrainStep(m, world_size=world, lr=1e-2)
+    before = step.bucket.flat_params.detach().clone()
+    raised = False
+    try:
+        step(x, eit, ea)
+    except IndexError:
+        raised = True
+    torch.cuda.synchronize()
+    unchanged = bool(torch.equal(before, step.bucket.flat_params))
+    print("RANK %d badgraph raised %d unchanged %d" % (rank, raised, unchanged), flush=True)
+    ok = unchanged and raised == (rank == 1)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 5)
 
 
 if __name__ == "__main__":

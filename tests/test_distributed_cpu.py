@@ -27,7 +27,8 @@ def test_flat_bucket_views_alias_param_grads():
     params = [p for l in lin for p in l.parameters()]
     b = FlatBucket(params)
     # every parameter starts on a 16-byte boundary of the flat buffers (sizes rounded up to 4 floats; the padding stays zero)
-    assert b.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in params)
+    # ... plus four spare elements: flat[n] carries a rank's invalid-graph flag through the gradient all-reduce (train.TrainStep)
+    assert b.n == sum((p.numel() + 3) // 4 * 4 for p in params) and b.flat.numel() == b.n + 4
     assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in params)
     assert all(p.data_ptr() >= b.flat_params.data_ptr() for p in params)
     b.views[id(params[0])].fill_(2.0)

@@ -38,10 +38,28 @@ def test_two_rank_train_step_averages_gradients_and_keeps_ranks_in_step(L, d):
     assert len(re.findall(r"RANK \d err", r.stdout)) == 2, r.stdout[-2000:]   # (the two ranks' lines may interleave)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    r = run_ranks(["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "A", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+def test_message_passing_bucket_collective_overlaps_the_encoder_backward():
+    """the side stream reaches the message-passing bucket's all-reduce before the caller's stream has finished
+    the encoder's backward (event timestamps; the best of three steps must show a positive lead)."""
+    r = run_ranks([os.path.join("tests", "dist_train_check.py"), "6", "64", "overlap"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "overlap lead_us" in r.stdout
+
+
+def test_invalid_graph_on_one_rank_stops_every_ranks_optimizer_step():
+    r = run_ranks([os.path.join("tests", "dist_train_check.py"), "6", "32", "badgraph"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "RANK 1 badgraph raised 1 unchanged 1" in r.stdout and "RANK 0 badgraph raised 0 unchanged 1" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("cfg", ["A", "D"])
+def test_bench_two_ranks_on_one_gpu(cfg):
+    """bench.py's N > 1 branch; cfg-D is the configuration BASELINE.json names for the 8-GPU run (one KITTIMOTS-like graph per rank)."""
+    r = run_ranks(["bench.py", "--gpus", "2", "--backend", "gloo", "--config", cfg, "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
                    "--no-split-line"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["mode"] == "train"
+    # SURVEY.md section 8e "Reporting": the all-reduce alone and the bus bandwidth it corresponds to
+    assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] > 0 and d["bus_gbs"] > 0, d

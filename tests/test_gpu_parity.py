@@ -739,3 +739,11 @@ def test_mlp_batchnorm_and_dropout_eval_mode():
         ref = torch.stack([l.view(-1) for l in O.forward(params, Wk, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
                                                         torch.from_numpy(g["edge_attr"]), return_state=True)[1]]).numpy()
     assert rel_err(lg.cpu().numpy(), ref) < 1e-4
+    # the same call with gradients enabled (parameters require grad: the autograd route, through torch.ops.mpnhip when the shim is
+    # built): the BatchNorm fold must not be lost there -- identical logits -- and the backward refuses (training with BatchNorm)
+    lg2 = model.hot_path(torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["edge_index"]).to(dev()),
+                         torch.from_numpy(g["edge_attr"]).to(dev()))
+    assert lg2.requires_grad
+    assert float((lg2.detach() - lg).abs().max()) <= 1e-6 * max(1.0, float(lg.abs().max()))
+    with pytest.raises(capi.MpnhipError):
+        lg2.sum().backward()
