@@ -264,6 +264,44 @@ def test_g3_cfgB_golden(golden, agg, precision):
     assert (rel_err if agg == "sum" else abs_err)(xo[:64], z["x_final_rows"]) < TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split", "bf16"])
+@pytest.mark.parametrize("agg", ["mean", "sum"])
+def test_g13_cfgE_full_size_golden(golden, agg, precision):
+    """BASELINE.json configs[4] at FULL size (20k nodes / 400k edges / 256-d), two steps: the reference's own forward (tools/
+    make_golden.py gen_g13) -- 4,096 sampled logits per step + whole-tensor checksums.  fp32 / fp32_split: per element
+    1e-4 max(1, |ref|) (O(1) logits); bf16 operands: the 2e-2 relative anchor of SURVEY.md section 8c against the fp32 reference."""
+    z = golden(f"g13_cfgE_{agg}.npz")
+    c = synth.CONFIGS["E"]
+    L = int(z["L"])
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    assert synth.checksum(g["x"]) == int(z["cs_x"]) and synth.checksum(g["edge_index"]) == int(z["cs_edge_index"])
+    params = synth.model_params(c["d"], L, agg)
+    W = synth.make_weights(params, seed=7, gain=float(z["gain"]))
+    assert synth.checksum(np.concatenate([v.ravel() for v in W.values()])) == int(z["cs_weights"])
+    model = make_model(params, W, precision)
+    capi.path_counters(reset=True)
+    logits, xo, eo = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    counts = capi.path_counters(reset=True)
+    if precision == "bf16":
+        assert counts["edge_chain_fwd_bf16"] == L, counts
+    ids = z["edge_ids"]
+    ref = z["logits"].astype(np.float64)
+    got = logits[:, ids].astype(np.float64)
+    if precision == "bf16":
+        for s in range(L):
+            assert np.linalg.norm(got[s] - ref[s]) / np.linalg.norm(ref[s]) < 2e-2, s
+            assert abs(float(np.abs(logits[s]).astype(np.float64).sum()) - float(z["step_abssum"][s])) / float(z["step_abssum"][s]) < 2e-2
+        return
+    q = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert float(q.max()) < TOL, float(q.max())
+    for s in range(L):
+        scale = max(1.0, float(z["step_max"][s]))
+        assert abs(float(np.abs(logits[s]).max()) - float(z["step_max"][s])) / scale < TOL
+        assert abs(float(np.abs(logits[s]).astype(np.float64).sum()) - float(z["step_abssum"][s])) / (scale * c["E"]) < 1e-5
+    assert abs_err(xo[:32], z["x_final_rows"]) < TOL * max(1.0, float(np.abs(z["x_final_rows"]).max()))
+    assert abs_err(eo[:32], z["e_final_rows"]) < TOL * max(1.0, float(np.abs(z["e_final_rows"]).max()))
+
+
 def test_permutation_equivariance_full_size():
     """Size-independent property at the full cfg-B size: relabelling the edges permutes the logits.
     (Node relabelling would change which edges are past / future, so only the edge order is shuffled.)"""

@@ -113,16 +113,21 @@ def test_cfgD_graphs_and_their_batch(precision):
 
 
 @pytest.mark.parametrize("agg,L,gain,precision", [("sum", 12, 0.7, "fp32"), ("sum", 12, 0.7, "fp32_split"), ("mean", 12, 1.0, "fp32"),
-                                                  ("max", 6, 1.0, "fp32"), ("max", 4, 1.0, "fp32_split"), ("sum", 5, 1.0, "fp32")])
+                                                  ("max", 6, 1.0, "fp32"), ("max", 4, 1.0, "fp32_split"), ("sum", 5, 1.0, "fp32"),
+                                                  ("sum", 12, 1.0, "fp32_split")])
 def test_cfgB(agg, L, gain, precision):
     """BASELINE.json configs[1] graph and widths (5k nodes / 50k edges / 128-d): the headline training workload
     ('sum', 12 steps, O(1) logits as in the g11 fixture) in both precisions, mean over 12 steps, max, and sum with unit-gain
-    weights (each case differentiates the float64 oracle twice at this size: ~40 s of host time)."""
+    weights (each case differentiates the float64 oracle twice at this size: ~40 s of host time).  The last case IS the workload
+    bench.py times: sum, 12 steps, unit-gain weights (logits to 3.7e7), the default precision (fp32_split: split chain kernels and
+    the row-panel weight-gradient kernel)."""
     c = synth.CONFIGS["B"]
     params = synth.model_params(c["d"], L, agg)
     counts = run_case(params, synth.make_weights(params, seed=7, gain=gain), synth.make_graph(c["N"], c["E"], seed=1), precision)
     split = precision == "fp32_split"
     assert counts["edge_chain_fwd_split" if split else "edge_chain_fwd"] == L and counts["edge_chain_bwd_split" if split else "edge_chain_bwd"] == L, counts
+    # the weight gradients came from the kernel of the precision under test
+    assert (counts["gemm_tn_panel"] > 0 and counts["gemm_tn_mfma"] == 0) if split else (counts["gemm_tn_mfma"] > 0 and counts["gemm_tn_panel"] == 0), counts
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

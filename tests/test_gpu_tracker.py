@@ -75,6 +75,22 @@ def test_construct_graph_matches_oracle():
         assert np.allclose(got["reid_emb_dists"].cpu().numpy(), want["reid_emb_dists"].numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["train_recip", "train_plain", "infer", "infer_mfd"])
+def test_construct_graph_matches_the_reference_motgraph(golden, tag):
+    """g14: the reference's MOTGraph._get_edge_ixs + construct_graph_object run on synthetic detections (tools/make_golden.py
+    gen_g14): the device-side construct_graph gives the same edge list (bit-exact) and the same features (<= 2e-6 relative)."""
+    z = golden("g14_construct_graph.npz")
+    det = {k: z[f"{tag}:{k}"] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y", "reid")}
+    inference, top_k, recip, mfd = (int(v) for v in z[f"{tag}:cfg"])
+    names = list(G.EDGE_FEAT_NAMES) + ["emb_dist"]
+    got = G.construct_graph(det, torch.from_numpy(det["reid"]).to(dev()), 25.0, "max" if mfd < 0 else mfd, names,
+                            top_k_nns=None if top_k < 0 else top_k, reciprocal_k_nns=bool(recip), inference_mode=bool(inference))
+    assert np.array_equal(got["edge_index"].cpu().numpy(), z[f"{tag}:edge_index"])
+    assert np.allclose(got["edge_attr"].cpu().numpy(), z[f"{tag}:edge_attr"], rtol=2e-6, atol=2e-6)
+    if inference:
+        assert np.allclose(got["reid_emb_dists"].cpu().numpy(), z[f"{tag}:reid_emb_dists"], rtol=2e-6)
+
+
 def _sequence(frames=14, seed=5):
     det = synth.make_detections(frames=frames, seed=seed, node_in_dim=64)
     names = list(G.EDGE_FEAT_NAMES) + ["emb_dist"]

@@ -277,3 +277,26 @@ def test_g10_sliding_window_oracle_against_reference_tracker(golden, tag):
     ref = z[f"{tag}:final_edge_preds"]
     assert got.shape == ref.shape and float(np.abs(ref).max()) > 0.05
     assert np.abs(got.numpy() - ref).max() < 2e-6
+
+
+def _g14_case(z, tag):
+    det = {k: z[f"{tag}:{k}"] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y", "reid")}
+    inference, top_k, recip, mfd = (int(v) for v in z[f"{tag}:cfg"])
+    return det, bool(inference), (None if top_k < 0 else top_k), bool(recip), ("max" if mfd < 0 else mfd)
+
+
+@pytest.mark.parametrize("tag", ["train_recip", "train_plain", "infer", "infer_mfd"])
+def test_g14_construct_graph_oracle_against_reference_motgraph(golden, tag):
+    """The reference's own MOTGraph._get_edge_ixs + construct_graph_object (data/mot_graph.py:195-218, 283-317; tools/make_golden.py
+    gen_g14) -- training mode with the kNN pruning inside (reciprocal or not) and inference mode -- pins the oracle's composition:
+    identical edge lists, features to fp32 rounding."""
+    from oracle import tracker_oracle as T
+    z = golden("g14_construct_graph.npz")
+    det, inference, top_k, recip, mfd = _g14_case(z, tag)
+    names = ["secs_time_dists", "norm_feet_x_dists", "norm_feet_y_dists", "bb_height_dists", "bb_width_dists", "emb_dist"]
+    got = T.construct_graph(det, torch.from_numpy(det["reid"]), 25.0, mfd, names, top_k_nns=top_k, reciprocal_k_nns=recip,
+                            inference_mode=inference)
+    assert np.array_equal(got["edge_index"].numpy(), z[f"{tag}:edge_index"])
+    assert np.allclose(got["edge_attr"].numpy(), z[f"{tag}:edge_attr"], rtol=1e-6, atol=1e-7)
+    if inference:
+        assert np.allclose(got["reid_emb_dists"].numpy(), z[f"{tag}:reid_emb_dists"], rtol=1e-6)

@@ -350,6 +350,32 @@ def gen_cfg(mpn, name, tag, sample=None):
         print(tag, agg, "max|logit| per step", rec["step_max"][[0, -1]])
 
 
+def gen_g13(mpn):
+    """BASELINE.json configs[4] at FULL size (20,000 nodes / 400,000 edges / 256-d), two message-passing steps: the reference's
+    forward (fp32, CPU) -- 4,096 sampled logits per step + whole-tensor checksums.  'mean' has O(1) logits; 'sum' with gain-0.8
+    weights keeps them O(10)."""
+    c = synth.CONFIGS["E"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    L = 2
+    for agg, gain in (("mean", 1.0), ("sum", 0.8)):
+        params = synth.model_params(c["d"], L, agg)
+        W = synth.make_weights(params, seed=7, gain=gain)
+        model = build_reference_model(mpn, params, W)
+        with torch.no_grad():
+            logits, xL, eL = ref_hot_path(model, torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]),
+                                          torch.from_numpy(g["edge_attr"]))
+        lg = np.stack([t.numpy().reshape(-1) for t in logits])
+        ids = (synth.uniform01(113, 4096, stream=0) * c["E"]).astype(np.int64)
+        rec = {"N": c["N"], "E": c["E"], "d": c["d"], "L": L, "agg": agg, "gain": gain,
+               "cs_x": np.uint64(synth.checksum(g["x"])), "cs_edge_index": np.uint64(synth.checksum(g["edge_index"])),
+               "cs_edge_attr": np.uint64(synth.checksum(g["edge_attr"])),
+               "cs_weights": np.uint64(synth.checksum(np.concatenate([v.ravel() for v in W.values()]))),
+               "step_sum": lg.astype(np.float64).sum(1), "step_abssum": np.abs(lg).astype(np.float64).sum(1), "step_max": np.abs(lg).max(1),
+               "edge_ids": ids, "logits": lg[:, ids], "x_final_rows": xL.numpy()[:32], "e_final_rows": eL.numpy()[:32]}
+        np.savez_compressed(os.path.join(GOLD, f"g13_cfgE_{agg}.npz"), **rec)
+        print("g13", agg, "max|logit| per step", rec["step_max"])
+
+
 def _grad_record(rec, names, grads, gx, gea, ids_e):
     """Gradient fixtures: small tensors whole, large ones as their first 20,000 elements + the Euclidean norm of all."""
     for k, gr in zip(names, grads):
@@ -689,6 +715,50 @@ def gen_g10():
     np.savez_compressed(os.path.join(GOLD, "g10_windows.npz"), **rec)
 
 
+def gen_g14():
+    """MOTGraph._get_edge_ixs + construct_graph_object (data/mot_graph.py:195-218, 283-317) of the reference itself, on synthetic
+    detections with the appearance data supplied directly (``_load_appearance_data`` replaced: it reads image crops / .pt files,
+    the rows before and after this path): training mode (kNN pruning inside, reciprocal and not) and inference mode (all
+    time-valid pairs + reid_emb_dists), 'max' and bounded frame distances.  The MOTGraph is built without its __init__ (which
+    slices a sequence data frame): the attributes construct_graph_object reads are set by hand."""
+    _import_tracking_stack()
+    import pandas as pd
+    from mot_neural_solver.data import mot_graph as MG
+    from mot_neural_solver.utils import graph as G
+    # (the reference moves the index computation to 'cuda' in inference mode: keep it on the CPU here)
+    real_tv, real_knn, real_feats = G.get_time_valid_conn_ixs, G.get_knn_mask, G.compute_edge_feats_dict
+    MG.get_time_valid_conn_ixs = lambda **kw: real_tv(**dict(kw, use_cuda=False))
+    MG.get_knn_mask = lambda **kw: real_knn(**dict(kw, use_cuda=False))
+    MG.compute_edge_feats_dict = lambda **kw: real_feats(**dict(kw, use_cuda=False))
+    names = ["secs_time_dists", "norm_feet_x_dists", "norm_feet_y_dists", "bb_height_dists", "bb_width_dists", "emb_dist"]
+    rec = {}
+    cases = [("train_recip", False, 5, True, "max"), ("train_plain", False, 4, False, 6), ("infer", True, 5, True, "max"),
+             ("infer_mfd", True, None, True, 4)]
+    for tag, inference, top_k, recip, mfd in cases:
+        det = synth.make_detections(frames=10, dets_lo=3, dets_hi=7, seed=21, emb_dim=32, node_in_dim=64, frame_stride=2)
+        n = det["frame"].shape[0]
+        df = pd.DataFrame({k: det[k] for k in ("frame", "bb_height", "bb_width", "feet_x", "feet_y")})
+        df["frame_path"] = "synthetic/img1/000001.jpg"
+        mg = object.__new__(MG.MOTGraph)
+        mg.graph_df = df
+        mg.max_frame_dist = mfd
+        mg.inference_mode = inference
+        mg.seq_info_dict = {"fps": 25.0}
+        mg.dataset_params = {"top_k_nns": top_k, "reciprocal_k_nns": recip, "edge_feats_to_use": names}
+        emb = torch.from_numpy(det["reid"])
+        mg._load_appearance_data = lambda emb=emb, det=det, n=n: (emb, torch.from_numpy(det["x"]).view(n, 64, 1, 1), None)
+        mg.construct_graph_object()
+        go = mg.graph_obj
+        rec.update({f"{tag}:frame": det["frame"], f"{tag}:bb_height": det["bb_height"], f"{tag}:bb_width": det["bb_width"],
+                    f"{tag}:feet_x": det["feet_x"], f"{tag}:feet_y": det["feet_y"], f"{tag}:reid": det["reid"],
+                    f"{tag}:edge_index": go.edge_index.numpy(), f"{tag}:edge_attr": go.edge_attr.numpy(),
+                    f"{tag}:cfg": np.array([int(inference), -1 if top_k is None else top_k, int(recip), -1 if mfd == "max" else mfd], np.int64)})
+        if inference:
+            rec[f"{tag}:reid_emb_dists"] = go.reid_emb_dists.numpy()
+        print("g14", tag, "nodes", n, "edges", go.edge_index.shape[1])
+    np.savez_compressed(os.path.join(GOLD, "g14_construct_graph.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="g0,g1,g4,g5,g6,g7,g8,g2,g3,g11,g12,g10,g9")
@@ -710,6 +780,8 @@ def main():
     if "g9" in only: gen_g9()
     if "g11" in only: gen_g11(mpn)
     if "g12" in only: gen_g12(mpn)
+    if "g13" in only: gen_g13(mpn)
+    if "g14" in only: gen_g14()
 
 
 if __name__ == "__main__":
