@@ -149,7 +149,12 @@ static int side_stream_ready(SideStream** out) {
     MPN_CHECK_ARG(dev >= 0 && dev < MAX_DEVICES, "backward: device ordinal %d", dev);
     SideStream& ss = g_side_dev[dev];
     if (!ss.stream) {
-        MPN_HIP(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+        // lowest priority: the caller's stream carries the critical path (the step loop); when both have workgroups pending, the
+        // dispatcher should place the loop's first (MPNHIP_SIDE_PRIORITY=0: default priority, for measurements)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        static const bool low = [] { const char* e = getenv("MPNHIP_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
+        MPN_HIP(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, low ? least : 0));
         MPN_HIP(hipEventCreateWithFlags(&ss.ready, hipEventDisableTiming));
         MPN_HIP(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
     }
@@ -783,9 +788,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         for (int i = 0; i < parsed; ++i) ok = ok && gsize[i] > 0;
         if (ok) {
             ngroups = parsed;
-        } else if (L >= 6 && (double)E * dn * dn >= 3e8) {
+        } else if (L >= 6 && (double)E * dn * dn >= 3e8 && !g_wgrad_split) {
             // (enough work per group to pay for a third round of ~30 launches: cfg-B 8e8; the reference's 32-d widths, 8e7 at
-            // cfg-C, do better with two groups -- measured 2.59 -> 2.48 ms)
+            // cfg-C, do better with two groups -- measured 2.59 -> 2.48 ms.  The row-panel products of MPNHIP_PREC_FP32_SPLIT are
+            // two launches per group whatever its size, and a larger group needs fewer slabs per row: two groups there,
+            // cfg-B 5.27 -> 5.23 ms)
             ngroups = 3;
             gsize[0] = (int)((5 * L + 6) / 12);
             gsize[2] = (int)(L / 4);

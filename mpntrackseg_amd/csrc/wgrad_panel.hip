@@ -465,10 +465,10 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
 
 // blocks wanted per job: a job alone needs enough row chunks to fill the chip (2 blocks per CU); the jobs of a batch run side by
 // side in one launch, and every extra chunk costs a slab (written, then read by the slab sum: at 512 chunks per job the slabs of a
-// cfg-B group were 30 % of the launch's traffic)
+// cfg-B group were 30 % of the launch's traffic; measured: cfg-B step 5.43 / 5.37 / 5.29 ms at 320 / 192 / 128 chunks per job)
 int wp_target_blocks(bool batched) {
     static const int alone = [] { const char* e = getenv("MPNHIP_WP_BLOCKS"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 512; }();
-    static const int shared = [] { const char* e = getenv("MPNHIP_WP_BLOCKS_BATCH"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 192; }();
+    static const int shared = [] { const char* e = getenv("MPNHIP_WP_BLOCKS_BATCH"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 128; }();
     return batched ? shared : alone;
 }
 
