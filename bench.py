@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--agg", default="sum", help="node_agg_fn (reference default: sum, configs/tracking_cfg.yaml:135)")
     ap.add_argument("--mode", default="auto", choices=["auto", "fwd", "train"])
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra measurement in the other fp32 mode (fp32 MFMAs / split)")
-    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp32_split", "bf16"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp32_split", "fp32_wgsplit", "bf16"],
                     help="operand precision of the Linear products; bf16 (fp32 accumulate) is inference only and is NOT the "
                          "headline configuration (BASELINE.json configs[4])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -384,7 +384,9 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "fp32_split": "f32 (fused chain kernels: every f32 operand as the exact sum of three bf16 pieces, six "
                                                  "v_mfma_f32_32x32x16_bf16 products per multiply, f32 accumulate -- nothing rounded to bf16; "
-                                                 "weight gradients and small products: f32 MFMA)",
+                                                 "weight gradients: the same operand form in the row-panel kernel)",
+                  "fp32_wgsplit": "f32 (fp32 MFMAs in the forward and the activation-gradient chain; weight gradients by the batched row-panel "
+                                  "kernel on three-piece bf16 operands, f32 accumulate -- nothing rounded to bf16)",
                   "bf16": "bf16 operands, f32 accumulate"}[args.precision],
         "data": "synthetic" if not args.graph_file else "graph file %s (random-init weights)" % os.path.basename(args.graph_file),
         "config": {"workload": "cfg-%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, "
@@ -422,7 +424,7 @@ def main():
 
     if mode == "train":
         out["forward_edges_per_ms"] = forward_rate()
-    if world == 1 and args.precision in ("fp32", "fp32_split") and not args.no_split_line:
+    if world == 1 and args.precision in ("fp32", "fp32_split", "fp32_wgsplit") and not args.no_split_line:
         other = "fp32_split" if args.precision == "fp32" else "fp32"
         try:
             # the same step in the OTHER fp32 mode, reported beside the headline: fp32 MFMAs
@@ -510,7 +512,7 @@ def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
     if cfg_name != "B" or precision == "bf16":
         return None
     for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(REPO, "profiles", rnd, "pmc_summary.json" if precision == "fp32" else "pmc_summary_split.json")
+        path = os.path.join(REPO, "profiles", rnd, "pmc_summary.json" if precision in ("fp32", "fp32_wgsplit") else "pmc_summary_split.json")
         try:
             v = json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
         except Exception:

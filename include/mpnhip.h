@@ -47,6 +47,12 @@ extern "C" {
  * fp32 MFMAs.  Forward and backward.  Operands must be finite and below 3.3e38 in magnitude: an infinite operand gives NaN
  * (inf - inf in the split) where the FP32 mode gives +-inf; pieces below the bf16 normal range (|x| < 1e-33) may be flushed. */
 #define MPNHIP_PREC_FP32_SPLIT 2
+/* FP32_WGSPLIT: MPNHIP_PREC_FP32 in every product of the forward and of the backward's activation-gradient chain (fp32 MFMAs), and
+ * the FP32_SPLIT form for the WEIGHT-GRADIENT products only: there it is the batched row-panel kernel (csrc/wgrad_panel.hip: all
+ * products of a group of steps in one launch) that pays -- at the reference's graph sizes (configs[2] / configs[3]: a few hundred
+ * nodes) a training step is bound by its ~50 small weight-gradient launches, while the chain kernels, one wave per SIMD, are
+ * faster on fp32 MFMAs.  Same accuracy class as the other two fp32 modes; what 'auto' selects for small graphs. */
+#define MPNHIP_PREC_FP32_WGSPLIT 3
 
 #define MPNHIP_AGG_SUM 0  /* torch_scatter.scatter_add  (models/mpn.py:273) */
 #define MPNHIP_AGG_MEAN 1 /* torch_scatter.scatter_mean (models/mpn.py:267) */

@@ -23,7 +23,7 @@ class MpnhipError(RuntimeError):
 
 
 # mpnhip_model.precision (include/mpnhip.h)
-PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp32_split': 2}
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp32_split': 2, 'fp32_wgsplit': 3}
 
 
 class Mlp(C.Structure):

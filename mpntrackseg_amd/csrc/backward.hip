@@ -335,13 +335,13 @@ static thread_local bool g_wgrad_split = false;
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
                        const int* h_idx, int n_out, int k_in, float* const gw[2], int64_t ldw, float* const gb[2],
                        const RowRange rr[2], int64_t rows, int nbatch, hipStream_t s) {
-    if (g_wgrad_split && (!dz_idx || n_out == 1) && !h_idx && !H2.p && rows > 0) {
+    if (g_wgrad_split && rows > 0) {
         // MPNHIP_PREC_FP32_SPLIT: the row-panel kernel (wgrad_panel.hip) -- recorded into the open batch (all products of a group of
         // steps: one product launch + one slab-sum launch), or run as a batch of its own
         WpProduct wp[2];
         for (int q = 0; q < ngroups; ++q)
             wp[q] = {dZ.p, dZ.ld, dZ.bstride, H.p, H.ld, H.bstride, rr ? rr[q].begin : nullptr, rr ? rr[q].end : nullptr, rows, nbatch,
-                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx};
+                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit};
         if (wp_batch_open()) {
             if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
         } else {
@@ -565,7 +565,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         bool old;
         explicit WgradScope(bool v) : old(g_wgrad_split) { g_wgrad_split = v; }
         ~WgradScope() { g_wgrad_split = old; }
-    } wgrad_scope(m.precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL"));
+    } wgrad_scope((m.precision == MPNHIP_PREC_FP32_SPLIT || m.precision == MPNHIP_PREC_FP32_WGSPLIT) && !getenv("MPNHIP_NO_WGRAD_PANEL"));
     FwdPlan f;
     size_t fneed = plan_forward(m, d, N, E, 1, fwd_workspace, &f);
     if (!fwd_workspace || fwd_workspace_bytes < fneed) {

@@ -130,15 +130,17 @@ int launch_gemm_tn(const TnArgs& args, hipStream_t stream);
 // ---- three-piece operand form, row-panel blocks, all products of a group of steps in one launch (wgrad_panel.hip) ----
 struct WpJob {             // one product (one direction group of it), as the kernels see it
     const float* dZ;       // [rows, n_out], leading dim ldz; batch b at dZ + b * z_bstride
-    const float* H;        // [rows, k_in], leading dim ldh
-    const int* dz_idx;     // optional row gather of dZ (n_out == 1 only: wp_block_vec)
+    const float* H;        // [rows, k_in], leading dim ldh (columns [0, csplit) when H2 is given)
+    const float* H2;       // columns [csplit, k_in) (row-panel variants only) or nullptr
+    const int* dz_idx;     // optional row gather of dZ (wp_block_vec, wp_block_small)
+    const int* h_idx;      // optional row gather of H (wp_block_small)
     const int* row_begin;  // device ints (nullptr -> 0 / m_static)
     const int* row_end;
     float* slab;           // [nbatch * nsplit][n_out][tn_kpad(k_in)]
     float* grad_w;         // += ; leading dim ldw
     float* grad_b;         // += ; may be nullptr
-    int64_t ldz, ldh, z_bstride, h_bstride, ldw, m_static;
-    int n_out, k_in, nbatch;
+    int64_t ldz, ldh, z_bstride, h_bstride, ldw, m_static, ldh2, h2_bstride;
+    int n_out, k_in, nbatch, csplit;
     int chunk, nsplit;     // rows per chunk, chunks per batch
     int variant;           // block tile shape (wgrad_panel.hip kVariants)
     int tiles_o, tiles_c;  // output tiles of that shape
@@ -154,7 +156,9 @@ struct WpProduct {         // host-side description of one product
     int64_t rows;          // rows of one batch (upper bound when ranged)
     int nbatch, n_out, k_in;
     float* grad_w; int64_t ldw; float* grad_b;
-    const int* dz_idx;     // optional row gather of dZ; n_out == 1 only
+    const int* dz_idx;     // optional row gathers (narrow products and the [1 x k] form only)
+    const int* h_idx;
+    const float* H2; int64_t ldh2, h2_bstride; int csplit;   // second column segment of H (nullptr: none)
 };
 struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched; };
 bool wp_eligible(const WpProduct& p);

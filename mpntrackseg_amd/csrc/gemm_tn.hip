@@ -541,7 +541,7 @@ static int weight_grad_run(const TnArgs& a, int precision, void* workspace, size
     if (precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL")) {
         const TnGroup& g = a.g[0];
         WpProduct p = {g.dZ, g.ldz, g.z_bstride, g.H, g.ldh, g.h_bstride, nullptr, nullptr, a.m_upper, a.nbatch, a.n_out, a.k_in,
-                       g.grad_w, g.ldw, g.grad_b, nullptr};
+                       g.grad_w, g.ldw, g.grad_b, nullptr, nullptr, nullptr, 0, 0, 0};
         WpBatch b;
         WpBatchGuard guard;
         wp_batch_begin(&b, g.slab, (workspace_bytes - 256) / sizeof(float), false);

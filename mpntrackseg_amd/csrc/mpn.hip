@@ -646,15 +646,16 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     }
     GraphView g;
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
-    MPN_CHECK_ARG(m.precision == MPNHIP_PREC_FP32 || m.precision == MPNHIP_PREC_BF16 || m.precision == MPNHIP_PREC_FP32_SPLIT,
-                  "forward: unknown precision %d", m.precision);
+    MPN_CHECK_ARG(m.precision == MPNHIP_PREC_FP32 || m.precision == MPNHIP_PREC_BF16 || m.precision == MPNHIP_PREC_FP32_SPLIT ||
+                  m.precision == MPNHIP_PREC_FP32_WGSPLIT, "forward: unknown precision %d", m.precision);
     MPN_CHECK_ARG(m.precision != MPNHIP_PREC_BF16 || !save, "forward: bf16 operands are an inference mode (save_for_backward must be 0)");
     // every product of this call rounds its operands as the model asks (restored on every exit path)
     struct PrecisionScope {
         int old;
         explicit PrecisionScope(int p) : old(gemm_precision()) { set_gemm_precision(p); }
         ~PrecisionScope() { set_gemm_precision(old); }
-    } precision_scope(m.precision);  // (FP32_SPLIT: the fused chain kernels, and the larger K-contiguous GEMMs -- gemm.hip)
+    } precision_scope(m.precision == MPNHIP_PREC_FP32_WGSPLIT ? MPNHIP_PREC_FP32 : m.precision);  // (FP32_SPLIT: the fused chain
+    // kernels, and the larger K-contiguous GEMMs -- gemm.hip; FP32_WGSPLIT differs from FP32 in the backward's weight gradients only)
 
     if (m.weights_prepacked && !save) {
         p.cw.ok = chain_shapes_ok(m, d);  // the images are already at the head of the workspace

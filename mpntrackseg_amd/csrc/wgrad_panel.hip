@@ -117,10 +117,15 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     const int zrow = tid / tz, zcol = (tid - zrow * tz) * 4;
     const int hrow = tid / th, hcol = (tid - hrow * th) * 4;
     const bool zact = zrow < rpz, hact = hrow < rph;
-    const int64_t ldz = J.ldz, ldh = J.ldh;
+    // H may come as two column segments (the reference's torch.cat([initial, current]) input, mpn.py:369-373): columns
+    // [0, csplit) from H, [csplit, k_in) from H2; csplit % 4 == 0, so a thread's four columns lie in one segment.  The H loads
+    // therefore take per-thread 64-bit addresses (the dZ loads: one uniform base + 32-bit offsets)
+    const bool hseg2 = J.H2 && c0 + hcol >= J.csplit;
+    const int64_t ldz = J.ldz, ldh = hseg2 ? J.ldh2 : J.ldh;
     // uniform bases (SGPRs) + 32-bit per-thread byte offsets: the row of pass j clamped into the stage (clamped lanes do not store)
     const char* zbase = reinterpret_cast<const char*>(J.dZ + (int64_t)batch * J.z_bstride + o0);
-    const char* hbase = reinterpret_cast<const char*>(J.H + (int64_t)batch * J.h_bstride + c0);
+    const char* hbase = hseg2 ? reinterpret_cast<const char*>(J.H2 + (int64_t)batch * J.h2_bstride + (c0 - J.csplit))
+                              : reinterpret_cast<const char*>(J.H + (int64_t)batch * J.h_bstride + c0);
     unsigned zoff[PZ], hoff[PH];
 #pragma unroll
     for (int j = 0; j < PZ; ++j) {
@@ -132,7 +137,7 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     for (int j = 0; j < PH; ++j) {
         int r = hrow + rph * j;
         r = (hact && r < WP_KB) ? r : WP_KB - 1;
-        hoff[j] = (unsigned)(((int64_t)r * ldh + (hact ? hcol : 0)) * 4);
+        hoff[j] = (unsigned)(((int64_t)r * ldh + hcol) * 4);   // (hcol < wc for every thread: in bounds in either segment)
     }
     char* zdst = lds + zrow * P + zcol * 2;
     char* hdst = lds + hrow * P + (BO + hcol) * 2;
@@ -161,7 +166,7 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
         _Pragma("unroll") for (int j = 0; j < PZ; ++j)                                                                   \
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ZR[j]) : "v"(zoff[j]), "s"(zb_));                       \
         _Pragma("unroll") for (int j = 0; j < PH; ++j)                                                                   \
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(HR[j]) : "v"(hoff[j]), "s"(hb_));                       \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(HR[j]) : "v"(hb_ + hoff[j]));                          \
     } while (0)
     // a stage buffer has landed when at most NLD later loads are outstanding (the other buffer's stage, if it was issued after it)
 #define WP_WAIT(ZR, HR, other_in_flight)                                                                                 \
@@ -280,7 +285,7 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
         for (int j = 0; j < PH; ++j) {
             int r = hrow + rph * j;
             r = (hact && r < tail) ? r : tail - 1;
-            hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + (hact ? hcol : 0)) * 4);
+            hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * 4);
         }
         store(B0{}, tail);
         __syncthreads();
@@ -362,6 +367,66 @@ __device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char*
     }
 }
 
+// Narrow products (n_out <= 32, k_in <= 32, any alignment; rows of either operand optionally gathered: the reference's 18-wide
+// edge encoder -- its first layer reads edge_attr through the sort permutation --, classifier layers): a block stages 64 rows of
+// dZ and H in LDS and every thread owns up to five output elements (o, c) -- c == k_in is the bias column, fed by a column of
+// ones -- reading dZ as a broadcast and H conflict-free; plain fp32 FMAs (gemm_tn_small_kernel's scheme, as a job of this launch).
+__device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, char* lds) {
+    constexpr int ROWS = 64;
+    float (*zs)[33] = reinterpret_cast<float (*)[33]>(lds);
+    float (*hs)[34] = reinterpret_cast<float (*)[34]>(lds + ROWS * 33 * sizeof(float));
+    const int n_out = J.n_out, k_in = J.k_in, kc = k_in + 1;
+    const int nout_total = n_out * kc;
+    const int rb = J.row_begin ? *J.row_begin : 0;
+    const int re = J.row_end ? *J.row_end : (int)J.m_static;
+    const int batch = by / J.nsplit, ci = by - batch * J.nsplit;
+    const int r0 = rb + ci * J.chunk;
+    int r1 = r0 + J.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;
+    const float* dZ = J.dZ + (int64_t)batch * J.z_bstride;
+    const float* H = J.H + (int64_t)batch * J.h_bstride;
+    const int* zi = J.dz_idx;
+    const int* hi = J.h_idx;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int oo[5], cc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = threadIdx.x + WP_NT * q;
+        oo[q] = t < nout_total ? t / kc : 0;
+        cc[q] = t < nout_total ? t % kc : 0;
+    }
+    for (int m0 = r0; m0 < r1; m0 += ROWS) {
+        const int nr = r1 - m0 < ROWS ? r1 - m0 : ROWS;
+        for (int i = threadIdx.x; i < ROWS * n_out; i += WP_NT) {
+            const int r = i / n_out, o = i - r * n_out;
+            const int64_t row = r < nr ? (zi ? zi[m0 + r] : m0 + r) : 0;
+            zs[r][o] = r < nr ? dZ[row * J.ldz + o] : 0.f;
+        }
+        for (int i = threadIdx.x; i < ROWS * kc; i += WP_NT) {
+            const int r = i / kc, c = i - r * kc;
+            const int64_t row = r < nr ? (hi ? hi[m0 + r] : m0 + r) : 0;
+            hs[r][c] = c == k_in ? (r < nr ? 1.f : 0.f) : (r < nr ? H[row * J.ldh + c] : 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (threadIdx.x + WP_NT * q < nout_total) {
+                float sacc = acc[q];
+#pragma unroll 8
+                for (int r = 0; r < ROWS; ++r) sacc = fmaf(zs[r][oo[q]], hs[r][cc[q]], sacc);
+                acc[q] = sacc;
+            }
+        }
+        __syncthreads();
+    }
+    float* slab = J.slab + (size_t)by * n_out * tn_kpad(k_in);
+    const float sg = (ci & 1) ? -1.f : 1.f;   // (odd chunks are subtracted by the slab sum)
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (threadIdx.x + WP_NT * q < nout_total) slab[(size_t)oo[q] * tn_kpad(k_in) + cc[q]] = sg * acc[q];
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
@@ -380,6 +445,7 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
         case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
         case 4: wp_block<2, 4>(J, tile, by, wp_lds); break;
         case 6: wp_block_vec(J, by, wp_lds); break;
+        case 7: wp_block_small(J, by, wp_lds); break;
         default: wp_block<2, 2>(J, tile, by, wp_lds); break;
     }
 }
@@ -453,7 +519,8 @@ const WpVariant kVariants[6] = {{5, 1}, {1, 5}, {4, 1}, {1, 1}, {2, 4}, {2, 2}};
 
 // the variant whose tiles cover [n_out, k_in] with the fewest staged columns per operand row (ties: fewer tiles)
 void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
-    if (n_out == 1) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
+    if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
+    if (n_out <= 32 && k_in <= 32) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                  // wp_block_small
     long best = -1;
     for (int v = 0; v < 6; ++v) {
         const int bo = 64 * kVariants[v].tm, bc = 64 * kVariants[v].tn;
@@ -473,12 +540,12 @@ int wp_target_blocks(bool batched) {
 }
 
 // rows per chunk / chunks per batch of one job: ~wp_target_blocks() blocks per job, chunks of at least 256 rows
-void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit) {
+void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit, int min_chunk = 256) {
     if (rows_expected < 1) rows_expected = 1;
     int want = wp_target_blocks(batched) / (nbatch * tiles);
     if (want < 1) want = 1;
     int64_t c = (rows_expected + want - 1) / want;
-    if (c < 256) c = 256;
+    if (c < min_chunk) c = min_chunk;
     c = (c + WP_KB - 1) / WP_KB * WP_KB;
     *chunk = (int)c;
     *nsplit = (int)((rows_upper + c - 1) / c);
@@ -493,13 +560,13 @@ size_t wp_lds_bytes() { return 3 * WP_KB * wp_pitch(320, 64); }   // the largest
 
 bool wp_eligible(const WpProduct& p) {
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-    if (p.rows <= 0 || p.rows >= (int64_t)1 << 31 || p.nbatch < 1 || !p.dZ || !p.H) return false;
-    if (p.n_out == 1)   // wp_block_vec: gathered dZ allowed
-        return p.k_in >= 4 && p.k_in % 4 == 0 && p.k_in <= 64 && al16(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0;
-    return !p.dz_idx && p.n_out >= 4 && p.k_in >= 4 && p.n_out % 4 == 0 && p.k_in % 4 == 0 &&
+    if (p.rows <= 0 || p.rows >= (int64_t)1 << 31 || p.nbatch < 1 || !p.dZ || !p.H || p.n_out < 1 || p.k_in < 1) return false;
+    if (p.n_out == 1 && p.k_in % 4 == 0 && p.k_in <= 64 && !p.h_idx && !p.H2 && al16(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0)
+        return true;   // wp_block_vec: gathered dZ allowed
+    if (p.n_out <= 32 && p.k_in <= 32) return !p.H2 && p.n_out * (p.k_in + 1) <= 5 * WP_NT;   // wp_block_small: any alignment, gathers allowed
+    return !p.dz_idx && !p.h_idx && p.n_out % 4 == 0 && p.k_in % 4 == 0 &&
            al16(p.dZ) && al16(p.H) && p.ldz % 4 == 0 && p.ldh % 4 == 0 && p.z_bstride % 4 == 0 && p.h_bstride % 4 == 0 &&
-           // narrow products stay with gemm_tn_small_kernel (their rows are 16-72 bytes: nothing to stream)
-           !(p.n_out <= 32 && p.k_in <= 32);
+           (!p.H2 || (al16(p.H2) && p.ldh2 % 4 == 0 && p.h2_bstride % 4 == 0 && p.csplit % 4 == 0 && p.csplit > 0 && p.csplit < p.k_in));
 }
 
 size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched) {
@@ -542,7 +609,8 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c);
         wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
-        J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows; J.dz_idx = p.dz_idx;
+        J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
+        J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows; J.dz_idx = p.dz_idx; J.h_idx = p.h_idx;
         J.slab = b->slab + b->used;
         J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
         J.n_out = p.n_out; J.k_in = p.k_in; J.nbatch = p.nbatch;

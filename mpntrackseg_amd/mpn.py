@@ -414,7 +414,9 @@ class MOTMPNet(nn.Module):
         configs[1] at any size (cfg-B training step 6.6 -> 5.7 ms, inference 2.05 -> 1.53 ms), the reference's 32-d widths from
         ~32k edges (cfg-C stand-in, 77.8k edges: 2.15 -> 2.07 ms / 0.47 -> 0.43 ms) -- and 'fp32' (fp32 MFMAs) on small graphs at
         narrow widths, where a launch is one wave per SIMD and the operand splitting sits on its critical path (cfg-D stand-in
-        forward, 14.4k edges: 0.112 ms against 0.143).  Logits and every gradient are as close to a float64 oracle in one mode as
+        forward, 14.4k edges: 0.112 ms against 0.143) -- as 'fp32_wgsplit': fp32 MFMAs in the forward and the activation-gradient
+        chain, the batched row-panel kernel (split operands) for the weight gradients, which is where a small graph's training step
+        spends its launches.  Logits and every gradient are as close to a float64 oracle in one mode as
         in the other.  The forward and the backward of one call see the same edge count, hence one mode."""
         prec = getattr(self, 'gemm_precision', 'auto')
         if prec == 'auto':
@@ -424,7 +426,7 @@ class MOTMPNet(nn.Module):
                 he = 0
             wide = he >= self.AUTO_SPLIT_MIN_HIDDEN
             big = n_edges is not None and int(n_edges) >= self.AUTO_SPLIT_MIN_EDGES
-            prec = 'fp32_split' if (wide or big) else 'fp32'
+            prec = 'fp32_split' if (wide or big) else 'fp32_wgsplit'
         if prec not in capi.PRECISIONS:
             raise capi.MpnhipError("gemm_precision must be 'auto' or one of %s, not %r" % (sorted(capi.PRECISIONS), prec))
         return prec

@@ -49,8 +49,8 @@ def test_operand_precision_policy():
     (128-d class), fp32 MFMAs at the reference's widths; explicit choices pass through; anything else raises."""
     from mpntrackseg_amd import capi
     ref = MOTMPNet(default_params())
-    assert ref.gemm_precision == "auto" and ref.operand_precision() == "fp32"
-    assert ref.operand_precision(14400) == "fp32" and ref.operand_precision(77800) == "fp32_split"   # (cfg-D / cfg-C stand-ins)
+    assert ref.gemm_precision == "auto" and ref.operand_precision() == "fp32_wgsplit"
+    assert ref.operand_precision(14400) == "fp32_wgsplit" and ref.operand_precision(77800) == "fp32_split"   # (cfg-D / cfg-C stand-ins)
     wide = MOTMPNet(synth.model_params(128, 2, "sum", node_in_dim=64))
     assert wide.operand_precision() == "fp32_split"
     for prec in ("fp32", "fp32_split", "bf16"):
