@@ -202,6 +202,8 @@ struct BwdPlan {
     // zero-padded copies of the per-edge weights for the fused backward chain (native [n][k] orientation)
     float* wf2p[2]; float* wfep[2]; float* wc1p; float* w2p; float* w1ep;
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
+    float* wt_scratch;                  // MPNHIP_PREC_BF16: transposed weight blocks of the activation-gradient products
+    size_t wt_scratch_floats;
     float* slab;                        // split partials of the weight-gradient products (2 groups)
     float* slab_side;                   // the same for the products issued on the side stream
     size_t slab_floats_per_group;
@@ -264,6 +266,17 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
         p.w1ep = a.f(HE * 2 * DE * 3 / 2);
     }
     p.gWnode = a.f((size_t)d.pw * d.kx);
+    {   // MPNHIP_PREC_BF16: transposition scratch of the activation-gradient products (two direction groups of the largest weight)
+        size_t mx = (size_t)d.pw * d.kx;
+        const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge, &m.edge, &m.flow_in, &m.flow_out, &m.node, &m.classifier};
+        for (const mpnhip_mlp* q : all)
+            for (int i = 0; i < q->n_layers; ++i) {
+                const size_t w = (size_t)q->out_dims[i] * (i == 0 ? q->in_dim : q->out_dims[i - 1]);
+                mx = w > mx ? w : mx;
+            }
+        p.wt_scratch_floats = m.precision == MPNHIP_PREC_BF16 ? 2 * mx : 0;
+        p.wt_scratch = a.f(p.wt_scratch_floats);
+    }
     size_t sl = 0;
     auto upd = [&](size_t f) { sl = f > sl ? f : sl; };
     // exactly the products mpnhip_backward launches (the slab size depends on the shape through tn_plan)
@@ -330,6 +343,12 @@ struct Operand {        // one side of a (batched) weight-gradient product
 
 // set by mpnhip_backward for a model in MPNHIP_PREC_FP32_SPLIT: weight gradients in the three-piece operand form (wgrad_panel.hip)
 static thread_local bool g_wgrad_split = false;
+// MPNHIP_PREC_BF16 (training): every product of the backward rounds its operands to bf16 like the forward's -- the activation
+// gradients dH = dZ W through the K-contiguous bf16 GEMM (the weight block transposed into g_wt_scratch first: the kernel takes
+// nn.Linear-style [out][in] operands), the weight gradients through the row-panel kernel with ONE bf16 piece per operand
+static thread_local bool g_bwd_bf16 = false;
+static thread_local float* g_wt_scratch = nullptr;
+static thread_local size_t g_wt_scratch_floats = 0;
 
 // dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
@@ -341,7 +360,7 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
         WpProduct wp[2];
         for (int q = 0; q < ngroups; ++q)
             wp[q] = {dZ.p, dZ.ld, dZ.bstride, H.p, H.ld, H.bstride, rr ? rr[q].begin : nullptr, rr ? rr[q].end : nullptr, rows, nbatch,
-                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit};
+                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit, g_bwd_bf16 ? 1 : 3};
         if (wp_batch_open()) {
             if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
         } else {
@@ -397,6 +416,8 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
     a.relu = 0;
     a.accumulate = accumulate;
     a.m_upper = rows;
+    const bool bf16 = g_bwd_bf16 && rows > 0 && (size_t)ngroups * K * N <= g_wt_scratch_floats;
+    if (g_bwd_bf16 && !bf16 && rows > 0) { set_error("backward (bf16): weight block %d x %d exceeds the transposition scratch", K, N); return MPNHIP_ERR_WORKSPACE; }
     for (int q = 0; q < ngroups; ++q) {
         GemmGroup& g = a.g[q];
         init_group(g);
@@ -405,6 +426,13 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
         g.a_idx = a_idx;
         g.B = W[q];
         g.ldb = ldw;
+        if (bf16) {
+            // WT[n][k] = W[k][n]: the block as an nn.Linear weight of the product C = A WT^T (bf16 operands, K-contiguous)
+            float* wt = g_wt_scratch + (size_t)q * K * N;
+            MPN_TRY(transpose_padded(W[q], ldw, 0, K, N, wt, K, N, s));
+            g.B = wt;
+            g.ldb = K;
+        }
         g.C = C;
         g.ldc = ldc;
         g.c_idx = c_idx;
@@ -413,6 +441,10 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
         g.m_static = rows;
         g.row_begin = rr ? rr[q].begin : nullptr;
         g.row_end = rr ? rr[q].end : nullptr;
+    }
+    if (bf16) {
+        struct Scope { int old; Scope() : old(gemm_precision()) { set_gemm_precision(MPNHIP_PREC_BF16); } ~Scope() { set_gemm_precision(old); } } scope;
+        return launch_gemm(a, A_KCONTIG, B_KCONTIG, s);
     }
     return launch_gemm(a, A_KCONTIG, B_NCONTIG, s);
 }
@@ -551,10 +583,6 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     const int64_t N = n_nodes, E = n_edges;
     MPN_CHECK_ARG(N >= 0 && E >= 0, "backward: negative sizes");
     MPN_CHECK_ARG((x || N == 0) && (edge_attr || E == 0) && (grad_logits || E == 0), "backward: null tensor");
-    if (m.precision == MPNHIP_PREC_BF16) {
-        set_error("backward: bf16-operand products are an inference mode; train with MPNHIP_PREC_FP32 or MPNHIP_PREC_FP32_SPLIT");
-        return MPNHIP_ERR_UNSUPPORTED;
-    }
     {
         const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge, &m.edge, &m.flow_in, &m.flow_out, &m.node, &m.classifier};
         for (const mpnhip_mlp* q : all)
@@ -565,7 +593,13 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         bool old;
         explicit WgradScope(bool v) : old(g_wgrad_split) { g_wgrad_split = v; }
         ~WgradScope() { g_wgrad_split = old; }
-    } wgrad_scope((m.precision == MPNHIP_PREC_FP32_SPLIT || m.precision == MPNHIP_PREC_FP32_WGSPLIT) && !getenv("MPNHIP_NO_WGRAD_PANEL"));
+    } wgrad_scope((m.precision == MPNHIP_PREC_FP32_SPLIT || m.precision == MPNHIP_PREC_FP32_WGSPLIT || m.precision == MPNHIP_PREC_BF16) &&
+                  !getenv("MPNHIP_NO_WGRAD_PANEL"));
+    struct Bf16Scope {
+        bool old; float* olds; size_t oldn;
+        Bf16Scope(bool v) : old(g_bwd_bf16), olds(g_wt_scratch), oldn(g_wt_scratch_floats) { g_bwd_bf16 = v; }
+        ~Bf16Scope() { g_bwd_bf16 = old; g_wt_scratch = olds; g_wt_scratch_floats = oldn; }
+    } bf16_scope(m.precision == MPNHIP_PREC_BF16);
     FwdPlan f;
     size_t fneed = plan_forward(m, d, N, E, 1, fwd_workspace, &f);
     if (!fwd_workspace || fwd_workspace_bytes < fneed) {
@@ -578,6 +612,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         set_error("backward: workspace %zu < %zu", bwd_workspace_bytes, need);
         return MPNHIP_ERR_WORKSPACE;
     }
+    g_wt_scratch = p.wt_scratch;
+    g_wt_scratch_floats = p.wt_scratch_floats;
     GraphView g;
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
     const int he = d.he, hn = d.hn, dn = d.dn, de = d.de, kx = d.kx, ke = d.ke, pw = d.pw, L = d.L;
@@ -816,7 +852,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
     bool node_a_done = false;   // dZn / dAGG of the coming step were already produced by node_step32_bwd
     // (k_node_step32_bwd stages the weights in LDS: 128 pw + 8 KB + ... <= 64 KB, 16-byte aligned rows)
-    const bool fuse_node_bwd = dn == 32 && N <= 4096 && pw <= 384 && kx % 4 == 0 &&
+    const bool fuse_node_bwd = !g_bwd_bf16 && dn == 32 && N <= 4096 && pw <= 384 && kx % 4 == 0 &&
                                ((((uintptr_t)f.Wnode) | ((uintptr_t)m.node.weight[0])) & 15) == 0 && !getenv("MPNHIP_NO_NODE_FUSION");
 
     for (int step = L; step >= 1; --step) {
@@ -919,7 +955,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 MPN_TRY(node_step32_bwd(dP, (int)N, pw, f.Wnode + dn, kx, f.x_hist + xs * (step - 1), m.node.weight[0],
                                         p.dZn + (size_t)(b_ - 1) * xs, p.dAGG, s));
                 node_a_done = true;
-            } else if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000) {
+            } else if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000 && !g_bwd_bf16) {
                 // [N, pw] x [pw, dn] is 157 tiles of 64 x 64 at cfg-B -- not enough blocks for 256 CUs and 34 K steps each: the two K
                 // halves run as the two groups of ONE grouped launch into dXp / dXh; the next step's ReLU-mask kernel adds them
                 GemmArgs a = {};
@@ -1103,7 +1139,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         const mpnhip_mlp& ee = m.enc_edge;
         const float* dz = p.dE0;
         int cur = 0;
-        const bool ref_encoder = ee.n_layers == 3 && ee.in_dim == 6 && ee.out_dims[0] == 18 && ee.out_dims[1] == 18 && ee.out_dims[2] == 16 &&
+        const bool ref_encoder = !g_bwd_bf16 && ee.n_layers == 3 && ee.in_dim == 6 && ee.out_dims[0] == 18 && ee.out_dims[1] == 18 && ee.out_dims[2] == 16 &&
                                  p.t_width >= 52 && !getenv("MPNHIP_NO_ENCODER_FUSION");
         if (E > 0 && ref_encoder) {
             // the reference's edge encoder: all three activation gradients in one launch (dz2 | dz1 | dz0 side by side in T[0]),

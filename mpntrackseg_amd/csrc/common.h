@@ -141,6 +141,8 @@ struct WpJob {             // one product (one direction group of it), as the ke
     float* grad_b;         // += ; may be nullptr
     int64_t ldz, ldh, z_bstride, h_bstride, ldw, m_static, ldh2, h2_bstride;
     int n_out, k_in, nbatch, csplit;
+    int pieces;            // 3: fp32 operands as three bf16 pieces, six products (MPNHIP_PREC_FP32_SPLIT); 1: operands rounded to
+                           // bf16, one product (MPNHIP_PREC_BF16)
     int chunk, nsplit;     // rows per chunk, chunks per batch
     int variant;           // block tile shape (wgrad_panel.hip kVariants)
     int tiles_o, tiles_c;  // output tiles of that shape
@@ -159,6 +161,7 @@ struct WpProduct {         // host-side description of one product
     const int* dz_idx;     // optional row gathers (narrow products and the [1 x k] form only)
     const int* h_idx;
     const float* H2; int64_t ldh2, h2_bstride; int csplit;   // second column segment of H (nullptr: none)
+    int pieces;            // 3 (fp32 from three bf16 pieces) or 1 (bf16-rounded operands); 0 = 3
 };
 struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched; };
 bool wp_eligible(const WpProduct& p);

@@ -538,10 +538,10 @@ static int weight_grad_args(const float* dZ, const float* H, int64_t rows, int n
 
 // precision MPNHIP_PREC_FP32_SPLIT: the row-panel kernel with three-piece bf16 operands (wgrad_panel.hip) where the shape allows it
 static int weight_grad_run(const TnArgs& a, int precision, void* workspace, size_t workspace_bytes, hipStream_t s) {
-    if (precision == MPNHIP_PREC_FP32_SPLIT && !getenv("MPNHIP_NO_WGRAD_PANEL")) {
+    if ((precision == MPNHIP_PREC_FP32_SPLIT || precision == MPNHIP_PREC_BF16) && !getenv("MPNHIP_NO_WGRAD_PANEL")) {
         const TnGroup& g = a.g[0];
         WpProduct p = {g.dZ, g.ldz, g.z_bstride, g.H, g.ldh, g.h_bstride, nullptr, nullptr, a.m_upper, a.nbatch, a.n_out, a.k_in,
-                       g.grad_w, g.ldw, g.grad_b, nullptr, nullptr, nullptr, 0, 0, 0};
+                       g.grad_w, g.ldw, g.grad_b, nullptr, nullptr, nullptr, 0, 0, 0, precision == MPNHIP_PREC_BF16 ? 1 : 3};
         WpBatch b;
         WpBatchGuard guard;
         wp_batch_begin(&b, g.slab, (workspace_bytes - 256) / sizeof(float), false);
@@ -553,7 +553,7 @@ static int weight_grad_run(const TnArgs& a, int precision, void* workspace, size
 
 extern "C" int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision,
                                        float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
-    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT, "weight_grad: precision %d", precision);
+    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT || precision == MPNHIP_PREC_BF16, "weight_grad: precision %d", precision);
     TnArgs a;
     MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
     if (rows == 0) return MPNHIP_OK;
@@ -570,7 +570,7 @@ extern "C" int mpnhip_time_weight_grad_prec(const float* dZ, const float* H, int
                                             void* stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     MPN_CHECK_ARG(avg_us && iters > 0 && rows > 0, "time_weight_grad: bad argument");
-    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT, "time_weight_grad: precision %d", precision);
+    MPN_CHECK_ARG(precision == MPNHIP_PREC_FP32 || precision == MPNHIP_PREC_FP32_SPLIT || precision == MPNHIP_PREC_BF16, "time_weight_grad: precision %d", precision);
     TnArgs a;
     MPN_TRY(weight_grad_args(dZ, H, rows, n_out, k_in, nbatch, grad_w, grad_b, workspace, workspace_bytes, &a));
     hipEvent_t t0, t1;

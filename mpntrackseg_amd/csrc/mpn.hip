@@ -648,7 +648,6 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
     MPN_CHECK_ARG(m.precision == MPNHIP_PREC_FP32 || m.precision == MPNHIP_PREC_BF16 || m.precision == MPNHIP_PREC_FP32_SPLIT ||
                   m.precision == MPNHIP_PREC_FP32_WGSPLIT, "forward: unknown precision %d", m.precision);
-    MPN_CHECK_ARG(m.precision != MPNHIP_PREC_BF16 || !save, "forward: bf16 operands are an inference mode (save_for_backward must be 0)");
     // every product of this call rounds its operands as the model asks (restored on every exit path)
     struct PrecisionScope {
         int old;

@@ -150,37 +150,32 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x4 zreg[2][PZ], hreg[2][PH];   // two stages in flight
+    f32x4 zreg[1][PZ], hreg[1][PH];   // the next stage, in flight under the current one's products
 
-    // full stages: rows m0 .. m0 + 15 all inside the chunk.  Inline assembly on purpose: hipcc's own s_waitcnt placement drains
-    // EVERY outstanding load before the first use of a stage (vmcnt(0) at the loop head), which would turn the two stages in flight
-    // into one; these loads are invisible to it and the waits are counted by hand (wait_stage: vector-memory operations of a
-    // wave complete in issue order, every thread issues all NLD loads of a stage)
-    constexpr int NLD = PZ + PH;
-    f32x4(&z0)[PZ] = zreg[0]; f32x4(&z1)[PZ] = zreg[1];
-    f32x4(&h0)[PH] = hreg[0]; f32x4(&h1)[PH] = hreg[1];
+    // full stages: rows m0 .. m0 + 15 all inside the chunk.  (Compiler-visible loads on purpose.  Inline-assembly loads into TWO
+    // stage buffers with hand-counted s_waitcnt kept two whole stages in flight -- hipcc's own placement waits for every
+    // outstanding load before the first use of a stage -- and were 3 % faster on the long products (110.5 vs 113.9 us), but the
+    // registers of an asm load are, to the compiler, ready when the statement ends: wherever its allocation put a copy or reused
+    // one of them before the hand-placed wait, the late-landing load overwrote live values -- memory faults on short chunks of
+    // the <2, 4> variant.  Not worth 3 %; and two compiler-visible buffers spill in that variant.)
+    f32x4(&z0)[PZ] = zreg[0];
+    f32x4(&h0)[PH] = hreg[0];
 #define WP_LOAD(ZR, HR, m0)                                                                                              \
     do {                                                                                                                 \
         const char* zb_ = zbase + (int64_t)(m0) * ldz * 4;                                                               \
         const char* hb_ = hbase + (int64_t)(m0) * ldh * 4;                                                               \
-        _Pragma("unroll") for (int j = 0; j < PZ; ++j)                                                                   \
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ZR[j]) : "v"(zoff[j]), "s"(zb_));                       \
-        _Pragma("unroll") for (int j = 0; j < PH; ++j)                                                                   \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(HR[j]) : "v"(hb_ + hoff[j]));                          \
+        _Pragma("unroll") for (int j = 0; j < PZ; ++j) ZR[j] = *reinterpret_cast<const f32x4*>(zb_ + zoff[j]);           \
+        _Pragma("unroll") for (int j = 0; j < PH; ++j) HR[j] = *reinterpret_cast<const f32x4*>(hb_ + hoff[j]);           \
     } while (0)
-    // a stage buffer has landed when at most NLD later loads are outstanding (the other buffer's stage, if it was issued after it)
-#define WP_WAIT(ZR, HR, other_in_flight)                                                                                 \
-    do {                                                                                                                 \
-        if (other_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");                                  \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
-        _Pragma("unroll") for (int j = 0; j < PZ; ++j) asm volatile("" : "+v"(ZR[j]));                                   \
-        _Pragma("unroll") for (int j = 0; j < PH; ++j) asm volatile("" : "+v"(HR[j]));                                   \
-    } while (0)
+    const bool one = J.pieces == 1;   // MPNHIP_PREC_BF16: operands rounded to bf16 (the first piece alone), one product per k block
     auto put = [&](char* d, float4 v, bool negate) {
         if (negate) { v.x = fneg_if(v.x, sx); v.y = fneg_if(v.y, sx); v.z = fneg_if(v.z, sx); v.w = fneg_if(v.w, sx); }
         const Pk3 s = split4(v);
+        *reinterpret_cast<uint2*>(d) = s.p[0];
+        if (!one) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PIECE) = s.p[q];
+            for (int q = 1; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PIECE) = s.p[q];
+        }
     };
     // nrows: live rows of the stage (16 for a full one); rows past it are stored as zeros
     auto store = [&](auto bsel, int nrows) {
@@ -212,7 +207,19 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     const char* rdb = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + (BO + 32 * (wn * TN)) * 2;
     // every tile of the wave is computed (columns past n_out / k_in hold whatever the LDS held: those outputs are never stored);
     // the operand pieces of the next tile are fetched before the six products of the current one
+    auto products1 = [&]() {   // one bf16 piece per operand
+        bf16x8 b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = tr_read<P>(rdb + 64 * j);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x8 a = tr_read<P>(rda + 64 * i);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
+        }
+    };
     auto products = [&]() {
+        if (one) { products1(); return; }
         if (TM >= TN) {
             bf16x8 b[TN][3];
 #pragma unroll
@@ -250,24 +257,14 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
         }
     };
     using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
     const int nfull = (r1 - r0) / WP_KB;          // full stages
     const int tail = (r1 - r0) - nfull * WP_KB;   // rows of the partial last stage (0: none)
     if (nfull > 0) {
         WP_LOAD(z0, h0, r0);
-        if (nfull > 1) WP_LOAD(z1, h1, r0 + WP_KB);
-        for (int st = 0; st < nfull; st += 2) {
-            WP_WAIT(z0, h0, st + 1 < nfull);
+        for (int st = 0; st < nfull; ++st) {
             store(B0{}, WP_KB);
             __syncthreads();
-            if (st + 2 < nfull) WP_LOAD(z0, h0, r0 + (st + 2) * WP_KB);
-            products();
-            __syncthreads();
-            if (st + 1 >= nfull) break;
-            WP_WAIT(z1, h1, st + 2 < nfull);
-            store(B1{}, WP_KB);
-            __syncthreads();
-            if (st + 3 < nfull) WP_LOAD(z1, h1, r0 + (st + 3) * WP_KB);
+            if (st + 1 < nfull) WP_LOAD(z0, h0, r0 + (st + 1) * WP_KB);
             products();
             __syncthreads();
         }
@@ -323,7 +320,6 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 }
 
 #undef WP_LOAD
-#undef WP_WAIT
 
 // n_out == 1, dZ rows optionally gathered (the classifier's output layer: dZ = grad_logits, one float per edge in ORIGINAL edge
 // order, read through the sort permutation): out[c] = sum_r z[idx[r]] H[r][c] with plain fp32 FMAs -- k_in / 4 threads per row,
@@ -347,10 +343,14 @@ __device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char*
     float bs = 0.f;
     if (rlane < rl) {
         for (int r = r0 + rlane; r < r1; r += rl) {
-            const float zz = z[(int64_t)(zi ? zi[r] : r) * J.ldz];
-            const float4 hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+            float zz = z[(int64_t)(zi ? zi[r] : r) * J.ldz];
+            float4 hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+            if (J.pieces == 1) {   // (MPNHIP_PREC_BF16: the same operand rounding as the MFMA jobs)
+                zz = (float)(__bf16)zz;
+                hv = make_float4((float)(__bf16)hv.x, (float)(__bf16)hv.y, (float)(__bf16)hv.z, (float)(__bf16)hv.w);
+            }
             acc.x = fmaf(zz, hv.x, acc.x); acc.y = fmaf(zz, hv.y, acc.y); acc.z = fmaf(zz, hv.z, acc.z); acc.w = fmaf(zz, hv.w, acc.w);
-            bs += zz;
+            bs += z[(int64_t)(zi ? zi[r] : r) * J.ldz];   // (the bias gradient is a plain sum: not a product, nothing rounded)
         }
     }
     float* part = reinterpret_cast<float*>(lds);   // [rl][kc + 4]
@@ -401,20 +401,27 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
         for (int i = threadIdx.x; i < ROWS * n_out; i += WP_NT) {
             const int r = i / n_out, o = i - r * n_out;
             const int64_t row = r < nr ? (zi ? zi[m0 + r] : m0 + r) : 0;
-            zs[r][o] = r < nr ? dZ[row * J.ldz + o] : 0.f;
+            float v = r < nr ? dZ[row * J.ldz + o] : 0.f;
+            zs[r][o] = v;
         }
         for (int i = threadIdx.x; i < ROWS * kc; i += WP_NT) {
             const int r = i / kc, c = i - r * kc;
             const int64_t row = r < nr ? (hi ? hi[m0 + r] : m0 + r) : 0;
-            hs[r][c] = c == k_in ? (r < nr ? 1.f : 0.f) : (r < nr ? H[row * J.ldh + c] : 0.f);
+            float v = c == k_in ? (r < nr ? 1.f : 0.f) : (r < nr ? H[row * J.ldh + c] : 0.f);
+            hs[r][c] = J.pieces == 1 ? (float)(__bf16)v : v;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             if (threadIdx.x + WP_NT * q < nout_total) {
                 float sacc = acc[q];
+                if (J.pieces == 1 && cc[q] != k_in) {   // (bias column: a plain sum of dZ, nothing rounded)
 #pragma unroll 8
-                for (int r = 0; r < ROWS; ++r) sacc = fmaf(zs[r][oo[q]], hs[r][cc[q]], sacc);
+                    for (int r = 0; r < ROWS; ++r) sacc = fmaf((float)(__bf16)zs[r][oo[q]], hs[r][cc[q]], sacc);
+                } else {
+#pragma unroll 8
+                    for (int r = 0; r < ROWS; ++r) sacc = fmaf(zs[r][oo[q]], hs[r][cc[q]], sacc);
+                }
                 acc[q] = sacc;
             }
         }
@@ -443,7 +450,6 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
         case 1: wp_block<1, 5>(J, tile, by, wp_lds); break;
         case 2: wp_block<4, 1>(J, tile, by, wp_lds); break;
         case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
-        case 4: wp_block<2, 4>(J, tile, by, wp_lds); break;
         case 6: wp_block_vec(J, by, wp_lds); break;
         case 7: wp_block_small(J, by, wp_lds); break;
         default: wp_block<2, 2>(J, tile, by, wp_lds); break;
@@ -523,6 +529,7 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
     if (n_out <= 32 && k_in <= 32) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                  // wp_block_small
     long best = -1;
     for (int v = 0; v < 6; ++v) {
+        if (v == 4) continue;   // (<2, 4>: 128 accumulator registers + a stage in flight spill; 128 x 224 takes two <2, 2> tiles)
         const int bo = 64 * kVariants[v].tm, bc = 64 * kVariants[v].tn;
         const int to = (n_out + bo - 1) / bo, tc = (k_in + bc - 1) / bc;
         const long cost = (long)to * tc * (bo + bc) * 64 + to * tc;
@@ -610,6 +617,7 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
         J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
+        J.pieces = p.pieces == 1 ? 1 : 3;
         J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows; J.dz_idx = p.dz_idx; J.h_idx = p.h_idx;
         J.slab = b->slab + b->used;
         J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
