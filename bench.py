@@ -289,9 +289,7 @@ def main():
     have_bwd = mtrain.backward_available()
     mode = args.mode
     if mode == "auto":
-        mode = "train" if have_bwd and args.precision != "bf16" else "fwd"
-    if mode == "train" and args.precision == "bf16":
-        raise SystemExit("--precision bf16 is an inference mode")
+        mode = "train" if have_bwd and args.precision != "bf16" else "fwd"   # (bf16 operands: the forward is BASELINE.json's configs[4] line; --mode train runs its training step)
     model.gemm_precision = args.precision
     # 'auto' (the library's default, MOTMPNet.operand_precision): fp32 results from three-piece bf16 operands where the fused chain
     # kernels have the MFMA work for it (cfg-B / cfg-E widths; the reference's widths from ~32k edges: cfg-C), fp32 MFMAs on small graphs (cfg-D)
