@@ -225,6 +225,23 @@ int segment_reduce_csr2(const float* src, int64_t lds, const int* list, const in
 // dn = 32 backward: dX = dP Wx, dZn = dX (.) [x_prev > 0], dAGG = dZn Wu in one launch (segment.hip)
 int node_step32_bwd(const float* dP, int N, int pw, const float* Wx, int64_t ldwx, const float* x_prev, const float* Wu, float* dZn,
                     float* dAGG, hipStream_t stream);
+// dn = 64 / 128: aggregation -> node update -> the next step's projections in one launch, split operands (node_chain.hip)
+struct NodeChainArgs {
+    int N, dn, pw, agg;
+    const int* seg_ptr;             // graph CSR over keys dir * N + row
+    const float* M;                 // [E, dn] messages, sorted edge order
+    const unsigned short* wu_img;   // packed units (pack_node_chain)
+    const float* bu;                // [dn]
+    const unsigned short* wx_img;
+    const float* P0;                // [N, pw]
+    float* P_next;                  // [N, pw] or nullptr (last step)
+    float* x_new;                   // [N, dn]
+    float* agg_out;                 // [N, 2 dn] or nullptr
+};
+bool node_chain_supported(int dn, int pw, int kx);
+size_t node_chain_image_shorts(int dn, int pw, size_t* off_wx);
+int pack_node_chain(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s);
+int launch_node_chain(const NodeChainArgs& a, hipStream_t s);
 // one segment_reduce_csr2 call as data; segment_reduce_csr2_x3: three of them, in one launch where the block kernel applies
 struct SegReduce2 {
     const float* src; int64_t lds; const int* list; const int* ptr; int nseg; int dim; float* out; int64_t ldo; int nmod; int off0; int off1;
@@ -278,7 +295,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_COUNT
 };
 void count_path(int id);
 

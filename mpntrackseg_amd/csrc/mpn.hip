@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -347,6 +347,7 @@ struct StepIO {
     int fuse_node;                        // 1: aggregate + node update (+ the NEXT step's projections unless `last`) in one launch
     int last;                             //    (node_step32: the reference's node width)
     float* P_next;                        //    where the next step's projections go (its step buffers; inference: the shared ones)
+    const unsigned short* nc_img;         //    non-null: node_chain.hip's kernel (dn = 64 / 128, split precision) instead of node_step32
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -481,6 +482,13 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         MPN_TRY(mlp_tail(m.flow_out, &m.flow_in, &g, b.HF, b.M, d.dn, nullptr, E, s));
     }
     // (5) aggregation (node_agg_fn, mpn.py:89,96) and node update (mpn.py:97-99)
+    if (io.fuse_node && io.nc_img) {
+        size_t off_wx = 0;
+        node_chain_image_shorts(d.dn, d.pw, &off_wx);
+        NodeChainArgs a = {(int)N, d.dn, d.pw, m.agg, g.seg_ptr, b.M, io.nc_img, m.node.bias[0], io.nc_img + off_wx, io.P0,
+                           io.last ? nullptr : io.P_next, io.x_new, save_acts ? b.AGG : nullptr};
+        return launch_node_chain(a, s);
+    }
     if (io.fuse_node) {
         MPN_TRY(node_step32(g, b.M, m.agg, m.node.weight[0], m.node.bias[0], io.x_new, save_acts ? b.AGG : nullptr, Wnode + io.kxa, d.kx,
                             io.P0, io.last ? nullptr : io.P_next, d.pw, s));
@@ -676,6 +684,9 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         MPN_TRY(rc);
         MPN_TRY(rf);
         MPN_TRY(rs);
+        // (after the flush: the unit images of the fused node-side kernel read the packed projection weights)
+        if (p.nc_img && m.precision == MPNHIP_PREC_FP32_SPLIT)
+            MPN_TRY(pack_node_chain(m.node.weight[0], p.Wnode, d.dn, d.pw, d.kx, p.nc_img, s));
     }
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
@@ -725,9 +736,13 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     // hoisted P0 form of the projections and 16-byte aligned weights; training with max aggregation keeps the separate
     // kernels (the fused one does not record the arg max)
     // (every 2-node block re-reads the 43 KB of node-side weights from L2: beyond a few thousand nodes the GEMMs win again)
-    const bool fuse_node = (!save || m.agg != MPNHIP_AGG_MAX) && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && N <= 4096 && m.precision != MPNHIP_PREC_BF16 &&
-                           ((((uintptr_t)m.node.weight[0]) | ((uintptr_t)p.P0) | ((uintptr_t)p.Wnode)) & 15) == 0 &&
-                           !getenv("MPNHIP_NO_NODE_FUSION");
+    const bool fuse_node32 = (!save || m.agg != MPNHIP_AGG_MAX) && hoist && d.dn == 32 && d.pw % 4 == 0 && E > 0 && N > 0 && N <= 4096 && m.precision != MPNHIP_PREC_BF16 &&
+                             ((((uintptr_t)m.node.weight[0]) | ((uintptr_t)p.P0) | ((uintptr_t)p.Wnode)) & 15) == 0 &&
+                             !getenv("MPNHIP_NO_NODE_FUSION");
+    // wider models in the split precision: the same three launches as one (node_chain.hip)
+    const bool fuse_node_chain = (!save || m.agg != MPNHIP_AGG_MAX) && hoist && p.nc_img && m.precision == MPNHIP_PREC_FP32_SPLIT && E > 0 && N > 0 &&
+                                 m.node.n_layers == 1 && (((uintptr_t)m.node.bias[0]) & 15) == 0;
+    const bool fuse_node = fuse_node32 || fuse_node_chain;
     if (proj_small) {
         const int64_t total = N * d.pw;
         hipLaunchKernelGGL(k_proj_hoist32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x0, p.Wnode, p.bnode, p.P0, step_at(p, 0).P,
@@ -751,6 +766,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.P0 = hoist ? p.P0 : nullptr;
         io.Q0 = hoist_e ? p.Q0 : nullptr;
         io.fuse_node = fuse_node ? 1 : 0;
+        io.nc_img = fuse_node_chain ? p.nc_img : nullptr;
         io.p_ready = (fuse_node && step > 0) || (proj_small && step == 0) ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;

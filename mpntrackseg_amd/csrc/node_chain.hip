@@ -1,0 +1,260 @@
+// The node side of one message-passing step in ONE launch (TimeAwareNodeModel.forward, reference models/mpn.py:85-99, and the
+// per-node projections the next step's edge kernel gathers):
+//   AGG[n]  = [ node_agg_fn over n's flow_in messages | ... flow_out messages ]          (mpn.py:89,96,97)
+//   x'[n]   = relu(Wu AGG[n] + bu)                                                        (mpn.py:98-99)
+//   P'[n]   = P0[n] + Wx x'[n]          the next step's [Pr | Pc | Pf_out | Pf_in] rows (P0: the re-attached x0's share + biases)
+// for widths above the reference's (dn = 64 / 128; dn = 32 has k_node_step32, segment.hip).  Before: k_aggregate + two launches of
+// the GEMM kernel (7 + 11 + 22 us at cfg-B: 157 row tiles of a [5000 x 128] x [128 x 1088] product are four K steps each -- all
+// prologue and epilogue).  Here a block owns 32 nodes:
+//   A. aggregation: dn / 4 lanes per (node, direction) segment read whole message rows, 4 rows in flight, in segment order; the
+//      tile [32 nodes][2 dn] goes to LDS (and to HBM when the backward needs it);
+//   B. x' tile t by wave t: transposed product D^T[feature][node] (nodes on the MFMA's lane dimension), fp32 operands as three bf16
+//      pieces, six v_mfma_f32_32x32x16_bf16 per 16 contraction steps (edge_chain.hip section "split operands"); bias, ReLU; x' to LDS;
+//   C. every wave takes every 4th 32-feature tile of P': C-in = the gathered P0 tile, 6 x dn / 16 products, rows stored.
+// Weights: packed once per forward as 1 KiB MFMA A-operand units [output tile][k block][piece] (k_pack_node_units), read
+// straight from L2 by contiguous 16-byte-per-lane loads, four k blocks ahead -- every block reads the same 1 MB image.
+#include "common.h"
+
+namespace mpnhip {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct NSplit8 { bf16x8 p[3]; };
+__device__ __forceinline__ NSplit8 nsplit8(const float4 lo, const float4 hi) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    NSplit8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float a = x[i] - (float)h;
+        const __bf16 m = (__bf16)a;
+        o.p[0][i] = h; o.p[1][i] = m; o.p[2][i] = (__bf16)(a - (float)m);
+    }
+    return o;
+}
+__device__ __forceinline__ void nmfma6(f32x16& acc, const bf16x8 (&a)[3], const NSplit8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.p[0], acc, 0, 0, 0);
+}
+// the three pieces of one (tile, k block): 3 x 1 KiB, lane * 16 bytes each
+__device__ __forceinline__ void ld_units(const unsigned short* img, int unit0, int lane, bf16x8 (&a)[3]) {
+    const uint4* p = reinterpret_cast<const uint4*>(img + (size_t)unit0 * 512) + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x8, p[q * 64]);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
+    constexpr int DN = 32 * DT, K2 = 2 * DN, KB2 = K2 / 16, KB1 = DN / 16;
+    constexpr int AP = K2 + 4, XP = DN + 4;      // LDS row pitches (floats): a lane's 16-byte pieces of 16 rows cover the banks once
+    constexpr int RD = 4;                        // k blocks of weight units in flight (phase B)
+    constexpr int RC = KB1;                      // ... phase C: a whole output tile ahead (L2 latency under 157 blocks' streams ~ 1 us)
+    static_assert(KB2 % RD == 0, "ring depth");
+    __shared__ __attribute__((aligned(16))) float agg_s[32 * AP];
+    __shared__ __attribute__((aligned(16))) float x_s[32 * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int N = A.N;
+
+    // ---- A. aggregation into LDS ------------------------------------------------------------------------------------------
+    // all 64 (node, direction) segments at once, 4 lanes each (a lane owns DN / 4 consecutive features = DN / 16 16-byte pieces of a
+    // row); two rows in flight per lane, added in segment order.  (One round: the offsets -> rows latency chain is paid once,
+    // not once per round of a few wide workers.)
+    {
+        constexpr int PC = DN / 16;              // 16-byte pieces per lane and row
+        const int sgm = tid >> 2, c0 = (tid & 3) * (DN / 4);
+        const int nl = sgm >> 1, q = sgm & 1;    // q = 0: flow_out (keys [0, N)), 1: flow_in ([N, 2N))
+        const int node = n0 + nl;
+        float4 acc[PC];
+#pragma unroll
+        for (int u = 0; u < PC; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node < N) {
+            const int key = q * N + node;
+            const int b = A.seg_ptr[key], e = A.seg_ptr[key + 1];
+            const float* src = A.M + c0;
+            if (A.agg == MPNHIP_AGG_MAX) {
+                if (e > b) {
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) acc[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    for (int j = b; j < e; ++j) {
+#pragma unroll
+                        for (int u = 0; u < PC; ++u) {
+                            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * DN + 4 * u);
+                            acc[u].x = fmaxf(acc[u].x, v.x); acc[u].y = fmaxf(acc[u].y, v.y); acc[u].z = fmaxf(acc[u].z, v.z); acc[u].w = fmaxf(acc[u].w, v.w);
+                        }
+                    }
+                }                                 // empty segment -> 0 (torch_scatter fills with 0)
+            } else {
+                int j = b;
+                for (; j + 2 <= e; j += 2) {
+                    float4 v0[PC], v1[PC];
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) {
+                        v0[u] = *reinterpret_cast<const float4*>(src + (int64_t)j * DN + 4 * u);
+                        v1[u] = *reinterpret_cast<const float4*>(src + (int64_t)(j + 1) * DN + 4 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) {
+                        acc[u].x += v0[u].x; acc[u].y += v0[u].y; acc[u].z += v0[u].z; acc[u].w += v0[u].w;
+                        acc[u].x += v1[u].x; acc[u].y += v1[u].y; acc[u].z += v1[u].z; acc[u].w += v1[u].w;
+                    }
+                }
+                if (j < e) {
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * DN + 4 * u);
+                        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+                    }
+                }
+                if (A.agg == MPNHIP_AGG_MEAN) {
+                    const float inv = 1.f / (float)(e - b > 1 ? e - b : 1);
+#pragma unroll
+                    for (int u = 0; u < PC; ++u) { acc[u].x *= inv; acc[u].y *= inv; acc[u].z *= inv; acc[u].w *= inv; }
+                }
+            }
+        }
+        // torch.cat((flow_in, flow_out)) (mpn.py:97): flow_in on the left
+#pragma unroll
+        for (int u = 0; u < PC; ++u) *reinterpret_cast<float4*>(&agg_s[nl * AP + (q == 0 ? DN : 0) + c0 + 4 * u]) = acc[u];
+    }
+    __syncthreads();
+    if (A.agg_out) {   // kept for the backward pass
+        for (int i = tid; i < 32 * (K2 / 4); i += 256) {
+            const int nl = i / (K2 / 4), c = (i - nl * (K2 / 4)) * 4;
+            if (n0 + nl < N) *reinterpret_cast<float4*>(A.agg_out + (int64_t)(n0 + nl) * K2 + c) = *reinterpret_cast<const float4*>(&agg_s[nl * AP + c]);
+        }
+    }
+
+    // ---- B. x' = relu(Wu AGG + bu): output tile `wave` ----------------------------------------------------------------------
+    if (wave < DT) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        bf16x8 ring[RD][3];
+#pragma unroll
+        for (int s = 0; s < RD; ++s) ld_units(A.wu_img, (wave * KB2 + s) * 3, lane, ring[s]);
+#pragma unroll
+        for (int kb = 0; kb < KB2; ++kb) {
+            const float* xr = &agg_s[lj * AP + 16 * kb + 8 * lh];
+            const NSplit8 b = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
+            nmfma6(acc, ring[kb % RD], b);
+            if (kb + RD < KB2) ld_units(A.wu_img, (wave * KB2 + kb + RD) * 3, lane, ring[kb % RD]);
+        }
+        const bool ok = n0 + lj < N;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = 32 * wave + 8 * g + 4 * lh;
+            const float4 bias = *reinterpret_cast<const float4*>(A.bu + n);
+            const float4 v = make_float4(fmaxf(acc[4 * g + 0] + bias.x, 0.f), fmaxf(acc[4 * g + 1] + bias.y, 0.f),
+                                         fmaxf(acc[4 * g + 2] + bias.z, 0.f), fmaxf(acc[4 * g + 3] + bias.w, 0.f));
+            *reinterpret_cast<float4*>(&x_s[lj * XP + n]) = v;
+            if (ok) *reinterpret_cast<float4*>(A.x_new + (int64_t)(n0 + lj) * DN + n) = v;
+        }
+    }
+    __syncthreads();
+    if (!A.P_next) return;   // last step: no projections needed
+
+    // ---- C. P' = P0 + Wx x': tiles wave, wave + 4, ... -----------------------------------------------------------------------
+    NSplit8 bx[KB1];
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+        const float* xr = &x_s[lj * XP + 16 * kb + 8 * lh];
+        bx[kb] = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
+    }
+    const int NT = A.pw / 32;
+    const int node = n0 + lj < N ? n0 + lj : N - 1;
+    const bool ok = n0 + lj < N;
+    const float* p0r = A.P0 + (int64_t)node * A.pw + 4 * lh;
+    float* pnr = A.P_next + (int64_t)node * A.pw + 4 * lh;
+    if (wave >= NT) return;
+    // this wave's tiles: wave, wave + 4, ...; every block walks them from a different starting tile (all blocks stream the same
+    // 1 MB image: started together on the same units they queue on the same L2 channels)
+    const int cnt = (NT - wave + 3) / 4;
+    int ii = (int)((blockIdx.x * 5u) % (unsigned)cnt);
+    int t = wave + 4 * ii;
+    bf16x8 ring[RC][3];
+#pragma unroll
+    for (int s = 0; s < RC; ++s) ld_units(A.wx_img, (t * KB1 + s) * 3, lane, ring[s]);
+    float4 cin[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * t + 8 * g);
+    for (int it = 0; it < cnt; ++it) {
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = cin[g].x; acc[4 * g + 1] = cin[g].y; acc[4 * g + 2] = cin[g].z; acc[4 * g + 3] = cin[g].w; }
+        ii = ii + 1 < cnt ? ii + 1 : 0;
+        const int tn = wave + 4 * ii;            // (after the last tile: the first one again -- unconditional loads)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * tn + 8 * g);
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            nmfma6(acc, ring[kb], bx[kb]);
+            ld_units(A.wx_img, (tn * KB1 + kb) * 3, lane, ring[kb]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(pnr + 32 * t + 8 * g) = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        t = tn;
+    }
+}
+
+// units [tile t][k block kb][piece]: lane (m = lane & 31, g = lane >> 5), element i = piece(W[32 t + m][col0 + 16 kb + 8 g + i])
+__global__ __launch_bounds__(64) void k_pack_node_units(const float* __restrict__ W, int64_t ldw, int col0, int n_out, int K,
+                                                         unsigned short* __restrict__ dst) {
+    const int lane = threadIdx.x, m = lane & 31, g = lane >> 5;
+    const int kbs = (K + 15) / 16;
+    const int t = blockIdx.x / kbs, kb = blockIdx.x - t * kbs;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = 32 * t + m, k = 16 * kb + 8 * g + i;
+        x[i] = (n < n_out && k < K) ? W[(int64_t)n * ldw + col0 + k] : 0.f;
+    }
+    const NSplit8 s = nsplit8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+    uint4* out = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * 3 * 512) + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q * 64] = __builtin_bit_cast(uint4, s.p[q]);
+}
+
+}  // namespace
+
+bool node_chain_supported(int dn, int pw, int kx) {
+    return (dn == 64 || dn == 128) && pw % 32 == 0 && pw >= 32 && kx == 2 * dn && !getenv("MPNHIP_NO_NODE_CHAIN");
+}
+size_t node_chain_image_shorts(int dn, int pw, size_t* off_wx) {
+    const size_t wu = (size_t)(dn / 32) * (2 * dn / 16) * 3 * 512;
+    if (off_wx) *off_wx = wu;
+    return wu + (size_t)(pw / 32) * (dn / 16) * 3 * 512;
+}
+// Wu: node update weight [dn, 2 dn]; Wnode: packed projection weights [pw, kx], their current-feature columns [dn, 2 dn)
+int pack_node_chain(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s) {
+    size_t off = 0;
+    node_chain_image_shorts(dn, pw, &off);
+    hipLaunchKernelGGL(k_pack_node_units, dim3((dn / 32) * (2 * dn / 16)), dim3(64), 0, s, Wu, (int64_t)2 * dn, 0, dn, 2 * dn, img);
+    hipLaunchKernelGGL(k_pack_node_units, dim3((pw / 32) * (dn / 16)), dim3(64), 0, s, Wnode, (int64_t)kx, dn, pw, dn, img + off);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+int launch_node_chain(const NodeChainArgs& a, hipStream_t s) {
+    if (a.N <= 0) return MPNHIP_OK;
+    count_path(PC_NODE_CHAIN);
+    const unsigned blocks = (unsigned)((a.N + 31) / 32);
+    if (a.dn == 128) hipLaunchKernelGGL(node_chain_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    else if (a.dn == 64) hipLaunchKernelGGL(node_chain_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    else { set_error("node_chain: unsupported width %d", a.dn); return MPNHIP_ERR_UNSUPPORTED; }
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+}  // namespace mpnhip

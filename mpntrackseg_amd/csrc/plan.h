@@ -133,6 +133,7 @@ struct FwdPlan {
     float* bnode;  // [pw]
     ChainWeights cw;
     ChainBf16 cb;
+    unsigned short* nc_img;   // unit images of the fused node-side kernel (node_chain.hip) or nullptr
     float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
     float* Q0;     // [E, he] step-invariant share of the edge MLP's first layer: e0 W1[:, e0 columns]^T (fused chain only)
     float* enc_n[2];
@@ -205,6 +206,9 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
             p.cb.img = reinterpret_cast<char*>(a.f(bytes / 4));
         }
     }
+    p.nc_img = nullptr;
+    if (node_chain_supported(d.dn, d.pw, d.kx) && m.node.n_layers == 1)
+        p.nc_img = reinterpret_cast<unsigned short*>(a.f((node_chain_image_shorts(d.dn, d.pw, nullptr) + 1) / 2));
     p.P0 = a.f((size_t)N * d.pw);
     p.Q0 = a.f((size_t)E * d.he);
     int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);

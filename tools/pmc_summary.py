@@ -20,6 +20,9 @@ KEYS = {  # json key -> substring of the kernel name (+ optional grid filter)
     "edge_chain_bwd": "edge_chain_bwd_kernel",
     "k_aggregate": "k_aggregate",
     "gemm_tn": "gemm_tn_kernel",
+    "wgrad_panel": "wgrad_panel_kernel",
+    "wgrad_reduce": "wgrad_reduce_kernel",
+    "segment_reduce3": "k_segment_reduce3",
 }
 
 

@@ -2,13 +2,16 @@
 # Round measurement set (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats of the default bench
 # command, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only), tracking-driver numbers.
 # Outputs land in gpurun_out/$RND/; copy what should be judged into profiles/$RND/.
-RND=${RND:-r02}
+RND=${RND:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$RND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_$RND.json
-python $R/bench.py --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_fwd_$RND.json
+python $R/bench.py --config E --precision bf16 --mode train --steps 3 --warmup 1 --no-cpu-baseline --no-split-line --no-extras 2>&1 | tail -1 > $O/bench_cfgE_bf16_train_$RND.json
+python $R/tools/wgrad_bench.py --check --split > $O/wgrad_bench_split_$RND.txt 2>&1
+python $R/tools/wgrad_bench.py --check > $O/wgrad_bench_fp32_$RND.txt 2>&1
+python $R/bench.py --mode fwd --no-cpu-baseline --no-extras 2>&1 | tail -1 > $O/bench_fwd_$RND.json
 python $R/bench.py --config C --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_train_$RND.json
 python $R/bench.py --config C --mode fwd --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgC_fwd_$RND.json
 python $R/bench.py --config D --mode train --no-cpu-baseline 2>&1 | tail -1 > $O/bench_cfgD_train_$RND.json
@@ -16,22 +19,23 @@ python $R/bench.py --config D --mode fwd --steps 300 --warmup 20 --no-cpu-baseli
 python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 2>&1 | tail -1 > $O/bench_cfgE_bf16_fwd_$RND.json
 python $R/bench.py --config E --precision fp32 --mode fwd --steps 6 --warmup 2 --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_cfgE_fp32_fwd_$RND.json
 # the default precision is 'auto' (cfg-B: MPNHIP_PREC_FP32_SPLIT, cfg-C / D: fp32 MFMAs); fp32 MFMAs everywhere: own bench lines
-python $R/bench.py --precision fp32 --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_fp32mfma_$RND.json
-python $R/bench.py --precision fp32 --mode fwd --no-cpu-baseline --no-split-line 2>&1 | tail -1 > $O/bench_fwd_fp32mfma_$RND.json
+python $R/bench.py --precision fp32 --no-cpu-baseline --no-split-line --no-extras 2>&1 | tail -1 > $O/bench_fp32mfma_$RND.json
+python $R/bench.py --precision fp32 --mode fwd --no-cpu-baseline --no-split-line --no-extras 2>&1 | tail -1 > $O/bench_fwd_fp32mfma_$RND.json
 # kernel stats of the default command and of the cfg-E line
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-split-line > $O/stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-split-line --no-extras > $O/stats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd -- python $R/bench.py --mode fwd --no-cpu-baseline --no-split-line > $O/stats_fwd.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_cfgE.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgC -- python $R/bench.py --config C --no-cpu-baseline --no-split-line > $O/stats_cfgC.log 2>&1
 # HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_fetch32.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line > $O/pmc_write32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write32.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_E.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_E.log 2>&1
 cd $R
 python tools/track_bench.py 2>/dev/null | tail -1 > $O/track_bench_$RND.json
+python tools/step_timeline.py $O/stats > $O/step_timeline_cfgB_train.txt 2>/dev/null
 F=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv | head -1)
 python tools/pmc_summary.py $F $W $O/pmc_summary_split.json > /dev/null
 F=$(ls $O/pmc_fetch32/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write32/*/*counter_collection.csv | head -1)
