@@ -242,6 +242,30 @@ bool node_chain_supported(int dn, int pw, int kx);
 size_t node_chain_image_shorts(int dn, int pw, size_t* off_wx);
 int pack_node_chain(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s);
 int launch_node_chain(const NodeChainArgs& a, hipStream_t s);
+// the whole step loop of an inference forward at the reference's widths in one launch (persist32.hip)
+struct Persist32Args {
+    int N, L, agg, pw, he, hn, hc, nodes_per_block;
+    int64_t E;
+    const int* seg_ptr; const int* srow; const int* scol; const int* perm;
+    const float* e0;               // [E, 16] encoder output, sorted order
+    float* e;                      // [E, 16] current edge features (written by step 1 on; the final e' on return)
+    const float* P0;               // [N, pw]
+    float* P[2];                   // P[0]: the first step's projections on entry
+    const float* W1; int64_t ld_w1; int col_w1;           // edge layer 0 [he, in_dim], its [e0 | e] columns start at col_w1
+    const float* W2;               // edge layer 1 [16, he]
+    const float* Wc1;              // classifier layer 0 [hc, 16]
+    const float* Wf1[2]; int64_t ld_wf1; int col_wf1;     // flow layer 0 [hn, in_dim], e' columns from col_wf1 (0: flow_out, 1: flow_in)
+    const float* Wf2[2];           // flow layer 1 [32, hn]
+    const float* Wu;               // node update [32, 64]
+    const float* Wnode;            // packed projections [pw, 64]
+    const float* b2; const float* bc1; const float* wc2; const float* bc2; const float* bf2[2]; const float* bu;
+    float* logits;                 // [L, E] original edge order
+    float* x_out;                  // [N, 32] the last step's node features
+    unsigned* barrier;             // 4 words, zeroed by the launcher: [0] arrivals, [1] set when a wait gave up
+    int debug;                     // timing experiments only (MPNHIP_PERSIST_DEBUG): 1 no barrier, 2 no edge tiles, 4 no node update
+};
+bool persist32_supported(int dn, int de, int he, int hn, int hc, int pw, int kx, int64_t N, int64_t E);
+int launch_persist32(Persist32Args a, hipStream_t s);
 // one segment_reduce_csr2 call as data; segment_reduce_csr2_x3: three of them, in one launch where the block kernel applies
 struct SegReduce2 {
     const float* src; int64_t lds; const int* list; const int* ptr; int nseg; int dim; float* out; int64_t ldo; int nmod; int off0; int off1;
@@ -295,7 +319,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_COUNT
 };
 void count_path(int id);
 

@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -750,7 +750,29 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         MPN_LAUNCH_CHECK();
     }
     int prev = 0;
-    for (int step = 0; step < d.L; ++step) {
+    // inference at the reference's widths: the whole step loop in one launch (persist32.hip); every fp32-class precision (the
+    // kernel computes on fp32 MFMAs)
+    const bool persist = !save && proj_small && d.ef == 2 && d.L >= 1 && m.precision != MPNHIP_PREC_BF16 && m.edge.n_layers == 2 &&
+                         m.flow_in.n_layers == 2 && m.flow_out.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
+                         m.node.n_layers == 1 && p.P_alt && (((uintptr_t)e0) & 15) == 0 &&
+                         persist32_supported(d.dn, d.de, d.he, d.hn, m.classifier.out_dims[0], d.pw, d.kx, N, E);
+    if (persist) {
+        Persist32Args a = {};
+        a.N = (int)N; a.L = d.L; a.agg = m.agg; a.pw = d.pw; a.he = d.he; a.hn = d.hn; a.hc = m.classifier.out_dims[0]; a.E = E;
+        a.seg_ptr = g.seg_ptr; a.srow = g.srow; a.scol = g.scol; a.perm = g.perm;
+        a.e0 = e0; a.e = p.e_hist + es; a.P0 = p.P0; a.P[0] = step_at(p, 0).P; a.P[1] = p.P_alt;
+        a.W1 = m.edge.weight[0]; a.ld_w1 = m.edge.in_dim; a.col_w1 = 2 * d.kx;
+        a.W2 = m.edge.weight[1]; a.Wc1 = m.classifier.weight[0];
+        a.Wf1[0] = m.flow_out.weight[0]; a.Wf1[1] = m.flow_in.weight[0]; a.ld_wf1 = m.flow_out.in_dim; a.col_wf1 = d.kx;
+        a.Wf2[0] = m.flow_out.weight[1]; a.Wf2[1] = m.flow_in.weight[1];
+        a.Wu = m.node.weight[0]; a.Wnode = p.Wnode;
+        a.b2 = m.edge.bias[1]; a.bc1 = m.classifier.bias[0]; a.wc2 = m.classifier.weight[1]; a.bc2 = m.classifier.bias[1];
+        a.bf2[0] = m.flow_out.bias[1]; a.bf2[1] = m.flow_in.bias[1]; a.bu = m.node.bias[0];
+        a.logits = logits; a.x_out = p.x_hist + xs; a.barrier = reinterpret_cast<unsigned*>(p.barrier);
+        MPN_TRY(launch_persist32(a, s));
+        prev = 1;
+    }
+    for (int step = 0; step < d.L && !persist; ++step) {
         int cur = save ? step + 1 : 1 + (step & 1);
         StepBufs b = step_at(p, step);
         StepIO io = {};

@@ -134,6 +134,8 @@ struct FwdPlan {
     ChainWeights cw;
     ChainBf16 cb;
     unsigned short* nc_img;   // unit images of the fused node-side kernel (node_chain.hip) or nullptr
+    float* P_alt;  // [N, pw] (inference, dn = 32) or nullptr
+    int* barrier;  // 4 words: grid barrier of the one-launch step loop
     float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
     float* Q0;     // [E, he] step-invariant share of the edge MLP's first layer: e0 W1[:, e0 columns]^T (fused chain only)
     float* enc_n[2];
@@ -210,6 +212,8 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     if (node_chain_supported(d.dn, d.pw, d.kx) && m.node.n_layers == 1)
         p.nc_img = reinterpret_cast<unsigned short*>(a.f((node_chain_image_shorts(d.dn, d.pw, nullptr) + 1) / 2));
     p.P0 = a.f((size_t)N * d.pw);
+    p.P_alt = (!save && d.dn == 32) ? a.f((size_t)N * d.pw) : nullptr;   // second projection buffer of the one-launch step loop (persist32.hip)
+    p.barrier = a.i(4);
     p.Q0 = a.f((size_t)E * d.he);
     int hn_ = max_hidden(m.enc_node), he_ = max_hidden(m.enc_edge);
     if (save) {

@@ -814,3 +814,31 @@ def test_mlp_batchnorm_and_dropout_eval_mode():
     assert float((lg2.detach() - lg).abs().max()) <= 1e-6 * max(1.0, float(lg.abs().max()))
     with pytest.raises(capi.MpnhipError):
         lg2.sum().backward()
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_one_launch_step_loop_matches_the_reference_fixtures(golden, agg, monkeypatch):
+    """csrc/persist32.hip (the whole message-passing loop of an inference forward in one launch, opt-in through MPNHIP_PERSIST=1:
+    it measured slower than the launch-per-module path): the reference's own outputs g2 (cfg-A, 6 steps) and
+    g4 (structure corner cases: isolated nodes, one-sided nodes, batched sub-graphs, self loops) within the fp32 tolerances."""
+    monkeypatch.setenv("MPNHIP_PERSIST", "1")
+    z = golden(f"g2_cfgA_{agg}.npz")
+    c = synth.CONFIGS["A"]
+    g = synth.make_graph(c["N"], c["E"], seed=1)
+    params = synth.model_params(c["d"], c["L"], agg)
+    model = make_model(params, synth.make_weights(params, seed=7), "fp32")
+    capi.path_counters(reset=True)
+    logits, xo, eo = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert capi.path_counters(reset=True)["persist32"] == 1
+    for s in range(c["L"]):
+        scale = max(1.0, float(z["step_max"][s])) if agg == "sum" else 1.0
+        assert float(np.abs(logits[s] - z["logits"][s]).max()) / scale < TOL, s
+    z4 = golden("g4_structure.npz")
+    params = synth.model_params(32, 3, agg, node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=8), "fp32")
+    err = logit_err(agg)
+    logits, xo, eo = run_hot(model, z4["x"], z4["edge_index"], z4["edge_attr"])
+    assert capi.path_counters(reset=True)["persist32"] == 1
+    assert err(logits, z4[f"logits_{agg}"]) < TOL
+    assert err(xo, z4[f"x_final_{agg}"]) < TOL
+    assert err(eo, z4[f"e_final_{agg}"]) < TOL
