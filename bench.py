@@ -176,7 +176,7 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
         for _ in range(warmup):
             step()
         if profile:
-            lib.mpnhip_profile_enable(3)
+            lib.mpnhip_profile_enable(5)   # coprime with the launches per step (4 / 7 / 12 chain, 3 weight-gradient)
         capi.path_counters(reset=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -342,7 +342,8 @@ def main():
         step()
     profiled = rank == 0 and not args.no_roofline
     if profiled:
-        lib.mpnhip_profile_enable(6)  # HIP events attached to every 6th launch of each profiled kernel kind
+        lib.mpnhip_profile_enable(7)  # HIP events attached to every 7th launch of each profiled kernel kind (7: coprime with the 12 chain
+        # launches and the 3 differently-sized weight-gradient launches of a step, so every position of a step is sampled)
     capi.path_counters(reset=True)
     barrier()
     torch.cuda.synchronize()

@@ -76,6 +76,14 @@ __device__ __forceinline__ bf16x8 tr_read(const char* base) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void wp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wp_static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
     // smallest products first (edge_chain.hip mfma6)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
@@ -150,7 +158,11 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x4 zreg[1][PZ], hreg[1][PH];   // the next stage, in flight under the current one's products
+    // stages in flight under the current one's products: ONE for the wide variants (a stage is 20 - 24 registers there), two or
+    // four for the narrow ones (a <1, 1> stage is 16 rows x 128 columns = 8 KB per block: with one in flight the kernel waits out
+    // the HBM latency every 16 rows -- 1.4 TB/s on the 32-d products of the reference's configuration)
+    constexpr int D = TM + TN <= 2 ? 4 : (TM + TN <= 5 && TM * TN <= 4 ? 2 : 1);
+    f32x4 zreg[D][PZ], hreg[D][PH];
 
     // full stages: rows m0 .. m0 + 15 all inside the chunk.  (Compiler-visible loads on purpose.  Inline-assembly loads into TWO
     // stage buffers with hand-counted s_waitcnt kept two whole stages in flight -- hipcc's own placement waits for every
@@ -158,8 +170,6 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     // registers of an asm load are, to the compiler, ready when the statement ends: wherever its allocation put a copy or reused
     // one of them before the hand-placed wait, the late-landing load overwrote live values -- memory faults on short chunks of
     // the <2, 4> variant.  Not worth 3 %; and two compiler-visible buffers spill in that variant.)
-    f32x4(&z0)[PZ] = zreg[0];
-    f32x4(&h0)[PH] = hreg[0];
 #define WP_LOAD(ZR, HR, m0)                                                                                              \
     do {                                                                                                                 \
         const char* zb_ = zbase + (int64_t)(m0) * ldz * 4;                                                               \
@@ -260,13 +270,30 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     const int nfull = (r1 - r0) / WP_KB;          // full stages
     const int tail = (r1 - r0) - nfull * WP_KB;   // rows of the partial last stage (0: none)
     if (nfull > 0) {
-        WP_LOAD(z0, h0, r0);
-        for (int st = 0; st < nfull; ++st) {
-            store(B0{}, WP_KB);
-            __syncthreads();
-            if (st + 1 < nfull) WP_LOAD(z0, h0, r0 + (st + 1) * WP_KB);
-            products();
-            __syncthreads();
+        wp_static_for<0, D>([&](auto d) {
+            if (d.value < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + d.value * WP_KB);
+        });
+        int st = 0;
+        // steady state (every stage of the round has a successor D stages on: straight-line code, the loads' waits are counted)
+        for (; st + 2 * D <= nfull; st += D) {
+            wp_static_for<0, D>([&](auto d) {
+                store(d, WP_KB);
+                __syncthreads();
+                WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
+                products();
+                __syncthreads();
+            });
+        }
+        for (; st < nfull; st += D) {
+            wp_static_for<0, D>([&](auto d) {
+                if (st + d.value < nfull) {   // (block-uniform)
+                    store(d, WP_KB);
+                    __syncthreads();
+                    if (st + d.value + D < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
+                    products();
+                    __syncthreads();
+                }
+            });
         }
     }
     if (tail > 0) {
@@ -367,15 +394,17 @@ __device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char*
     }
 }
 
-// Narrow products (n_out <= 32, k_in <= 32, any alignment; rows of either operand optionally gathered: the reference's 18-wide
+// Narrow products (k_in <= 32 and n_out <= 32 -- or n_out <= 96 while n_out (k_in + 1) <= 1280: the edge encoder's first layer
+// at 128-d, [72 x 6] --, any alignment; rows of either operand optionally gathered: the reference's 18-wide
 // edge encoder -- its first layer reads edge_attr through the sort permutation --, classifier layers): a block stages 64 rows of
 // dZ and H in LDS and every thread owns up to five output elements (o, c) -- c == k_in is the bias column, fed by a column of
 // ones -- reading dZ as a broadcast and H conflict-free; plain fp32 FMAs (gemm_tn_small_kernel's scheme, as a job of this launch).
 __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, char* lds) {
     constexpr int ROWS = 64;
-    float (*zs)[33] = reinterpret_cast<float (*)[33]>(lds);
-    float (*hs)[34] = reinterpret_cast<float (*)[34]>(lds + ROWS * 33 * sizeof(float));
     const int n_out = J.n_out, k_in = J.k_in, kc = k_in + 1;
+    const int zp = n_out <= 32 ? 33 : 97;   // (odd row pitch)
+    float* const zs = reinterpret_cast<float*>(lds);
+    float (*hs)[34] = reinterpret_cast<float (*)[34]>(lds + ROWS * zp * sizeof(float));
     const int nout_total = n_out * kc;
     const int rb = J.row_begin ? *J.row_begin : 0;
     const int re = J.row_end ? *J.row_end : (int)J.m_static;
@@ -402,7 +431,7 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
             const int r = i / n_out, o = i - r * n_out;
             const int64_t row = r < nr ? (zi ? zi[m0 + r] : m0 + r) : 0;
             float v = r < nr ? dZ[row * J.ldz + o] : 0.f;
-            zs[r][o] = v;
+            zs[r * zp + o] = v;
         }
         for (int i = threadIdx.x; i < ROWS * kc; i += WP_NT) {
             const int r = i / kc, c = i - r * kc;
@@ -417,10 +446,10 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
                 float sacc = acc[q];
                 if (J.pieces == 1 && cc[q] != k_in) {   // (bias column: a plain sum of dZ, nothing rounded)
 #pragma unroll 8
-                    for (int r = 0; r < ROWS; ++r) sacc = fmaf((float)(__bf16)zs[r][oo[q]], hs[r][cc[q]], sacc);
+                    for (int r = 0; r < ROWS; ++r) sacc = fmaf((float)(__bf16)zs[r * zp + oo[q]], hs[r][cc[q]], sacc);
                 } else {
 #pragma unroll 8
-                    for (int r = 0; r < ROWS; ++r) sacc = fmaf(zs[r][oo[q]], hs[r][cc[q]], sacc);
+                    for (int r = 0; r < ROWS; ++r) sacc = fmaf(zs[r * zp + oo[q]], hs[r][cc[q]], sacc);
                 }
                 acc[q] = sacc;
             }
@@ -524,9 +553,12 @@ struct WpVariant { int tm, tn; };
 const WpVariant kVariants[6] = {{5, 1}, {1, 5}, {4, 1}, {1, 1}, {2, 4}, {2, 2}};
 
 // the variant whose tiles cover [n_out, k_in] with the fewest staged columns per operand row (ties: fewer tiles)
+bool wp_is_small(int n_out, int k_in) {   // wp_block_small's shapes
+    return k_in <= 32 && (n_out <= 32 || (n_out <= 96 && k_in % 4 != 0));
+}
 void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
     if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
-    if (n_out <= 32 && k_in <= 32) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                  // wp_block_small
+    if (wp_is_small(n_out, k_in)) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                   // wp_block_small
     long best = -1;
     for (int v = 0; v < 6; ++v) {
         if (v == 4) continue;   // (<2, 4>: 128 accumulator registers + a stage in flight spill; 128 x 224 takes two <2, 2> tiles)
@@ -561,7 +593,13 @@ void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, b
 
 thread_local WpBatch* g_wp = nullptr;
 
-size_t wp_lds_bytes() { return 3 * WP_KB * wp_pitch(320, 64); }   // the largest variant image (BO + BC = 384)
+size_t wp_lds_bytes() {
+    // the largest variant image (BO + BC = 384): 39 KB.  MPNHIP_WP_LDS=<bytes> asks for more than the kernel uses: above 80 KB
+    // only ONE block of this kernel fits a CU, which leaves the other wave slot of every SIMD to the caller's stream (A-B switch)
+    static const size_t need = 3 * WP_KB * wp_pitch(320, 64);
+    static const size_t ask = [] { const char* e = getenv("MPNHIP_WP_LDS"); const long x = e ? atol(e) : 0; return (size_t)(x > 0 ? x : 0); }();
+    return ask > need ? ask : need;
+}
 
 }  // namespace
 
@@ -570,7 +608,8 @@ bool wp_eligible(const WpProduct& p) {
     if (p.rows <= 0 || p.rows >= (int64_t)1 << 31 || p.nbatch < 1 || !p.dZ || !p.H || p.n_out < 1 || p.k_in < 1) return false;
     if (p.n_out == 1 && p.k_in % 4 == 0 && p.k_in <= 64 && !p.h_idx && !p.H2 && al16(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0)
         return true;   // wp_block_vec: gathered dZ allowed
-    if (p.n_out <= 32 && p.k_in <= 32) return !p.H2 && p.n_out * (p.k_in + 1) <= 5 * WP_NT;   // wp_block_small: any alignment, gathers allowed
+    if (wp_is_small(p.n_out, p.k_in))   // wp_block_small: any alignment, gathers allowed
+        return !p.H2 && p.n_out * (p.k_in + 1) <= 5 * WP_NT;
     return !p.dz_idx && !p.h_idx && p.n_out % 4 == 0 && p.k_in % 4 == 0 &&
            al16(p.dZ) && al16(p.H) && p.ldz % 4 == 0 && p.ldh % 4 == 0 && p.z_bstride % 4 == 0 && p.h_bstride % 4 == 0 &&
            (!p.H2 || (al16(p.H2) && p.ldh2 % 4 == 0 && p.h2_bstride % 4 == 0 && p.csplit % 4 == 0 && p.csplit > 0 && p.csplit < p.k_in));
