@@ -248,6 +248,32 @@ int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out,
 int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision, float* grad_w,
                             float* grad_b, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The gradient of node_agg_fn (models/mpn.py:266-273; torch_scatter's scatter_add / scatter_mean / scatter_max backward), gather
+ * form: grad_src[j] = grad_out[row[j]] (sum), / count[row[j]] (mean; count int32 [x_size]), or only where argmax[row[j]][d] == j
+ * (max; `argmax` as mpnhip_segment_reduce returned it).  grad_out [x_size, dim], grad_src [M, dim]. */
+int mpnhip_segment_reduce_backward(const float* grad_out, const int64_t* row, const int32_t* argmax, const int32_t* count, int64_t m,
+                                   int dim, int x_size, int agg, float* grad_src, void* stream);
+
+/* nn.BatchNorm1d (TRAINING mode: batch statistics) -> nn.ReLU -> nn.Dropout as models/mlp.py:12-23 stacks them behind each
+ * nn.Linear, and their gradients -- the layer-by-layer training path of a model built with use_batchnorm / dropout_p
+ * (mpntrackseg_amd/modular.py; no shipped configuration enables them, configs/tracking_cfg.yaml:150-167; in eval mode BatchNorm
+ * folds into the Linear layers and the fused path runs).  z [M, N] dense = the Linear's output.
+ *   forward : use_bn: mean / biased variance over the M rows (two passes), y = relu(gamma (z - mean) invstd + beta) keep / (1 - p);
+ *             running_mean / running_var (may be NULL) updated like nn.BatchNorm1d (momentum, unbiased variance); save_mean /
+ *             save_invstd [N] receive the batch statistics for the backward.  M == 1 with use_bn is refused like torch does.
+ *             keep(r, c) = hash(seed, r N + c) >= p: the backward regenerates it from the same seed, nothing is stored.
+ *   backward: dz [M, N], dgamma / dbeta [N] (may be NULL; written, not accumulated).
+ * Column sums in a fixed order (no float atomics): bitwise reproducible.  workspace: mpnhip_bn_dropout_workspace_bytes. */
+size_t mpnhip_bn_dropout_workspace_bytes(int64_t m, int n);
+int mpnhip_bn_relu_dropout_forward(const float* z, int64_t m, int n, int use_bn, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, int relu, float dropout_p,
+                                   uint64_t seed, float* y, float* save_mean, float* save_invstd, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int mpnhip_bn_relu_dropout_backward(const float* dy, const float* z, int64_t m, int n, int use_bn, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, int relu, float dropout_p,
+                                    uint64_t seed, float* dz, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* MLP.forward (models/mlp.py:27-28): all layers; scratch [2, M, max(out_dims)] floats. */
 size_t mpnhip_mlp_workspace_bytes(const mpnhip_mlp* mlp, int64_t m);
 int mpnhip_mlp_forward(const mpnhip_mlp* mlp, const float* x, float* y, int64_t m, void* workspace,

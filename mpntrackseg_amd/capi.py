@@ -74,6 +74,11 @@ SIGNATURES = {
     "mpnhip_meta_layer_forward": (_I, [C.POINTER(Model), _P, _I, _L, _P, _P, _P, _P, _P, _Z, _P]),
     "mpnhip_segment_reduce_workspace_bytes": (_Z, [_L, _I]),
     "mpnhip_segment_reduce": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "mpnhip_segment_reduce_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "mpnhip_bn_dropout_workspace_bytes": (_Z, [_L, _I]),
+    "mpnhip_bn_relu_dropout_forward": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, C.c_float, C.c_float, _I, C.c_float, C.c_uint64, _P, _P, _P,
+                                            _P, _Z, _P]),
+    "mpnhip_bn_relu_dropout_backward": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, C.c_float, C.c_uint64, _P, _P, _P, _P, _Z, _P]),
     "mpnhip_linear": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _P]),
     "mpnhip_weight_grad_workspace_bytes": (_Z, [_I, _I, _L, _I]),
     "mpnhip_weight_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),

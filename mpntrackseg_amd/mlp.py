@@ -35,13 +35,12 @@ class MLP(nn.Module):
     def require_fast_path(self):
         """BatchNorm1d / Dropout (mlp.py:14,20; never enabled in the shipped configs, tracking_cfg.yaml:150-167): in eval mode
         Dropout is the identity and BatchNorm is an affine map of the Linear's output that folds into its weight and bias
-        (``effective_linears``), so inference runs on the same kernels.  TRAINING with them -- batch statistics, random masks
-        and their gradients -- is not covered by the HIP path and raises."""
+        (``effective_linears``), so inference runs on the fused kernels.  TRAINING with them -- batch statistics, random masks
+        and their gradients -- runs layer by layer (``modular.py``); the FUSED path refuses such a module in training mode."""
         if not self.fast_path and self.training:
             raise capi.MpnhipError(
-                "training with BatchNorm / Dropout inside the MPN MLPs is not covered by the HIP path: call .eval() (BatchNorm "
-                "then folds into the Linear layers), or build the model with use_batchnorm=False, dropout_p=0 as all shipped "
-                "reference configs do (configs/tracking_cfg.yaml:150-167)")
+                "BatchNorm / Dropout in training mode cannot run in the fused kernels (batch statistics need every row of a layer "
+                "first): MOTMPNet.forward / MLP.forward take the layer-by-layer path (mpntrackseg_amd/modular.py) for it")
 
     def effective_linears(self):
         """[(weight, bias)] of the Linear layers as the kernels see them: eval-mode BatchNorm1d folded in
@@ -76,12 +75,14 @@ class MLP(nn.Module):
         return s
 
     def forward(self, input):
-        """models/mlp.py:27-28.  Inference-only at operator level (the fused MOTMPNet path owns autograd)."""
-        self.require_fast_path()
+        """models/mlp.py:27-28.  Inference: all layers in one native call; with autograd (or BatchNorm / Dropout in training
+        mode): ``modular.mlp_forward``.  (``MOTMPNet.forward`` evaluates its MLPs fused and owns its own backward.)"""
         capi.require_device(input)
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise capi.MpnhipError("operator-level MLP.forward has no autograd; use MOTMPNet.forward for training "
-                                   "or wrap the call in torch.no_grad()")
+        needs_grad = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or (self.training and not self.fast_path):
+            # autograd, and training-mode BatchNorm / Dropout: layer by layer, every layer a HIP op with a hand-written gradient
+            from .modular import mlp_forward
+            return mlp_forward(self, input)
         lib = capi.load()
         x = capi.f32c(input)
         lead = x.shape[:-1]

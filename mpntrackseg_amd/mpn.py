@@ -49,6 +49,13 @@ def check_hot_path_inputs(m, g, x, edge_attr):
         raise capi.MpnhipError("x / edge_attr / edge_index live on different devices")
 
 
+def _wants_modular(module, *inputs):
+    """Operator-level calls: autograd requested, or BatchNorm / Dropout MLPs in training mode -> ``modular.py``."""
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in module.parameters())):
+        return True
+    return any(isinstance(m_, MLP) and m_.training and not m_.fast_path for m_ in module.modules())
+
+
 class NodeAggFn:
     """The reference's ``node_agg_fn`` lambdas (mpn.py:266-273): ``fn(out, row, x_size)``."""
 
@@ -63,7 +70,8 @@ class NodeAggFn:
     def __call__(self, out, row, x_size):
         capi.require_device(out, row)
         if torch.is_grad_enabled() and out.requires_grad:
-            raise capi.MpnhipError("operator-level node_agg_fn has no autograd; use MOTMPNet.forward for training")
+            from .modular import segment_reduce
+            return segment_reduce(out, row, x_size, self.code)
         lib = capi.load()
         src = capi.f32c(out)
         row = row.contiguous().to(torch.int64)
@@ -92,6 +100,9 @@ class EdgeModel(nn.Module):
         ``MetaLayer.forward`` / ``MOTMPNet.forward`` evaluate the same module fused (project-then-gather)."""
         from .graph import gather_rows
         capi.require_device(node_feats, edge_index, edge_attr)
+        if _wants_modular(self, node_feats, edge_attr):
+            from .modular import edge_model_forward
+            return edge_model_forward(self, capi.f32c(node_feats), edge_index.to(torch.int64), edge_attr)
         row, col = edge_index[0].to(torch.int32).contiguous(), edge_index[1].to(torch.int32).contiguous()
         out = torch.cat([gather_rows(node_feats, row), gather_rows(node_feats, col), capi.f32c(edge_attr)], dim=1)
         return self.edge_model(out)
@@ -112,6 +123,9 @@ class TimeAwareNodeModel(nn.Module):
         gathers / MLPs / ``node_agg_fn`` / Linear native calls.  ``MetaLayer.forward`` evaluates the same module fused."""
         from .graph import compact, gather_rows
         capi.require_device(x, edge_index, edge_attr)
+        if _wants_modular(self, x, edge_attr):
+            from .modular import node_model_forward
+            return node_model_forward(self, capi.f32c(x), edge_index.to(torch.int64), edge_attr)
         with torch.cuda.device(x.device):
             return self._forward(x, edge_index, edge_attr, compact, gather_rows)
 
@@ -173,10 +187,10 @@ class MetaLayer(nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         capi.require_device(x, edge_index, edge_attr)
-        if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
-            raise capi.MpnhipError("operator-level MetaLayer.forward has no autograd; use MOTMPNet.forward for "
-                                   "training or wrap the call in torch.no_grad()")
+        if _wants_modular(self, x, edge_attr):
+            # autograd at operator level (and BatchNorm / Dropout in training mode): module by module, mpn.py:47-53
+            edge_attr = self.edge_model(x, edge_index, edge_attr)
+            return self.node_model(x, edge_index, edge_attr), edge_attr
         lib = capi.load()
         keep = []
         m = self.core_struct(keep)
@@ -386,6 +400,10 @@ class MOTMPNet(nn.Module):
             out += [l.weight, l.bias]
         return out
 
+    def _hot_path_mlps(self):
+        return [self.encoder.node_model, self.encoder.edge_model, self.MPNet.edge_model.edge_model,
+                self.MPNet.node_model.flow_in_model, self.MPNet.node_model.flow_out_model, self.classifier.edge_model]
+
     def c_model(self, keep, grads=None, n_edges=None):
         if self.encoder.node_model is None or self.encoder.edge_model is None or self.classifier.edge_model is None:
             raise capi.MpnhipError("MOTMPNet needs node and edge encoders and an edge classifier")
@@ -476,6 +494,14 @@ class MOTMPNet(nn.Module):
         like the reference when edge_index leaves [0, N) (read once per prepared graph, after the launch; callers that build
         the indices themselves -- the sliding-window driver -- skip it)."""
         capi.require_device(x, edge_index, edge_attr)
+        slow = [m_ for m_ in self._hot_path_mlps() if not m_.fast_path]
+        if slow and (any(m_.training for m_ in slow) or (torch.is_grad_enabled() and (
+                x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self._hp_params())))):
+            # BatchNorm / Dropout (mlp.py:14,20) in TRAINING mode -- batch statistics rule the fused kernels out -- or their
+            # gradients in eval mode (BatchNorm as the affine map of its running statistics): layer by layer
+            from . import modular
+            logits = modular.hot_path(self, x, edge_index, edge_attr)
+            return (logits, None, None) if return_state else logits
         if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
                                         any(p.requires_grad for p in self._hp_params())):
             from .autograd import mpn_hot_path_autograd

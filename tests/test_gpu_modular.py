@@ -1,0 +1,286 @@
+"""The layer-by-layer training path (mpntrackseg_amd/modular.py, csrc/bn_dropout.hip): MLPs with nn.BatchNorm1d / nn.Dropout in
+TRAINING mode (models/mlp.py:12-23) and operator-level autograd.
+
+Reference: the SAME modules evaluated by stock torch on the CPU in float64 -- the mirror's ``fc_layers`` are plain
+nn.Linear / nn.BatchNorm1d / nn.ReLU / nn.Dropout, so ``fc_layers(x)`` of a deep copy IS the reference's ``MLP.forward``
+(mlp.py:27-28) -- composed as the reference's forward composes them (mpn.py:59-99,349-392).  Tolerances: logits and
+activations 1e-4 (north_star), gradients 2e-4 relative to the tensor's largest entry (fp32 products against float64)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from mpntrackseg_amd import capi, modular, synth
+from mpntrackseg_amd.mlp import MLP
+from mpntrackseg_amd.mpn import MOTMPNet
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1.0, float(np.abs(b).max()))) if a.size else 0.0
+
+
+def scatter(src, idx, n, agg):
+    """torch_scatter's scatter_add / scatter_mean / scatter_max values (empty segments 0), with autograd."""
+    out = torch.zeros((n, src.shape[1]), dtype=src.dtype)
+    ix = idx.view(-1, 1).expand(-1, src.shape[1])
+    if agg == "sum":
+        return out.scatter_add(0, ix, src)
+    if agg == "mean":
+        cnt = torch.bincount(idx, minlength=n).clamp(min=1).to(src.dtype).view(-1, 1)
+        return out.scatter_add(0, ix, src) / cnt
+    return out.scatter_reduce(0, ix, src, "amax", include_self=False)
+
+
+def ref_forward(m, x, ei, ea, agg):
+    """mpn.py:349-392 (tracking branch) over the stock modules of a CPU float64 copy of the mirror."""
+    row, col = ei
+    e = m.encoder.edge_model.fc_layers(ea)
+    h = m.encoder.node_model.fc_layers(x)
+    e0, h0 = e, h
+    logits = []
+    nm = m.MPNet.node_model
+    for _ in range(int(m.num_enc_steps)):
+        if m.reattach_initial_edges:
+            e = torch.cat((e0, e), dim=1)
+        if m.reattach_initial_nodes:
+            h = torch.cat((h0, h), dim=1)
+        e = m.MPNet.edge_model.edge_model.fc_layers(torch.cat([h[row], h[col], e], dim=1))       # mpn.py:67-69
+        fi, fo = row > col, row < col                                                             # mpn.py:85-96
+        flow_out = scatter(nm.flow_out_model.fc_layers(torch.cat([h[col[fo]], e[fo]], dim=1)), row[fo], h.shape[0], agg)
+        flow_in = scatter(nm.flow_in_model.fc_layers(torch.cat([h[col[fi]], e[fi]], dim=1)), row[fi], h.shape[0], agg)
+        h = nm.node_model(torch.cat((flow_in, flow_out), dim=1))                                  # mpn.py:97-99
+        logits.append(m.classifier.edge_model.fc_layers(e).view(-1))
+    return torch.stack(logits)
+
+
+def bn_model(agg, L=2, d=32, bn=True, p=0.0, seed=5):
+    params = synth.model_params(d, L, agg, node_in_dim=48)
+    for k in ("encoder_feats_dict", "edge_model_feats_dict", "node_model_feats_dict", "classifier_feats_dict"):
+        params[k]["use_batchnorm"] = bn
+        params[k]["dropout_p"] = p
+    torch.manual_seed(seed)
+    model = MOTMPNet(params)
+    for mod in model.modules():   # non-trivial BatchNorm state
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data.uniform_(0.6, 1.4)
+            mod.bias.data.normal_(0, 0.2)
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+    return params, model
+
+
+def graph(N=90, E=700, seed=4):
+    g = synth.make_graph(N, E, seed=seed, node_in_dim=48)
+    return torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"])
+
+
+def test_mlp_batchnorm_training_matches_stock_torch():
+    """One MLP (Linear -> BatchNorm1d -> ReLU, last layer of width 1 bare: mlp.py:12-23) in training mode: output, input
+    gradient, every parameter gradient incl. gamma / beta, and the running statistics nn.BatchNorm1d keeps."""
+    torch.manual_seed(1)
+    mlp = MLP(20, [40, 24, 1], dropout_p=0, use_batchnorm=True)
+    for mod in mlp.fc_layers:
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.3)
+    ref = copy.deepcopy(mlp).double().train()
+    x = torch.from_numpy(synth.normal(3, (777, 20)))
+    xr = x.double().requires_grad_(True)
+    yr = ref.fc_layers(xr)
+    w = torch.from_numpy(synth.normal(4, tuple(yr.shape))).double()
+    (yr * w).sum().backward()
+
+    mlp = mlp.to(dev()).train()
+    xd = x.to(dev()).requires_grad_(True)
+    y = mlp(xd)
+    (y * w.float().to(dev())).sum().backward()
+    assert rel(y, yr) < 1e-4
+    assert rel(xd.grad, xr.grad) < 2e-4
+    for (n1, p1), (_, p2) in zip(mlp.named_parameters(), ref.named_parameters()):
+        assert p1.grad is not None, n1
+        assert rel(p1.grad, p2.grad) < 2e-4, n1
+    for b1, b2 in zip(mlp.buffers(), ref.buffers()):   # running_mean, running_var, num_batches_tracked
+        assert rel(b1, b2) < 1e-5
+    # a single row cannot be normalised: torch raises ValueError there
+    with pytest.raises(ValueError):
+        mlp(x[:1].to(dev()))
+    # bitwise reproducible (fixed-order column sums)
+    mlp2 = copy.deepcopy(mlp)
+    mlp.zero_grad()
+    mlp2.zero_grad()
+    for mm in (mlp, mlp2):
+        xx = x.to(dev()).requires_grad_(True)
+        (mm(xx) * w.float().to(dev())).sum().backward()
+    for p1, p2 in zip(mlp.parameters(), mlp2.parameters()):
+        assert torch.equal(p1.grad, p2.grad)
+
+
+def test_dropout_mask_semantics_and_gradient():
+    """nn.Dropout(p) in training mode: elements are zeroed with probability p and the rest scaled by 1 / (1 - p) (mlp.py:20-21);
+    the gradient uses the SAME mask (regenerated from the seed); the mask follows torch.manual_seed."""
+    n, m, p = 64, 4000, 0.3
+    z = torch.from_numpy(synth.normal(7, (m, n))).to(dev())
+    y = modular._BnReluDropout.apply(z.clone().requires_grad_(True), None, None, None, True, p, 1234)
+    r = torch.relu(z)
+    pos = r > 0
+    kept = (y != 0) & pos
+    frac = float(kept.sum()) / float(pos.sum())
+    assert abs(frac - (1 - p)) < 4 * np.sqrt(p * (1 - p) / float(pos.sum()))
+    assert torch.allclose(y[kept], r[kept] / (1 - p), rtol=1e-6)
+    # per column / per row the mask is not degenerate
+    assert float(kept.float().mean(0).min()) > 0.2 and float(kept.float().mean(1).min()) > 0.05
+    zz = z.clone().requires_grad_(True)
+    yy = modular._BnReluDropout.apply(zz, None, None, None, True, p, 1234)
+    assert torch.equal(yy, y)                       # same seed, same mask
+    dy = torch.from_numpy(synth.normal(8, (m, n))).to(dev())
+    yy.backward(dy)
+    assert torch.allclose(zz.grad, torch.where(kept, dy / (1 - p), torch.zeros_like(dy)), rtol=1e-6)
+    y3 = modular._BnReluDropout.apply(z, None, None, None, True, p, 99)
+    assert not torch.equal(y3, y)                   # another seed, another mask
+
+    mlp = MLP(16, [32, 8], dropout_p=0.4, use_batchnorm=False).to(dev()).train()
+    x = torch.from_numpy(synth.normal(9, (500, 16))).to(dev())
+    torch.manual_seed(11)
+    a = mlp(x)
+    torch.manual_seed(11)
+    b = mlp(x)
+    c = mlp(x)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    mlp.eval()
+    with torch.no_grad():
+        e1, e2 = mlp(x), mlp(x)
+    assert torch.equal(e1, e2)                      # eval: identity, the fused inference path
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_model_with_batchnorm_trains_like_stock_torch(agg):
+    """MOTMPNet built with use_batchnorm=True everywhere, TRAINING mode: per-step logits, every parameter gradient (Linear and
+    BatchNorm) and the BatchNorm running statistics against the float64 stock-torch evaluation of the same modules."""
+    params, model = bn_model(agg)
+    ref = copy.deepcopy(model).double().train()
+    x, ei, ea = graph()
+    lr = ref_forward(ref, x.double(), ei, ea.double(), agg)
+    w = torch.from_numpy(synth.normal(12, tuple(lr.shape))).double()
+    (lr * w).sum().backward()
+
+    model = model.to(dev()).train()
+    lg = model.hot_path(x.to(dev()), ei.to(dev()), ea.to(dev()))
+    assert lg.requires_grad and tuple(lg.shape) == tuple(lr.shape)
+    (lg * w.float().to(dev())).sum().backward()
+    assert rel(lg, lr) < 1e-4
+    bad = []
+    for (n1, p1), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        if p2.grad is None:
+            continue
+        assert p1.grad is not None, n1
+        if rel(p1.grad, p2.grad) >= 2e-4:
+            bad.append((n1, rel(p1.grad, p2.grad)))
+    assert not bad, bad
+    for (n1, b1), (_, b2) in zip(model.named_buffers(), ref.named_buffers()):
+        assert rel(b1, b2) < 1e-5, n1
+    # forward() (the reference's dict of per-step outputs) goes the same way
+    class D:
+        pass
+    d = D()
+    d.x, d.edge_index, d.edge_attr = x.to(dev()), ei.to(dev()), ea.to(dev())
+    out = model(d)
+    assert len(out["classified_edges"]) == int(model.num_class_steps) and out["classified_edges"][0].shape == (ei.shape[1], 1)
+
+
+def test_model_with_dropout_trains_and_follows_the_seed():
+    params, model = bn_model("sum", bn=False, p=0.25)
+    model = model.to(dev()).train()
+    x, ei, ea = (t.to(dev()) for t in graph())
+    torch.manual_seed(3)
+    a = model.hot_path(x, ei, ea)
+    a.sum().backward()
+    ga = [p.grad.clone() for p in model.hot_path_parameters()]
+    assert all(bool(torch.isfinite(g).all()) for g in ga) and any(float(g.abs().max()) > 0 for g in ga)
+    model.zero_grad()
+    torch.manual_seed(3)
+    b = model.hot_path(x, ei, ea)
+    b.sum().backward()
+    assert torch.equal(a, b)
+    for g1, p in zip(ga, model.hot_path_parameters()):
+        assert torch.equal(g1, p.grad)
+    c = model.hot_path(x, ei, ea)
+    assert not torch.equal(a, c)
+    # eval mode: Dropout is the identity -- the fused path, equal to a model built without Dropout
+    params0 = copy.deepcopy(params)
+    for k in ("encoder_feats_dict", "edge_model_feats_dict", "node_model_feats_dict", "classifier_feats_dict"):
+        params0[k]["dropout_p"] = 0
+    plain = MOTMPNet(params0)
+    sd = model.state_dict()
+    remap = {}
+    for k, v in sd.items():   # Sequential indices shift without the Dropout modules: Linear, ReLU, Dropout -> Linear, ReLU
+        if ".fc_layers." in k:
+            head, tail = k.split(".fc_layers.")
+            idx, rest = tail.split(".")
+            remap["%s.fc_layers.%d.%s" % (head, int(idx) // 3 * 2, rest)] = v
+        else:
+            remap[k] = v
+    plain.load_state_dict(remap)
+    plain = plain.to(dev()).eval()
+    model.eval()
+    with torch.no_grad():
+        assert rel(model.hot_path(x, ei, ea), plain.hot_path(x, ei, ea)) < 1e-6
+
+
+def test_eval_mode_batchnorm_gradients():
+    """eval(): BatchNorm is the affine map of its running statistics; with gradients enabled the layer-by-layer path gives the
+    gradients stock torch gives in eval mode."""
+    params, model = bn_model("mean")
+    ref = copy.deepcopy(model).double().eval()
+    x, ei, ea = graph()
+    lr = ref_forward(ref, x.double(), ei, ea.double(), "mean")
+    lr.sum().backward()
+    model = model.to(dev()).eval()
+    lg = model.hot_path(x.to(dev()), ei.to(dev()), ea.to(dev()))
+    lg.sum().backward()
+    assert rel(lg, lr) < 1e-4
+    for (n1, p1), (_, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        if p2.grad is not None:
+            assert rel(p1.grad, p2.grad) < 2e-4, n1
+    with torch.no_grad():   # and without gradients: the fused path on folded weights
+        assert rel(model.hot_path(x.to(dev()), ei.to(dev()), ea.to(dev())), lr) < 1e-4
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_operator_level_autograd(agg):
+    """MLP.forward, node_agg_fn, MetaLayer.forward with gradients enabled at operator level (plain MLPs): values and gradients
+    against stock torch (the reference's modules have autograd everywhere; the fused MOTMPNet path owns its own backward)."""
+    params, model = bn_model(agg, bn=False, p=0.0)
+    ref = copy.deepcopy(model).double()
+    model = model.to(dev())
+    N, E = 60, 400
+    g = synth.make_graph(N, E, seed=9, node_in_dim=48)
+    ei = torch.from_numpy(g["edge_index"])
+    h = torch.from_numpy(synth.normal(21, (N, 64)))      # [x0 | x] at d = 32
+    e = torch.from_numpy(synth.normal(22, (E, 32)))      # [e0 | e]
+    hr, er = h.double().requires_grad_(True), e.double().requires_grad_(True)
+    row, col = ei
+    nm = ref.MPNet.node_model
+    e1 = ref.MPNet.edge_model.edge_model.fc_layers(torch.cat([hr[row], hr[col], er], dim=1))
+    fi, fo = row > col, row < col
+    f_out = scatter(nm.flow_out_model.fc_layers(torch.cat([hr[col[fo]], e1[fo]], dim=1)), row[fo], N, agg)
+    f_in = scatter(nm.flow_in_model.fc_layers(torch.cat([hr[col[fi]], e1[fi]], dim=1)), row[fi], N, agg)
+    h1 = nm.node_model(torch.cat((f_in, f_out), dim=1))
+    (h1.sum() + 0.5 * e1.sum()).backward()
+
+    hd, ed = h.to(dev()).requires_grad_(True), e.to(dev()).requires_grad_(True)
+    h2, e2 = model.MPNet(hd, ei.to(dev()), ed)
+    (h2.sum() + 0.5 * e2.sum()).backward()
+    assert rel(h2, h1) < 1e-4 and rel(e2, e1) < 1e-4
+    assert rel(hd.grad, hr.grad) < 2e-4 and rel(ed.grad, er.grad) < 2e-4
+    for (n1, p1), (_, p2) in zip(model.MPNet.named_parameters(), ref.MPNet.named_parameters()):
+        assert rel(p1.grad, p2.grad) < 2e-4, n1

@@ -755,7 +755,7 @@ def test_two_streams_do_not_share_scratch():
 
 def test_mlp_batchnorm_and_dropout_eval_mode():
     """MLP with use_batchnorm / dropout (models/mlp.py:14,20): eval mode folds BatchNorm1d into the Linear layers and drops the
-    Dropout -- checked against stock torch modules with the same state; training with them raises."""
+    Dropout -- checked against stock torch modules with the same state."""
     torch.manual_seed(3)
     mlp = MLP(12, [24, 16, 1], dropout_p=0.3, use_batchnorm=True)
     for m in mlp.fc_layers:
@@ -770,10 +770,7 @@ def test_mlp_batchnorm_and_dropout_eval_mode():
         ref = torch.nn.Sequential.forward(mlp.fc_layers, x.clone())     # stock torch evaluation of the same Sequential
         got = mlp.to(dev())(x.to(dev()))
     assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
-    mlp.train()
-    with pytest.raises(capi.MpnhipError):
-        with torch.no_grad():
-            mlp(x.to(dev()))
+    # (training mode -- batch statistics, random masks -- takes the layer-by-layer path: tests/test_gpu_modular.py)
     # the same inside the full model: a MOTMPNet built with batch-norm MLPs runs its hot path in eval mode
     params = synth.model_params(32, 2, "sum", node_in_dim=64)
     for k in ("edge_model_feats_dict", "node_model_feats_dict"):
@@ -807,13 +804,14 @@ def test_mlp_batchnorm_and_dropout_eval_mode():
                                                         torch.from_numpy(g["edge_attr"]), return_state=True)[1]]).numpy()
     assert rel_err(lg.cpu().numpy(), ref) < 1e-4
     # the same call with gradients enabled (parameters require grad: the autograd route, through torch.ops.mpnhip when the shim is
-    # built): the BatchNorm fold must not be lost there -- identical logits -- and the backward refuses (training with BatchNorm)
+    # built): eval-mode BatchNorm with gradients runs layer by layer (modular.py) -- the same logits within fp32 rounding, and a
+    # backward that reaches every parameter
     lg2 = model.hot_path(torch.from_numpy(g["x"]).to(dev()), torch.from_numpy(g["edge_index"]).to(dev()),
                          torch.from_numpy(g["edge_attr"]).to(dev()))
     assert lg2.requires_grad
-    assert float((lg2.detach() - lg).abs().max()) <= 1e-6 * max(1.0, float(lg.abs().max()))
-    with pytest.raises(capi.MpnhipError):
-        lg2.sum().backward()
+    assert float((lg2.detach() - lg).abs().max()) <= 2e-5 * max(1.0, float(lg.abs().max()))
+    lg2.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.hot_path_parameters())
 
 
 @pytest.mark.parametrize("agg", ["sum", "mean", "max"])
