@@ -158,8 +158,10 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    // stages in flight under the current one's products: ONE for the wide variants (a stage is 20 - 24 registers there), two or
-    // four for the narrow ones (a <1, 1> stage is 16 rows x 128 columns = 8 KB per block: with one in flight the kernel waits out
+    // stages in flight under the current one's products: ONE for the wide variants (a stage is 20 - 24 registers there; two fit
+    // without spills since the loops exist once per operand form, and measure the same: 118.7 / 113.2 us against 114.2 / 110.3 on
+    // the edge-level products, the step unchanged -- the kernel is not bound by its bytes in flight),
+    // two or four for the narrow ones (a <1, 1> stage is 16 rows x 128 columns = 8 KB per block: with one in flight the kernel waits out
     // the HBM latency every 16 rows -- 1.4 TB/s on the 32-d products of the reference's configuration)
     constexpr int D = TM + TN <= 2 ? 4 : (TM + TN <= 5 && TM * TN <= 4 ? 2 : 1);
     f32x4 zreg[D][PZ], hreg[D][PH];
@@ -228,9 +230,8 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
         }
     };
-    auto products = [&]() {
-        if (one) { products1(); return; }
-        if (TM >= TN) {
+    auto products6 = [&]() {
+        if constexpr (TM >= TN) {
             bf16x8 b[TN][3];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -269,53 +270,59 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     using B0 = std::integral_constant<int, 0>;
     const int nfull = (r1 - r0) / WP_KB;          // full stages
     const int tail = (r1 - r0) - nfull * WP_KB;   // rows of the partial last stage (0: none)
-    if (nfull > 0) {
-        wp_static_for<0, D>([&](auto d) {
-            if (d.value < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + d.value * WP_KB);
-        });
-        int st = 0;
-        // steady state (every stage of the round has a successor D stages on: straight-line code, the loads' waits are counted)
-        for (; st + 2 * D <= nfull; st += D) {
+    // (one copy of the loops per operand form: a branch on `one` inside them makes every accumulator a phi of two versions --
+    // register copies and spills)
+    auto run = [&](auto&& products) {
+        if (nfull > 0) {
             wp_static_for<0, D>([&](auto d) {
-                store(d, WP_KB);
-                __syncthreads();
-                WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
-                products();
-                __syncthreads();
+                if (d.value < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + d.value * WP_KB);
             });
-        }
-        for (; st < nfull; st += D) {
-            wp_static_for<0, D>([&](auto d) {
-                if (st + d.value < nfull) {   // (block-uniform)
+            int st = 0;
+            // steady state (every stage of the round has a successor D stages on: straight-line code, the loads' waits are counted)
+            for (; st + 2 * D <= nfull; st += D) {
+                wp_static_for<0, D>([&](auto d) {
                     store(d, WP_KB);
                     __syncthreads();
-                    if (st + d.value + D < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
+                    WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
                     products();
                     __syncthreads();
-                }
-            });
+                });
+            }
+            for (; st < nfull; st += D) {
+                wp_static_for<0, D>([&](auto d) {
+                    if (st + d.value < nfull) {   // (block-uniform)
+                        store(d, WP_KB);
+                        __syncthreads();
+                        if (st + d.value + D < nfull) WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
+                        products();
+                        __syncthreads();
+                    }
+                });
+            }
         }
-    }
-    if (tail > 0) {
-        // the partial stage: rows clamped to the chunk's last row, zeros stored past it
-        const int m0 = r0 + nfull * WP_KB;
-#pragma unroll
-        for (int j = 0; j < PZ; ++j) {
-            int r = zrow + rpz * j;
-            r = (zact && r < tail) ? r : tail - 1;
-            zreg[0][j] = *reinterpret_cast<const f32x4*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * 4);
+        if (tail > 0) {
+            // the partial stage: rows clamped to the chunk's last row, zeros stored past it
+            const int m0 = r0 + nfull * WP_KB;
+    #pragma unroll
+            for (int j = 0; j < PZ; ++j) {
+                int r = zrow + rpz * j;
+                r = (zact && r < tail) ? r : tail - 1;
+                zreg[0][j] = *reinterpret_cast<const f32x4*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * 4);
+            }
+    #pragma unroll
+            for (int j = 0; j < PH; ++j) {
+                int r = hrow + rph * j;
+                r = (hact && r < tail) ? r : tail - 1;
+                hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * 4);
+            }
+            store(B0{}, tail);
+            __syncthreads();
+            products();
+            __syncthreads();
         }
-#pragma unroll
-        for (int j = 0; j < PH; ++j) {
-            int r = hrow + rph * j;
-            r = (hact && r < tail) ? r : tail - 1;
-            hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * 4);
-        }
-        store(B0{}, tail);
-        __syncthreads();
-        products();
-        __syncthreads();
-    }
+    };
+    if (one) run(products1);
+    else run(products6);
 
     // ---- the partial output tile into this chunk's slab (odd chunks negated as a whole: the slab sum subtracts them) ----
     const int kpad = tn_kpad(J.k_in);

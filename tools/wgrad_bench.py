@@ -19,11 +19,12 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma-separated indices into the shape list")
     ap.add_argument("--split", action="store_true", help="MPNHIP_PREC_FP32_SPLIT: three-piece bf16 operands (wgrad_panel.hip)")
+    ap.add_argument("--bf16", action="store_true", help="MPNHIP_PREC_BF16: operands rounded to bf16, one product per k block")
     a = ap.parse_args()
     lib = capi.load()
     dev = torch.device("cuda:0")
     tot = 0.0
-    prec = capi.PRECISIONS["fp32_split"] if a.split else capi.PRECISIONS["fp32"]
+    prec = capi.PRECISIONS["bf16"] if a.bf16 else (capi.PRECISIONS["fp32_split"] if a.split else capi.PRECISIONS["fp32"])
     shapes = [CFG_B[int(i)] for i in a.only.split(",")] if a.only else CFG_B
     for rows, n_out, k_in, what in shapes:
         nb = 1 if "nbatch 1" in what else a.nbatch
