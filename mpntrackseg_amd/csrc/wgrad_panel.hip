@@ -171,7 +171,7 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     // outstanding load before the first use of a stage -- and were 3 % faster on the long products (110.5 vs 113.9 us), but the
     // registers of an asm load are, to the compiler, ready when the statement ends: wherever its allocation put a copy or reused
     // one of them before the hand-placed wait, the late-landing load overwrote live values -- memory faults on short chunks of
-    // the <2, 4> variant.  Not worth 3 %; and two compiler-visible buffers spill in that variant.)
+    // a since-removed <2, 4> variant.  Not worth 3 %.)
 #define WP_LOAD(ZR, HR, m0)                                                                                              \
     do {                                                                                                                 \
         const char* zb_ = zbase + (int64_t)(m0) * ldz * 4;                                                               \
