@@ -46,7 +46,10 @@ def run_case(params, W, g, precision, seed=11, logit_tol=None):
     frac = d.mismatches / max(d.units, 1)
     print("decisions: %d of %d units differ (%.2e), worst margin |z|/rms %.2e, sites %s"
           % (d.mismatches, d.units, frac, d.worst_margin, dict(sorted(d.per_site.items(), key=lambda kv: -kv[1])[:4])))
-    assert frac <= MISMATCH_FRACTION, "too many decisions differ from the float64 oracle: %.3g" % frac
+    # (a fraction of the units, but never fewer than ONE: a single knife-edge unit is 2e-6 of a 490k-unit case -- found by
+    # tools/diag/fuzz_parity.py seed 31 -- and must still pass the margin test below)
+    assert d.mismatches <= max(1, int(np.ceil(MISMATCH_FRACTION * d.units))), \
+        "too many decisions differ from the float64 oracle: %d of %d (%.3g)" % (d.mismatches, d.units, frac)
     assert d.worst_margin <= MARGIN, "a decision differs on a unit that is NOT at the boundary: |z|/rms = %.3g" % d.worst_margin
     # forward: relative to the step's largest logit for sum, absolute for mean / max
     for s in range(L):
