@@ -87,7 +87,7 @@ def main():
             if tiny:
                 tp.TOLS = {k: (10 * v[0], 10 * v[1]) for k, v in saved.items()}
             try:
-                for prec in ("fp32", "fp32_split"):
+                for prec in ("fp32", "fp32_split", "fp32_wgsplit"):
                     tp.run_case(params, W, g, prec, seed=seed)
             finally:
                 tp.TOLS = saved
