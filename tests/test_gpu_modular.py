@@ -29,38 +29,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, float(np.abs(b).max()))) if a.size else 0.0
 
 
-def scatter(src, idx, n, agg):
-    """torch_scatter's scatter_add / scatter_mean / scatter_max values (empty segments 0), with autograd."""
-    out = torch.zeros((n, src.shape[1]), dtype=src.dtype)
-    ix = idx.view(-1, 1).expand(-1, src.shape[1])
-    if agg == "sum":
-        return out.scatter_add(0, ix, src)
-    if agg == "mean":
-        cnt = torch.bincount(idx, minlength=n).clamp(min=1).to(src.dtype).view(-1, 1)
-        return out.scatter_add(0, ix, src) / cnt
-    return out.scatter_reduce(0, ix, src, "amax", include_self=False)
-
-
-def ref_forward(m, x, ei, ea, agg):
-    """mpn.py:349-392 (tracking branch) over the stock modules of a CPU float64 copy of the mirror."""
-    row, col = ei
-    e = m.encoder.edge_model.fc_layers(ea)
-    h = m.encoder.node_model.fc_layers(x)
-    e0, h0 = e, h
-    logits = []
-    nm = m.MPNet.node_model
-    for _ in range(int(m.num_enc_steps)):
-        if m.reattach_initial_edges:
-            e = torch.cat((e0, e), dim=1)
-        if m.reattach_initial_nodes:
-            h = torch.cat((h0, h), dim=1)
-        e = m.MPNet.edge_model.edge_model.fc_layers(torch.cat([h[row], h[col], e], dim=1))       # mpn.py:67-69
-        fi, fo = row > col, row < col                                                             # mpn.py:85-96
-        flow_out = scatter(nm.flow_out_model.fc_layers(torch.cat([h[col[fo]], e[fo]], dim=1)), row[fo], h.shape[0], agg)
-        flow_in = scatter(nm.flow_in_model.fc_layers(torch.cat([h[col[fi]], e[fi]], dim=1)), row[fi], h.shape[0], agg)
-        h = nm.node_model(torch.cat((flow_in, flow_out), dim=1))                                  # mpn.py:97-99
-        logits.append(m.classifier.edge_model.fc_layers(e).view(-1))
-    return torch.stack(logits)
+from modular_ref import ref_forward, scatter  # noqa: E402
 
 
 def bn_model(agg, L=2, d=32, bn=True, p=0.0, seed=5):
@@ -195,6 +164,42 @@ def test_model_with_batchnorm_trains_like_stock_torch(agg):
     d.x, d.edge_index, d.edge_attr = x.to(dev()), ei.to(dev()), ea.to(dev())
     out = model(d)
     assert len(out["classified_edges"]) == int(model.num_class_steps) and out["classified_edges"][0].shape == (ei.shape[1], 1)
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_batchnorm_training_matches_the_reference_fixture(agg):
+    """g15 (tools/make_golden.py gen_g15): the REFERENCE's MOTMPNet with use_batchnorm=True everywhere, train() mode, float64 -- its
+    per-step logits, its autograd (Linear and BatchNorm parameters, x, edge_attr) and the running statistics after the forward."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_batchnorm_train.npz"))
+    N, E, L, nin = 90, 700, 2, 48
+    params = synth.model_params(32, L, agg, node_in_dim=nin)
+    for k in ("encoder_feats_dict", "edge_model_feats_dict", "node_model_feats_dict", "classifier_feats_dict"):
+        params[k] = dict(params[k], use_batchnorm=True, dropout_p=0)
+    g = synth.make_graph(N, E, seed=4, node_in_dim=nin)
+    model = MOTMPNet(params)
+    state = {k[len(agg) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(agg + ":state:")}
+    model.load_state_dict(state, strict=True)       # same keys as the reference's hot path, BatchNorm buffers included
+    model = model.to(dev()).train()
+    x = torch.from_numpy(g["x"]).to(dev()).requires_grad_(True)
+    ea = torch.from_numpy(g["edge_attr"]).to(dev()).requires_grad_(True)
+    lg = model.hot_path(x, torch.from_numpy(g["edge_index"]).to(dev()), ea)
+    r = torch.from_numpy(synth.normal(12, (L, E))).to(dev())
+    (lg * r).sum().backward()
+    assert float(np.abs(lg.detach().cpu().numpy() - z[agg + ":logits"]).max()) < 1e-4      # north_star: 1e-4 on the logits
+    assert rel(x.grad, z[agg + ":grad_x"]) < 2e-4 and rel(ea.grad, z[agg + ":grad_edge_attr"]) < 2e-4
+    named = dict(model.named_parameters())
+    checked = 0
+    for k in z.files:
+        if k.startswith(agg + ":grad:"):
+            name = k[len(agg) + 6:]
+            assert rel(named[name].grad, z[k]) < 2e-4, name
+            checked += 1
+    assert checked == len(named)
+    bufs = dict(model.named_buffers())
+    for k in z.files:
+        if k.startswith(agg + ":after:"):
+            assert rel(bufs[k[len(agg) + 7:]], z[k]) < 1e-5, k
 
 
 def test_model_with_dropout_trains_and_follows_the_seed():

@@ -300,3 +300,39 @@ def test_g14_construct_graph_oracle_against_reference_motgraph(golden, tag):
     assert np.allclose(got["edge_attr"].numpy(), z[f"{tag}:edge_attr"], rtol=1e-6, atol=1e-7)
     if inference:
         assert np.allclose(got["reid_emb_dists"].numpy(), z[f"{tag}:reid_emb_dists"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max"])
+def test_g15_stock_torch_replica_against_reference_batchnorm_training(golden, agg):
+    """tests/modular_ref.py (the float64 stock-torch composition tests/test_gpu_modular.py checks the HIP layer-by-layer path against)
+    reproduces the REFERENCE's own training-mode forward, autograd and BatchNorm running statistics (g15, tools/make_golden.py
+    gen_g15): the mirror's modules ARE the reference's (same Sequential, same keys), composed the same way."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from modular_ref import ref_forward
+    from mpntrackseg_amd.mpn import MOTMPNet
+    z = golden("g15_batchnorm_train.npz")
+    N, E, L, nin = 90, 700, 2, 48
+    params = synth.model_params(32, L, agg, node_in_dim=nin)
+    for k in ("encoder_feats_dict", "edge_model_feats_dict", "node_model_feats_dict", "classifier_feats_dict"):
+        params[k] = dict(params[k], use_batchnorm=True, dropout_p=0)
+    g = synth.make_graph(N, E, seed=4, node_in_dim=nin)
+    model = MOTMPNet(params)
+    model.load_state_dict({k[len(agg) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(agg + ":state:")}, strict=True)
+    model = model.double().train()
+    x = torch.from_numpy(g["x"]).double().requires_grad_(True)
+    ea = torch.from_numpy(g["edge_attr"]).double().requires_grad_(True)
+    lg = ref_forward(model, x, torch.from_numpy(g["edge_index"]), ea, agg)
+    (lg * torch.from_numpy(synth.normal(12, (L, E))).double()).sum().backward()
+    assert np.abs(lg.detach().numpy() - z[agg + ":logits"]).max() < 1e-9
+    assert np.abs(x.grad.numpy() - z[agg + ":grad_x"]).max() < 1e-9 * max(1.0, np.abs(z[agg + ":grad_x"]).max())
+    named = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith(agg + ":grad:"):
+            ref = z[k]
+            assert np.abs(named[k[len(agg) + 6:]].grad.numpy() - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    bufs = dict(model.named_buffers())
+    for k in z.files:
+        if k.startswith(agg + ":after:"):
+            assert np.abs(bufs[k[len(agg) + 7:]].double().numpy() - z[k]).max() < 1e-9, k

@@ -27,6 +27,8 @@ Fixtures:
   g7_graph_utils.npz           the reference's utils/graph.py on a synthetic detection table (synth.make_detections):
                                get_time_valid_conn_ixs ('max' and 3 frames), compute_edge_feats_dict, F.pairwise_distance,
                                get_knn_mask (reciprocal on/off; one direction per pair and both directions).
+  g15_batchnorm_train.npz      MLPs with BatchNorm1d in TRAINING mode: the reference's forward, autograd (incl. BatchNorm weights) and
+                               running statistics in float64 (three aggregations).
   g6_mask_branch.npz           full forward WITH the attention / mask branch (deterministic weights for all 54
                                tensors): mask predictions + reference-autograd gradients through both branches.
 
@@ -402,6 +404,51 @@ def _ref_fwd_bwd(mpn, params, W, g, r):
     grads = torch.autograd.grad(loss, [xp, ea] + list(hot.values()))
     lg = np.stack([t.detach().numpy().reshape(-1) for t in logits])
     return lg, xL.detach(), eL.detach(), list(hot.keys()), grads
+
+
+def gen_g15(mpn):
+    """MLPs with BatchNorm1d in TRAINING mode (models/mlp.py:14; `use_batchnorm: True` in every feats dict, dropout 0): the
+    reference's own forward (batch statistics), its autograd incl. the BatchNorm weights / biases, and the running statistics it
+    leaves behind, in float64 -- the fixture of the layer-by-layer path (mpntrackseg_amd/modular.py, tests/test_gpu_modular.py)."""
+    rec = {}
+    for agg in ("sum", "mean", "max"):
+        N, E, L, nin = 90, 700, 2, 48
+        params = synth.model_params(32, L, agg, node_in_dim=nin)
+        for k in ("encoder_feats_dict", "edge_model_feats_dict", "node_model_feats_dict", "classifier_feats_dict"):
+            params[k] = dict(params[k], use_batchnorm=True, dropout_p=0)
+        g = synth.make_graph(N, E, seed=4, node_in_dim=nin)
+        full = dict(params)
+        full.update(MASK_PARAMS)
+        torch.manual_seed(5)
+        model = mpn.MOTMPNet(full)
+        hot = ("encoder.", "MPNet.", "classifier.")
+        for name, mod in model.named_modules():      # non-trivial BatchNorm state (float32-representable)
+            if isinstance(mod, torch.nn.BatchNorm1d) and name.startswith(hot):
+                mod.weight.data.uniform_(0.6, 1.4)
+                mod.bias.data.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+        state = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(hot)}
+        model = model.double().train()
+        xp = torch.from_numpy(g["x"]).double().requires_grad_(True)
+        ea = torch.from_numpy(g["edge_attr"]).double().requires_grad_(True)
+        logits, _, _ = ref_hot_path(model, xp, torch.from_numpy(g["edge_index"]), ea)
+        r = synth.normal(12, (L, E))
+        loss = sum((logits[s].view(-1) * torch.from_numpy(r[s]).double()).sum() for s in range(L))
+        named = [(k, p) for k, p in model.named_parameters() if k.startswith(hot)]
+        grads = torch.autograd.grad(loss, [xp, ea] + [p for _, p in named])
+        rec["%s:logits" % agg] = np.stack([t.detach().numpy().reshape(-1) for t in logits])
+        rec["%s:grad_x" % agg] = grads[0].numpy()
+        rec["%s:grad_edge_attr" % agg] = grads[1].numpy()
+        for (k, _), gr in zip(named, grads[2:]):
+            rec["%s:grad:%s" % (agg, k)] = gr.numpy()
+        for k, v in state.items():
+            rec["%s:state:%s" % (agg, k)] = v.numpy()
+        for k, v in model.state_dict().items():       # buffers AFTER the training-mode forward
+            if k.startswith(hot) and ("running_" in k or "num_batches" in k):
+                rec["%s:after:%s" % (agg, k)] = v.detach().numpy()
+        print("g15", agg, "max|logit|", float(np.abs(rec["%s:logits" % agg]).max()))
+    np.savez_compressed(os.path.join(GOLD, "g15_batchnorm_train.npz"), **rec)
 
 
 def gen_g11(mpn):
@@ -782,6 +829,7 @@ def main():
     if "g12" in only: gen_g12(mpn)
     if "g13" in only: gen_g13(mpn)
     if "g14" in only: gen_g14()
+    if "g15" in only: gen_g15(mpn)
 
 
 if __name__ == "__main__":
