@@ -17,7 +17,9 @@
 // independent of the hidden widths: X (first-layer input, bf16) + output accumulators + one tile.
 //
 // A block is 8 waves = 256 edges of one direction group (2 waves per SIMD): twice the edges per weight byte of the fp32
-// kernel, because at these widths the weight stream (0.7 MB per block, L2 -> LDS by LDS-DMA) is what a block moves most of.
+// kernel, because at these widths the weight stream (0.7 MB per block, L2 -> LDS by LDS-DMA) is what a block moves most of
+// -- or, at 256-d since round 3, 4 waves = 128 edges with ONE hidden tile per chunk (51 KB of LDS: two independent blocks per CU,
+// whose serial phases -- first-layer input rows at the start, aggregation at the end -- run under each other's MFMA phases).
 // Weight images ("pair" images, pack_pair_bf16): one SECTION per hidden tile t = [first-layer units of tile t (all k blocks)
 // | second-layer units of the two k blocks the tile feeds (x all output tiles)], units of 1 KiB = one MFMA A operand
 // (64 lanes x 8 bf16; element i of lane (m, g) = W[n0 + m][k0 + (i & 3) + 8 (i >> 2) + 4 g], the accumulator layout's
@@ -93,13 +95,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // NU KiB of an image -> LDS by LDS-DMA: unit 8 q + wave is moved by wave `wave` (one 1 KiB wave instruction each)
-template <int NU>
+template <int NU, int NW = 8>
 __device__ __forceinline__ void chunk_fetch(const char* src, char* buf, int wave, int lane) {
 #pragma unroll
-    for (int q = 0; q < (NU + 7) / 8; ++q) {
-        if (8 * q + wave < NU)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(8 * q + wave) * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(buf + (8 * q + wave) * 1024), 16, 0, 0);
+    for (int q = 0; q < (NU + NW - 1) / NW; ++q) {
+        if (NW * q + wave < NU)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(NW * q + wave) * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(buf + (NW * q + wave) * 1024), 16, 0, 0);
     }
 }
 
@@ -148,20 +150,24 @@ __device__ __forceinline__ void hidden_tile(unsigned wa, const bf16x8* xin, f32x
 
 // T1 = ceil(he/32), T2 = ceil(de/32), TF = ceil(hn/32), TD = ceil(dn/32), TC = ceil(hc/32); EF = 1: first-layer input e,
 // 2: [e0 | e] (each half padded to 32 T2 columns in the image).
-template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT>
-__global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Args A) {
+// NW waves per block (8: 256 edges, one block per CU; 4: 128 edges, two independent blocks per CU whose serial phases -- the
+// first-layer input rows at the start, the aggregation at the end -- run under each other's MFMA phases, for twice the weight
+// stream), CTI hidden tiles per weight chunk.
+template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kernel(EdgeChainBf16Args A) {
+    constexpr int EPB = 32 * NW;           // edges per block
     constexpr int DE = 32 * T2, DN = 32 * TD, HC = 32 * TC;
     constexpr int KBE = 2 * T2;            // k blocks of e'
     constexpr int KB1 = KBE * EF;          // k blocks of the first-layer input
     constexpr int SEC1 = KB1 + 2 * T2;     // units (KiB) per H1 tile section
     constexpr int SECF = KBE + 2 * TD;     // per HF tile section
     constexpr int SECC = KBE;              // per HC tile section (classifier layer 0 only; its layer 1 is a dot product)
-    constexpr int CT = 2;                  // hidden tiles per chunk
+    constexpr int CT = CTI;                // hidden tiles per chunk
     constexpr int NCH1 = (T1 + CT - 1) / CT, NCHF = (TF + CT - 1) / CT;
     constexpr int CHU = bmax(bmax(CT * SEC1, CT * SECF), TC * SECC);   // KiB per chunk buffer
     // one LDS object: two chunk buffers, then the biases [b2 (DE) | bc1 (HC) | wc2 (HC) | bf2 (DN)], zero-padded
     // (the fused aggregation's per-wave slabs reuse the chunk buffers after the last chunk: 8 x [32 edges][32 RT + 1] floats)
-    constexpr int AGG_RT = TD >= 2 ? 2 : 1, AGG_BYTES = 8 * (32 * AGG_RT) * 36 * 4;
+    constexpr int AGG_RT = TD >= 2 ? 2 : 1, AGG_BYTES = NW * (32 * AGG_RT) * 36 * 4;
     constexpr int WB_BYTES = bmax(2 * CHU * 1024, (AGG_BYTES + 15) / 16 * 16);
     __shared__ __attribute__((aligned(16))) char smem[WB_BYTES + (DE + 2 * HC + DN) * 4];
     float* const sbias = reinterpret_cast<float*>(smem + WB_BYTES);
@@ -176,12 +182,12 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
     const int e_out = A.header[1], e_in = A.header[2];
     int grp, beg, end, blk = blockIdx.x;
     {
-        const int nb0 = (e_out + 255) >> 8, nb1 = (e_in + 255) >> 8;
+        const int nb0 = (e_out + EPB - 1) / EPB, nb1 = (e_in + EPB - 1) / EPB;
         if (blk < nb0) { grp = 0; beg = 0; end = e_out; }
         else if (blk < nb0 + nb1) { grp = 1; blk -= nb0; beg = e_out; end = e_out + e_in; }
         else { grp = 2; blk -= nb0 + nb1; beg = e_out + e_in; end = A.E; }
     }
-    const int tile0 = beg + blk * 256;
+    const int tile0 = beg + blk * EPB;
     if (tile0 >= end) return;
     const int edge_raw = tile0 + wave * 32 + lj;
     const bool edge_ok = edge_raw < end;
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
     const char* const img1 = static_cast<const char*>(A.img_edge);
     const char* const imgf = static_cast<const char*>(grp == 1 ? A.img_flow[1] : A.img_flow[0]);
 
-    chunk_fetch<bmin(CT, T1) * SEC1>(img1, WBUF(0), wave, lane);
+    chunk_fetch<bmin(CT, T1) * SEC1, NW>(img1, WBUF(0), wave, lane);
     {
         const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
-        for (int i = tid; i < DE + 2 * HC + DN; i += 512) {
+        for (int i = tid; i < DE + 2 * HC + DN; i += 64 * NW) {
             float v = 0.f;
             if (i < DE) v = i < de ? A.b2[i] : 0.f;
             else if (i < DE + HC) v = i - DE < hc ? A.bc1[i - DE] : 0.f;
@@ -243,10 +249,10 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
     for (int ch = 0; ch < NCH1; ++ch) {
         const int nt = bmin(CT, T1 - ch * CT);
         if (ch + 1 < NCH1) {
-            if (T1 - (ch + 1) * CT >= CT) chunk_fetch<CT * SEC1>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
-            else chunk_fetch<(T1 % CT ? T1 % CT : CT) * SEC1>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
+            if (T1 - (ch + 1) * CT >= CT) chunk_fetch<CT * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
+            else chunk_fetch<(T1 % CT ? T1 % CT : CT) * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
         } else {
-            chunk_fetch<TC * SECC>(static_cast<const char*>(A.img_cls), WBUF(c + 1), wave, lane);
+            chunk_fetch<TC * SECC, NW>(static_cast<const char*>(A.img_cls), WBUF(c + 1), wave, lane);
         }
 #pragma unroll
         for (int tt = 0; tt < CT; ++tt) {
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
         }
     }
     // ---- phase 3: classifier (its image is in the current buffer) -------------------------------------------------------
-    if (flow) chunk_fetch<bmin(CT, TF) * SECF>(imgf, WBUF(c + 1), wave, lane);
+    if (flow) chunk_fetch<bmin(CT, TF) * SECF, NW>(imgf, WBUF(c + 1), wave, lane);
     {
         float part = 0.f;
 #pragma unroll
@@ -333,8 +339,8 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
     for (int ch = 0; ch < NCHF; ++ch) {
         const int nt = bmin(CT, TF - ch * CT);
         if (ch + 1 < NCHF) {
-            if (TF - (ch + 1) * CT >= CT) chunk_fetch<CT * SECF>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
-            else chunk_fetch<(TF % CT ? TF % CT : CT) * SECF>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
+            if (TF - (ch + 1) * CT >= CT) chunk_fetch<CT * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
+            else chunk_fetch<(TF % CT ? TF % CT : CT) * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
         }
 #pragma unroll
         for (int tt = 0; tt < CT; ++tt) {
@@ -376,10 +382,10 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
         // slab layout [feature][edge], 36 floats per feature row: the writes of one accumulator register are two runs of 32
         // consecutive floats, the walk reads a lane's row with eight conflict-free ds_read_b128
         constexpr int RT = AGG_RT, FR = 32 * RT, LP = 36, ROUNDS = TD / RT;
-        static_assert(TD % RT == 0 && 8 * FR * LP * 4 <= WB_BYTES, "aggregation slabs do not fit the chunk buffers");
+        static_assert(TD % RT == 0 && NW * FR * LP * 4 <= WB_BYTES, "aggregation slabs do not fit the chunk buffers");
         __syncthreads();   // every wave has consumed the last weight chunk
         float* const wl = reinterpret_cast<float*>(smem) + wave * (FR * LP);
-        const int wt = blockIdx.x * 8 + wave;
+        const int wt = blockIdx.x * NW + wave;
         const int tile_first = tile0 + wave * 32;
         const int key = grp * A.N + row;
         const int s0 = A.seg_ptr[key], s1 = A.seg_ptr[key + 1];
@@ -443,15 +449,16 @@ __global__ __launch_bounds__(512, 1) void edge_chain_bf16_kernel(EdgeChainBf16Ar
 // which such a segment BEGINS; it walks the following tiles' continuation pieces in order until the segment ends.
 __global__ __launch_bounds__(64) void k_agg_fixup(const int* __restrict__ header, const int* __restrict__ seg_ptr,
                                                   const int* __restrict__ start_row, const float* __restrict__ piece,
-                                                  float* __restrict__ agg_out, int N, int dn, int DN, int agg) {
-    const int wt = blockIdx.x, blk = wt >> 3, wave = wt & 7;
+                                                  float* __restrict__ agg_out, int N, int dn, int DN, int agg, int nw) {
+    const int wt = blockIdx.x, blk = wt / nw, wave = wt - blk * nw;
     const int e_out = header[1], e_in = header[2];
-    const int nb0 = (e_out + 255) >> 8, nb1 = (e_in + 255) >> 8;
+    const int epb = 32 * nw;
+    const int nb0 = (e_out + epb - 1) / epb, nb1 = (e_in + epb - 1) / epb;
     int grp, beg, end, bl;
     if (blk < nb0) { grp = 0; beg = 0; end = e_out; bl = blk; }
     else if (blk < nb0 + nb1) { grp = 1; beg = e_out; end = e_out + e_in; bl = blk - nb0; }
     else return;
-    const int first = beg + bl * 256 + wave * 32;
+    const int first = beg + bl * epb + wave * 32;
     if (first >= end) return;
     const int r = start_row[wt];
     if (r < 0) return;
@@ -560,13 +567,19 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s) {
         set_error("edge_chain_bf16: graph too large for 32-bit row offsets");
         return MPNHIP_ERR_UNSUPPORTED;
     }
-    const unsigned blocks = (unsigned)((a.E + 255) / 256 + 3);
+    // 256-d: 4-wave blocks, two per CU (cfg-E: 643 -> 581 us per launch; A-B switch MPNHIP_CHAIN_BF16_NW=8 for one 8-wave block)
+    static const int nw_env = [] { const char* e = getenv("MPNHIP_CHAIN_BF16_NW"); return e ? atoi(e) : 0; }();
+    const int variant = chain_bf16_variant(a.he, a.de, a.hn, a.dn, a.hc);
+    const bool four = variant == 256 && nw_env != 8;
+    const int epb = four ? 128 : 256;
+    const unsigned blocks = (unsigned)((a.E + epb - 1) / epb + 3);
     count_path(PC_CHAIN_FWD_BF16);
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0;
-    switch (chain_bf16_variant(a.he, a.de, a.hn, a.dn, a.hc)) {
+    switch (variant) {
         case 256:
             // (widths that are multiples of 32 only: the masked form of this variant does not fit the register budget)
-            MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true>), dim3(blocks), dim3(512), s, a);
+            if (four) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1>), dim3(blocks), dim3(256), s, a);
+            else MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true>), dim3(blocks), dim3(512), s, a);
             break;
         case 128:
             if (exact) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<10, 2, 7, 4, 1, 2, true>), dim3(blocks), dim3(512), s, a);
@@ -578,8 +591,8 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s) {
     }
     MPN_LAUNCH_CHECK();
     if (a.agg_out) {
-        hipLaunchKernelGGL(k_agg_fixup, dim3(blocks * 8), dim3(64), 0, s, a.header, a.seg_ptr, a.start_row, a.piece, a.agg_out, a.N, a.dn,
-                           (a.dn + 31) / 32 * 32, a.agg);
+        hipLaunchKernelGGL(k_agg_fixup, dim3(blocks * (four ? 4 : 8)), dim3(64), 0, s, a.header, a.seg_ptr, a.start_row, a.piece, a.agg_out,
+                           a.N, a.dn, (a.dn + 31) / 32 * 32, a.agg, four ? 4 : 8);
         MPN_LAUNCH_CHECK();
     }
     return MPNHIP_OK;
