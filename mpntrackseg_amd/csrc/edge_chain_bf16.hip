@@ -105,6 +105,17 @@ __device__ __forceinline__ void chunk_fetch(const char* src, char* buf, int wave
     }
 }
 
+// Barrier at the end of a weight chunk WITHOUT draining the gathers in flight: __syncthreads() carries a fence, i.e.
+// s_waitcnt vmcnt(0), which also waits for the next tile's row gathers issued a moment ago -- once per chunk, the whole gather
+// latency exposed (ablation at cfg-E: 151 of the launch's 592 us).  What the barrier needs is the NEXT chunk's LDS-DMA (issued at
+// the top of this chunk, pinned there by a compiler barrier) and nothing younger: vmcnt(N) with N = the loads issued after it,
+// which the loop knows exactly (N row gathers of the next tile).  Other waves' DMA pieces are covered by their own waits.
+template <int N>
+__device__ __forceinline__ void chunk_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin_order() { asm volatile("" ::: "memory"); }
+
 constexpr int DEPTH = 4;   // A operands in flight per wave
 
 // NU units from LDS address wa + OFF0 (+ 1 KiB per unit), DEPTH reads in flight; use(u, a) consumes unit u's A operand
@@ -248,12 +259,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
 #pragma unroll
     for (int ch = 0; ch < NCH1; ++ch) {
         const int nt = bmin(CT, T1 - ch * CT);
-        if (ch + 1 < NCH1) {
-            if (T1 - (ch + 1) * CT >= CT) chunk_fetch<CT * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
-            else chunk_fetch<(T1 % CT ? T1 % CT : CT) * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
-        } else {
-            chunk_fetch<TC * SECC, NW>(static_cast<const char*>(A.img_cls), WBUF(c + 1), wave, lane);
-        }
+        // the next chunk's DMA goes out AFTER the first tile has taken its gathered C-in (the compiler's wait for those loads is
+        // vmcnt(0): issued earlier, the DMA would be waited for right there, its whole L2 latency exposed once per chunk)
+        auto fetch_next = [&]() {
+            if (ch + 1 < NCH1) {
+                if (T1 - (ch + 1) * CT >= CT) chunk_fetch<CT * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
+                else chunk_fetch<(T1 % CT ? T1 % CT : CT) * SEC1, NW>(img1 + (size_t)(ch + 1) * CT * SEC1 * 1024, WBUF(c + 1), wave, lane);
+            } else {
+                chunk_fetch<TC * SECC, NW>(static_cast<const char*>(A.img_cls), WBUF(c + 1), wave, lane);
+            }
+            pin_order();
+        };
 #pragma unroll
         for (int tt = 0; tt < CT; ++tt) {
             if (tt < nt) {
@@ -264,13 +280,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                     acc[4 * g + 0] = cin[g].x + cin[4 + g].x; acc[4 * g + 1] = cin[g].y + cin[4 + g].y;
                     acc[4 * g + 2] = cin[g].z + cin[4 + g].z; acc[4 * g + 3] = cin[g].w + cin[4 + g].w;
                 }
+                if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }   // (acc is formed before the DMA goes out)
                 if (t + 1 < T1) cin_issue(t + 1);
                 else if (flow) pf_issue(0);
                 if (tt == 0) hidden_tile<0, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en);
                 else hidden_tile<SEC1 * 1024, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en);
             }
         }
-        __syncthreads();
+        // (the chunk's last tile issued the 8 gathers of the tile after it -- except the very last one: 4 or none, drain)
+        if (ch * CT + nt < T1) chunk_barrier<8>();
+        else __syncthreads();
         ++c;
     }
     // ---- e' = relu(. + b2): out, and as the B operand of the classifier and the flow MLPs -------------------------------
@@ -338,10 +357,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
 #pragma unroll
     for (int ch = 0; ch < NCHF; ++ch) {
         const int nt = bmin(CT, TF - ch * CT);
-        if (ch + 1 < NCHF) {
-            if (TF - (ch + 1) * CT >= CT) chunk_fetch<CT * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
-            else chunk_fetch<(TF % CT ? TF % CT : CT) * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
-        }
+        auto fetch_next = [&]() {
+            if (ch + 1 < NCHF) {
+                if (TF - (ch + 1) * CT >= CT) chunk_fetch<CT * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
+                else chunk_fetch<(TF % CT ? TF % CT : CT) * SECF, NW>(imgf + (size_t)(ch + 1) * CT * SECF * 1024, WBUF(c + 1), wave, lane);
+            }
+            pin_order();
+        };
 #pragma unroll
         for (int tt = 0; tt < CT; ++tt) {
             if (tt < nt) {
@@ -349,13 +371,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 f32x16 acc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = pf[g].x; acc[4 * g + 1] = pf[g].y; acc[4 * g + 2] = pf[g].z; acc[4 * g + 3] = pf[g].w; }
+                if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }
                 if (t + 1 < TF) pf_issue(t + 1);
                 if (tt == 0) hidden_tile<0, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm);
                 else hidden_tile<SECF * 1024, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm);
             }
         }
         if (ch + 1 < NCHF) {
-            __syncthreads();
+            chunk_barrier<4>();   // (4 Pf gathers of the next tile stay in flight)
             ++c;
         }
     }
