@@ -219,6 +219,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             sbias[i] = v;
         }
     }
+    // (the edge's end points first: the C-in gathers that depend on them then go out under the input rows' loads)
+    const int row = A.srow[edge], col = A.scol[edge];
+    const unsigned pro = (unsigned)row * (unsigned)A.pw;
+    const unsigned pco = (unsigned)col * (unsigned)A.pw + (unsigned)he;
+    const unsigned pfo = pco + (unsigned)(he + (grp == 1 ? hn : 0));
     // ---- first-layer input: this lane's edge row(s), k = 16 kb + 4h + (0..3), 16 kb + 8 + 4h + (0..3) per k block ------
     bf16x8 X[KB1];
 #pragma unroll
@@ -228,10 +233,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
         for (int kb = 0; kb < KBE; ++kb)
             X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 4 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 + 4 * lh, de));
     }
-    const int row = A.srow[edge], col = A.scol[edge];
-    const unsigned pro = (unsigned)row * (unsigned)A.pw;
-    const unsigned pco = (unsigned)col * (unsigned)A.pw + (unsigned)he;
-    const unsigned pfo = pco + (unsigned)(he + (grp == 1 ? hn : 0));
     // gathered C-in of one H1 tile: Pr[row] and Pc[col], 4 row pieces each; fetched one tile ahead
     float4 cin[8];
     auto cin_issue = [&](int t) {
