@@ -30,7 +30,7 @@ extern "C" {
 /* Operand precision of every Linear layer's product.  FP32 (default): fp32 operands and accumulation, the reference's
  * arithmetic.  BF16: activations and weights are rounded to bf16 (round to nearest even) as they enter the product,
  * accumulation, biases, gather-adds and aggregation stay fp32 -- BASELINE.json's "bf16 MLP GEMMs on MFMA"
- * configuration (SURVEY.md section 8d cfg-E); forward only (mpnhip_backward refuses it). */
+ * configuration (SURVEY.md section 8d cfg-E).  mpnhip_backward rounds the operands of its products the same way (round 3). */
 #define MPNHIP_PREC_FP32 0
 #define MPNHIP_PREC_BF16 1
 /* FP32_SPLIT: fp32 results from bf16 matrix instructions.  In the fused per-edge chain kernels (forward and backward) every
@@ -88,7 +88,7 @@ typedef struct {
     mpnhip_mlp flow_out;  /* MPNet.node_model.flow_out_model (mpn.py:304) */
     mpnhip_mlp node;      /* MPNet.node_model.node_model: ONE Linear(2dn -> dn) + ReLU (mpn.py:309-310) */
     mpnhip_mlp classifier;/* classifier.edge_model    (mpn.py:238) */
-    int precision;        /* MPNHIP_PREC_*: operand precision of the Linear layers' products (inference only) */
+    int precision;        /* MPNHIP_PREC_*: operand precision of the Linear layers' products (forward and backward) */
     int weights_prepacked;/* != 0: the head of `workspace` still holds the weight images a previous mpnhip_forward
                            * (save_for_backward = 0) of THIS model wrote there and no weight has changed since: skip
                            * re-packing them (about 20 small launches).  The caller vouches for it; 0 is always safe. */
