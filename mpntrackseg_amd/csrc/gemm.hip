@@ -456,6 +456,49 @@ __global__ __launch_bounds__(NTHREADS) void gemm_generic_kernel(GemmArgs args, i
     }
 }
 
+// K <= 8 (the edge encoder's first layer: edge_attr [E, 6] read through the sort permutation -> 18 d / 32 features): a thread
+// owns four neighbouring outputs of a row -- its 4 x K weights and 4 biases stay in registers while it walks rows -- so a row costs
+// K broadcast loads and one 16-byte store.  The one-thread-per-output kernel above took 414 us at cfg-E (57.6 M outputs, 12 loads
+// and a 64-bit division each) for a layer that writes 230 MB; bf16 mode rounds the operands like the MFMA path (products of two
+// bf16 values are exact in fp32, the sum runs in fp32).
+__global__ __launch_bounds__(NTHREADS) void gemm_smallk_kernel(GemmArgs args, int bf16) {
+    const GemmGroup& G = args.g[0];
+    const int N = args.N, K = args.K;
+    const int tpr = N >> 2, rpp = NTHREADS / tpr;
+    const int n4 = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
+    if (r0 >= rpp) return;
+    const int n = 4 * n4;
+    float w[4][8], bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias[j] = G.bias ? G.bias[n + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = k < K ? G.B[(int64_t)(n + j) * G.ldb + k] : 0.f;
+            w[j][k] = bf16 ? (float)(__bf16)v : v;
+        }
+    }
+    const int b = G.row_begin ? *G.row_begin : 0;
+    const int e = G.row_end ? *G.row_end : (int)G.m_static;
+    for (int64_t m = b + (int64_t)blockIdx.x * rpp + r0; m < e; m += (int64_t)gridDim.x * rpp) {
+        const int64_t ri = G.a_idx ? G.a_idx[m] : m;
+        const float* ar = G.A + ri * G.lda;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K) {
+                float av = ar[k];
+                if (bf16) av = (float)(__bf16)av;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(av, w[j][k], acc[j]);
+            }
+        }
+        float4 o = make_float4(acc[0] + bias[0], acc[1] + bias[1], acc[2] + bias[2], acc[3] + bias[3]);
+        if (args.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(G.C + m * G.ldc + n) = o;
+    }
+}
+
 template <int WM, int WN, int TN>
 static int launch_cfg(const GemmArgs& a, int bl, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * TN * WN;
@@ -509,6 +552,18 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
     }
     a.epi_vec = epi_vec ? 1 : 0;
     if (!fast) {
+        const GemmGroup& G0 = a.g[0];
+        if (a.ngroups == 1 && a.K >= 1 && a.K <= 8 && a.ksplit == a.K && bl == B_KCONTIG && !G0.A2 && !G0.G1 && !G0.G2 && !G0.mask &&
+            !G0.c_idx && !a.accumulate && a.N % 4 == 0 && a.N >= 4 && a.N <= 4 * NTHREADS && G0.ldc % 4 == 0 &&
+            (((uintptr_t)G0.C) & 15) == 0 && a.m_upper >= 4096 && !getenv("MPNHIP_NO_SMALLK")) {
+            const int rpp = NTHREADS / (a.N / 4);
+            // (a thread's 4 x K weights are 28 scalar loads: at least eight row passes per block to pay for them)
+            int64_t nb = ((a.m_upper + rpp - 1) / rpp + 7) / 8;
+            nb = nb > 256 * 16 ? 256 * 16 : (nb < 1 ? 1 : nb);
+            hipLaunchKernelGGL(gemm_smallk_kernel, dim3((unsigned)nb), dim3(NTHREADS), 0, s, a, g_precision == 1 ? 1 : 0);
+            MPN_LAUNCH_CHECK();
+            return MPNHIP_OK;
+        }
         int64_t total = a.m_upper * a.N;
         unsigned blocks = (unsigned)((total + NTHREADS - 1) / NTHREADS);
         if (blocks > 65535u * 16) blocks = 65535u * 16;
@@ -526,6 +581,12 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         for (int tn = 8; tn >= 1; --tn) {
             int cost = ((nt + tn - 1) / tn) * tn;
             if (cost < best_cost) { best_cost = cost; best = tn; }
+        }
+        // ... but not so wide that the grid leaves CUs idle: with fewer than 256 blocks (20,000 rows x 256 columns at cfg-E: 157
+        // blocks of 128 x 256) halve the strip until every CU has one (cfg-E forward 9.84 -> 9.65 ms)
+        {
+            const int64_t rb = (M + 127) / 128;
+            while (best > 1 && rb * ((nt + best - 1) / best) < 256) best = (best + 1) / 2;
         }
         if (const char* e = getenv("MPNHIP_TN")) {  // tuning override
             int v = atoi(e);
