@@ -173,8 +173,16 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
             def step():
                 return stepper(x, ei, ea, holder=holder)
         lib = capi.load()
+        t_warm = time.perf_counter()
         for _ in range(warmup):
             step()
+        torch.cuda.synchronize()
+        # (these short cases follow the headline's CPU leg: at least 0.2 s of untimed steps, so that a 0.1 ms step is not timed
+        # while the clocks are still coming back up -- seen once: cfg-D forward 0.139 ms in the line against 0.099 alone)
+        while time.perf_counter() - t_warm < 0.2:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
         if profile:
             lib.mpnhip_profile_enable(5)   # coprime with the launches per step (4 / 7 / 12 chain, 3 weight-gradient)
         capi.path_counters(reset=True)
