@@ -406,10 +406,23 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
 #pragma unroll
             for (int g = 0; g < 4; ++g) set4(h1[t], g, ldrow<EXACT>(pr, 32 * t + 8 * g + 4 * lh, he));
         if (A.Q0) {  // + the step-invariant share of the layer (hoisted out of the step loop like P0)
+            // four tiles' pieces in flight at a time (written tile by tile the compiler waits for every tile's four loads before it
+            // issues the next: ten load latencies in a row at the head of every wave)
 #pragma unroll
-            for (int t = 0; t < T1; ++t)
+            for (int t0 = 0; t0 < T1; t0 += 4) {
+                float4 q[4][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) add4(h1[t], g, ldrow<EXACT>(A.Q0, eh, 32 * t + 8 * g + 4 * lh, he));
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (t0 + tt < T1) q[tt][g] = ldrow<EXACT>(A.Q0, eh, 32 * (t0 + tt) + 8 * g + 4 * lh, he);
+                __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink every load to its add again)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (t0 + tt < T1) add4(h1[t0 + tt], g, q[tt][g]);
+            }
         }
     }
     // Pc[col] joins H1 after the MFMAs, two tiles (8 row pieces) per gather round; round r is issued one chunk before
