@@ -38,11 +38,14 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "fwd", "train"])
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra measurement in the other fp32 mode (fp32 MFMAs / split)")
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "fp32_split", "fp32_wgsplit", "bf16"],
-                    help="operand precision of the Linear products; bf16 (fp32 accumulate) is inference only and is NOT the "
-                         "headline configuration (BASELINE.json configs[4])")
+                    help="operand precision of the Linear products; bf16 (bf16 operands, fp32 accumulate: inference and training) is "
+                         "BASELINE.json configs[4]'s mode, never the headline configuration")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, one rank per GPU); gloo lets several ranks "
                          "share ONE GPU -- a functional run of the N > 1 path where only one GPU is available, not a scaling number")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: create a 1-rank process group on --backend and issue the training step's collectives anyway "
+                         "(TrainStep(force_collectives=True)): the RCCL code path on the one GPU that is there; adds allreduce_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -260,9 +263,13 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_pg = args.force_collectives and world == 1
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -340,7 +347,7 @@ def main():
             with torch.no_grad():
                 return model.hot_path(x, ei, ea, holder=holder)
     else:
-        stepper = mtrain.TrainStep(model, world_size=world)
+        stepper = mtrain.TrainStep(model, world_size=world, force_collectives=force_pg)
 
         def step():
             return stepper(x, ei, ea, holder=holder)
@@ -401,7 +408,9 @@ def main():
                                                           "training step (fwd+bwd%s)" % ("+RCCL grad all-reduce" if world > 1 else "")
                                                           if mode == "train" else "inference forward"),
                    "nodes": N, "edges": E, "feat_dim": c["d"], "mp_steps": c["L"], "agg": args.agg, "mode": mode,
-                   "parallelism": "graphs sharded 1 per GPU (dp%d)" % world if args.backend == "nccl" or world == 1 else
+                   "parallelism": ("1-rank %s process group, collectives issued (functional run of the data-parallel code path)"
+                                   % ("RCCL (nccl)" if args.backend == "nccl" else args.backend)) if force_pg else
+                                  "graphs sharded 1 per GPU (dp%d)" % world if args.backend == "nccl" or world == 1 else
                                   "dp%d over gloo, %d ranks per GPU (functional run of the N > 1 path, not a scaling number)"
                                   % (world, (world + torch.cuda.device_count() - 1) // torch.cuda.device_count())},
         "graph_prep_ms": prep_ms, "graph_prep_steady_ms": prep_steady_ms,
@@ -456,7 +465,7 @@ def main():
         except Exception as exc:   # the headline line above must survive a failure of the extra measurement
             model.gemm_precision = args.precision
             out["fp32_split" if other == "fp32_split" else "fp32_mfma"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    if world > 1 and mode == "train":
+    if (world > 1 or force_pg) and mode == "train":
         # SURVEY.md section 8e "Reporting": the gradient all-reduce alone -- S bytes of the flat fp32 bucket, all-reduce(sum) as
         # one collective, HIP events around 20 calls -- and the bus bandwidth 2 (n - 1) / n x S / t it corresponds to (ring
         # all-reduce over xGMI: 7 links x ~153 GB/s per GPU; at these sizes, 1.2 - 19 MB, the collective is latency-bound)
@@ -498,10 +507,14 @@ def main():
         except Exception as exc:
             out["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(ordered_line(out)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+TRAFFIC_SOURCE = ("committed builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (profiles/rNN/pmc_summary*.json, "
+                  "tools/pmc_summary.py), not this run")
 
 
 def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
@@ -535,6 +548,14 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
     inference = the fused forward chain; training = whichever of forward chain / backward chain / weight-gradient products
     takes most of a step (round 2: the weight-gradient product kernel); the others are reported beside it."""
     gemm_us, gemm_n, agg_us, agg_n, empty_us, extra, per_step = prof
+    # which fused chain kernel the timed region actually launched (path counters): 2 = bf16-operand chain, 1 = fp32 / split chain,
+    # 0 = none (the unfused GEMM path) -- mpnhip_edge_chain_active() only says what the model's shapes allow
+    if per_step.get("edge_chain_fwd_bf16", 0) > 0:
+        chain = 2
+    elif per_step.get("edge_chain_fwd", 0) + per_step.get("edge_chain_fwd_split", 0) > 0:
+        chain = 1
+    else:
+        chain = 0
     # avg_us: HIP events attached to the kernel's own dispatch on the launch stream (hipExtLaunchKernelGGL start / stop
     # events): the dispatch's begin -> end, what rocprofv3's kernel trace reports too (profiles/).  `empty_event_pair_us`
     # is what a plain record pair with nothing between costs on this box -- the overhead the attached events avoid.
@@ -669,7 +690,106 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         res["roofline"] = dict(res[top], dominant_of={k: round(v, 3) for k, v in cand.items()},
                                what="the kernel with the largest time per training step (ms_per_step = avg_us x launches per step); "
                                     "also listed under '%s'" % top)
+    if "roofline_aggregation" not in res and per_step.get("node_chain", 0) > 0:
+        # no separate aggregation launch in this mode: node_agg_fn runs inside node_chain_kernel (aggregate -> node update -> next
+        # projections, csrc/node_chain.hip); the HBM-streaming aggregation figure is other_configs.cfgE_*_unfused_aggregation
+        res["roofline_aggregation"] = {"fused_into": "node_chain_kernel", "launches": 0}
+    elif "roofline_aggregation" not in res and chain == 2 and agg_n == 0:
+        res["roofline_aggregation"] = {"fused_into": "edge_chain_bf16_kernel", "launches": 0}
+    for v in res.values():
+        if isinstance(v, dict) and "traffic" in v:
+            v["traffic_source"] = TRAFFIC_SOURCE if v["traffic"] else None
     return res
+
+
+def ordered_line(out):
+    """The JSON line with the long descriptive objects FIRST and the contract keys plus the compact figures LAST, so that a
+    2,000-character tail of the line carries the numbers.  Nothing is dropped: the full per-kernel
+    roofline objects stay under `details`."""
+    def short(v, n=60):
+        return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+    def compact_roofline(r):
+        if not isinstance(r, dict):
+            return r
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_us", "launches_per_step",
+                "ms_per_step", "algorithmic_bytes", "algorithmic_flops", "traffic_over_algorithmic", "mfma_frac_of_bf16_peak",
+                "dominant_of", "fused_into")
+        c = {k: r[k] for k in keep if k in r}
+        if "kernel" in c:
+            c["kernel"] = short(c["kernel"].split(":")[0].split(" (")[0], 60)
+        if c.get("traffic_source"):
+            c["traffic_source"] = "committed rocprofv3 --pmc pass (profiles/), not this run"
+        return c
+
+    details = {}
+    for k in ("roofline_fwd_chain", "roofline_bwd_chain", "roofline_weight_grad", "roofline_aggregation"):
+        if k in out:
+            details[k] = out[k]
+    if "roofline" in out:
+        details["roofline_full"] = out["roofline"]
+    if isinstance(out.get("dtype"), str) and len(out["dtype"]) > 40:
+        details["dtype_note"] = out["dtype"]
+    for k in ("fp32_mfma", "fp32_split", "allreduce_what"):
+        if k in out:
+            details[k] = out[k]
+    line = {}
+    if "other_configs" in out:
+        oc = {}
+        for name, v in out["other_configs"].items():
+            if isinstance(v, dict):
+                v = dict(v)
+                for kk in list(v):
+                    if kk.startswith("roofline") and isinstance(v[kk], dict):
+                        v[kk] = compact_roofline(v[kk])
+                if "workload" in v:
+                    v["workload"] = short(v["workload"], 110)
+            oc[name] = v
+        line["other_configs"] = oc
+    line["details"] = details
+    # ---- the contract keys and the compact figures: the tail of the line --------------------------------------------------
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        line[k] = out[k]
+    line["dtype"] = out["dtype"].split(" (")[0] if isinstance(out.get("dtype"), str) else out.get("dtype")
+    line["data"] = out["data"]
+    line["config"] = out["config"]
+    for k in ("graph_prep_ms", "graph_prep_steady_ms", "edge_steps_per_ms", "allreduce_ms", "allreduce_bytes", "bus_gbs", "allreduce_error"):
+        if k in out:
+            line[k] = out[k]
+    if "cpu_baseline" in out:
+        cb = dict(out["cpu_baseline"])
+        cb["sample"] = short(cb.get("sample", ""), 200)
+        line["cpu_baseline"] = cb
+    if "roofline" in out:
+        line["roofline"] = compact_roofline(out["roofline"])
+    summary = {}
+    if "forward_edges_per_ms" in out:
+        summary["forward_edges_per_ms"] = round(out["forward_edges_per_ms"], 1)
+    for k in ("fp32_mfma", "fp32_split"):
+        if isinstance(out.get(k), dict) and "value" in out[k]:
+            summary[k + "_edges_per_ms"] = round(out[k]["value"], 1)
+            if "forward_edges_per_ms" in out[k]:
+                summary[k + "_forward_edges_per_ms"] = round(out[k]["forward_edges_per_ms"], 1)
+    for k in ("roofline_fwd_chain", "roofline_bwd_chain", "roofline_weight_grad", "roofline_aggregation"):
+        r = out.get(k)
+        if isinstance(r, dict) and "frac" in r:
+            summary[k.replace("roofline_", "") + "_frac"] = round(r["frac"], 4)
+            if "ms_per_step" in r:
+                summary[k.replace("roofline_", "") + "_ms_per_step"] = round(r["ms_per_step"], 3)
+            if r.get("traffic_over_algorithmic"):
+                summary[k.replace("roofline_", "") + "_traffic_over_algorithmic"] = round(r["traffic_over_algorithmic"], 2)
+        elif isinstance(r, dict) and "fused_into" in r:
+            summary[k.replace("roofline_", "") + "_fused_into"] = r["fused_into"]
+    for name, v in (out.get("other_configs") or {}).items():
+        if isinstance(v, dict) and "ms_per_step" in v:
+            summary[name + "_ms"] = round(v["ms_per_step"], 4)
+            for kk in ("roofline", "roofline_weight_grad", "roofline_aggregation", "roofline_fwd_chain", "roofline_bwd_chain"):
+                if isinstance(v.get(kk), dict) and "frac" in v[kk]:
+                    summary[name + "_" + kk.replace("roofline_", "").replace("roofline", "top") + "_frac"] = round(v[kk]["frac"], 4)
+        elif isinstance(v, dict) and ("error" in v or "skipped" in v):
+            summary[name] = short(v.get("error") or v.get("skipped"), 80)
+    line["summary"] = summary
+    return line
 
 
 if __name__ == "__main__":

@@ -330,6 +330,13 @@ int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* e
  * on gradients of a clamped graph, without a host read on the ranks whose own graph is fine. */
 int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, const float* skip_flag, void* stream);
+/* The same with the step count kept where the skip decision is made: `calls` = 1, 2, ... counts the CALLS, *skipped_calls (device
+ * int, zero before the first call, may be NULL) the calls that were skipped; a skipped call adds one to it and an applied update uses
+ * the bias corrections of step calls - *skipped_calls -- torch.optim.Adam's count of applied steps -- so a skipped step followed by a
+ * good one equals ONE reference step (pl_module.py:76-77).  skipped_calls == NULL: mpnhip_adam_step_guarded. */
+int mpnhip_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int calls, const float* skip_flag, int* skipped_calls,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph construction on the device: what MOTGraph.construct_graph_object

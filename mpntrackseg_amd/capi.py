@@ -95,6 +95,7 @@ SIGNATURES = {
     "mpnhip_avgpool": (_I, [_P, _L, _I, _P, _P]),
     "mpnhip_adam_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "mpnhip_adam_step_guarded": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P, _P]),
+    "mpnhip_adam_step_counted": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P, _P, _P]),
     "mpnhip_time_valid_conn_workspace_bytes": (_Z, [_I]),
     "mpnhip_time_valid_conn_count": (_I, [_P, _I, _L, _P, _P, _Z, _P]),
     "mpnhip_time_valid_conn_fill": (_I, [_P, _I, _L, _P, _L, _P, _P]),
@@ -337,6 +338,7 @@ class PreparedGraph:
         # that cares reads it with raise_if_invalid() AFTER it has enqueued its own work -- by then the prep is long done
         self._status_slot = None
         self._validated = False
+        self._invalid = False
         if validate:
             st = self.status()
             self._validated = True
@@ -346,17 +348,18 @@ class PreparedGraph:
             self._status_slot = _status_ring.post(self)
 
     def raise_if_invalid(self):
-        """The reference raises IndexError from its ``x[row]`` / ``x[col]`` gathers when edge_index leaves [0, N) (mpn.py:69);
-        graph prep clamps such entries and sets a flag.  Reads the flag once per prepared graph (waits for the prep kernels
-        only, never for work enqueued after them)."""
-        if self._validated:
-            return
-        flag = _status_ring.read(self._status_slot, self) if self._status_slot is not None else None
-        if flag is None:
-            flag = self.status()[0]
-        self._validated = True
-        self._status_slot = None
-        if flag != 0:
+        """The reference raises IndexError from its ``x[row]`` / ``x[col]`` gathers when edge_index leaves [0, N) (mpn.py:69)
+        -- on EVERY call; graph prep clamps such entries and sets a flag.  The flag is read once per prepared graph (the read
+        waits for the prep kernels only, never for work enqueued after them) and its value kept: every later call on the same
+        prepared graph raises again."""
+        if not self._validated:
+            flag = _status_ring.read(self._status_slot, self) if self._status_slot is not None else None
+            if flag is None:
+                flag = self.status()[0]
+            self._validated = True
+            self._status_slot = None
+            self._invalid = flag != 0
+        if self._invalid:
             raise IndexError("index out of range in edge_index: entries must lie in [0, %d) (reference mpn.py:69 gathers "
                              "x[row], x[col])" % self.N)
 

@@ -363,12 +363,24 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
                      n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit, g_bwd_bf16 ? 1 : 3};
         if (wp_batch_open()) {
             if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
+            bool eligible = true;
+            for (int q = 0; q < ngroups; ++q) eligible = eligible && wp_eligible(wp[q]);
+            if (eligible) {
+                // the open batch is full (more than WP_MAX_JOBS jobs in a group of steps: deeper MLPs; or its slab region): run it
+                // and go on in a fresh one rather than switch kernels in the middle of a group
+                int st = MPNHIP_OK;
+                if (wp_batch_roll(&st) && wp_batch_add(wp, ngroups)) return MPNHIP_OK;
+                MPN_TRY(st);
+            }
+            // not a shape / alignment of the row-panel kernel (or the batch cannot be rolled): the fp32 kernel below, counted
+            count_path(PC_TN_PANEL_FALLBACK);
         } else {
             WpBatch own;
             WpBatchGuard guard;
             wp_batch_begin(&own, slab_base, 2 * p.slab_floats_per_group, false);
             if (wp_batch_add(wp, ngroups)) return wp_batch_flush(s);
             wp_batch_abort();
+            count_path(PC_TN_PANEL_FALLBACK);
         }
     }
     TnArgs a = {};
@@ -723,7 +735,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         // (calls are serialised on `st`, so successive groups may share the slab region)
         WpBatch wpb;
         WpBatchGuard wpg;
-        if (g_wgrad_split) wp_batch_begin(&wpb, p.slab_wp, p.slab_wp_floats, true);
+        if (g_wgrad_split) { wp_batch_begin(&wpb, p.slab_wp, p.slab_wp_floats, true); wp_batch_set_stream(st); }
         auto finish = [&]() -> int { return wp_batch_open() ? wp_batch_flush(st) : MPNHIP_OK; };
         {   // node update Linear
             float* gw[2] = {m.node.grad_weight[0], nullptr};

@@ -163,11 +163,16 @@ struct WpProduct {         // host-side description of one product
     const float* H2; int64_t ldh2, h2_bstride; int csplit;   // second column segment of H (nullptr: none)
     int pieces;            // 3 (fp32 from three bf16 pieces) or 1 (bf16-rounded operands); 0 = 3
 };
-struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched; };
+struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched;
+                 hipStream_t stream; bool has_stream; };   // has_stream: the stream every flush of this batch goes to is known (wp_batch_roll)
 bool wp_eligible(const WpProduct& p);
 // (batched: the job shares its launch with the other products of a group of steps -- fewer row chunks per job)
 size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched);
 void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched);   // opens b for the calling thread
+void wp_batch_set_stream(hipStream_t s);     // the open batch will be flushed on `s` (allows wp_batch_roll)
+// the open batch is full (job table or slab space) for these eligible products: run what it holds on its stream and reopen it
+// empty -- launches on one stream are serial, so the slab region is reused; false: not possible (no stream set / nothing recorded)
+bool wp_batch_roll(int* status);
 bool wp_batch_open();
 bool wp_batch_add(const WpProduct& p);       // true: recorded (a batch is open, the product is eligible, table and slab space suffice)
 bool wp_batch_add(const WpProduct* ps, int n);   // all n (the direction groups of one product) or none
@@ -319,7 +324,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_COUNT
 };
 void count_path(int id);
 

@@ -149,6 +149,7 @@ struct EdgeChainBf16Args {
     float* piece;             // chain_bf16_agg_scratch_floats()
     int* start_row;
     int agg;                  // MPNHIP_AGG_*
+    int plain_barriers;       // 1: __syncthreads() at the weight-chunk ends instead of the counted waits (A-B switch)
 };
 // floats of the fused aggregation's scratch: piece [tiles][2][pad32(dn)] followed by start_row [tiles] (ints)
 size_t chain_bf16_agg_scratch_floats(int64_t E, int dn, size_t* off_start_row);

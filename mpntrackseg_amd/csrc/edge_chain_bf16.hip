@@ -110,9 +110,13 @@ __device__ __forceinline__ void chunk_fetch(const char* src, char* buf, int wave
 // latency exposed (ablation at cfg-E: 151 of the launch's 592 us).  What the barrier needs is the NEXT chunk's LDS-DMA (issued at
 // the top of this chunk, pinned there by a compiler barrier) and nothing younger: vmcnt(N) with N = the loads issued after it,
 // which the loop knows exactly (N row gathers of the next tile).  Other waves' DMA pieces are covered by their own waits.
+// lgkmcnt(0) rides along (free here): a wave must not cross the barrier with ds_reads of the current buffer outstanding while
+// another wave's DMA of the chunk after next overwrites it.  `plain` (EdgeChainBf16Args::plain_barriers, MPNHIP_CHAIN_BF16_PLAIN_BARRIERS=1):
+// the A-B fallback to __syncthreads() -- a test compares the two bit for bit (tests/test_gpu_parity.py).
 template <int N>
-__device__ __forceinline__ void chunk_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+__device__ __forceinline__ void chunk_barrier(bool plain) {
+    if (plain) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pin_order() { asm volatile("" ::: "memory"); }
 
@@ -234,7 +238,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 4 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 + 4 * lh, de));
     }
     // gathered C-in of one H1 tile: Pr[row] and Pc[col], 4 row pieces each; fetched one tile ahead
-    float4 cin[8];
+    // (CIN_LOADS / PF_LOADS: the vector-memory operations cin_issue / pf_issue put behind a chunk's LDS-DMA -- what the counted
+    // chunk barriers below leave in flight; change the loops and these together)
+    constexpr int CIN_LOADS = 8, PF_LOADS = 4;
+    float4 cin[CIN_LOADS];
+    static_assert(sizeof(cin) / sizeof(cin[0]) == 2 * 4 && CIN_LOADS == 2 * 4, "cin_issue issues 2 x 4 row loads");
     auto cin_issue = [&](int t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             cin[4 + g] = ldrow<EXACT>(A.P, pco, 32 * t + 8 * g + 4 * lh, he);
         }
     };
-    float4 pf[4];
+    float4 pf[PF_LOADS];
+    static_assert(sizeof(pf) / sizeof(pf[0]) == 4 && PF_LOADS == 4, "pf_issue issues 4 row loads");
     auto pf_issue = [&](int t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) pf[g] = ldrow<EXACT>(A.P, pfo, 32 * t + 8 * g + 4 * lh, hn);
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             }
         }
         // (the chunk's last tile issued the 8 gathers of the tile after it -- except the very last one: 4 or none, drain)
-        if (ch * CT + nt < T1) chunk_barrier<8>();
+        if (ch * CT + nt < T1) chunk_barrier<CIN_LOADS>(A.plain_barriers != 0);
         else __syncthreads();
         ++c;
     }
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             }
         }
         if (ch + 1 < NCHF) {
-            chunk_barrier<4>();   // (4 Pf gathers of the next tile stay in flight)
+            chunk_barrier<PF_LOADS>(A.plain_barriers != 0);   // (the Pf gathers of the next tile stay in flight)
             ++c;
         }
     }
@@ -585,8 +594,10 @@ int pack_chain_bf16(const float* w_edge0, int ld_edge0, int col0_edge, int ef, c
     return MPNHIP_OK;
 }
 
-int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s) {
-    if (a.E <= 0) return MPNHIP_OK;
+int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
+    if (a_in.E <= 0) return MPNHIP_OK;
+    EdgeChainBf16Args a = a_in;
+    if (const char* e = getenv("MPNHIP_CHAIN_BF16_PLAIN_BARRIERS")) a.plain_barriers = e[0] == '1' ? 1 : 0;
     if ((int64_t)a.E * bmax(bmax(a.he, a.dn), a.de) >= ((int64_t)1 << 32) || (int64_t)a.N * a.pw >= ((int64_t)1 << 32)) {
         set_error("edge_chain_bf16: graph too large for 32-bit row offsets");
         return MPNHIP_ERR_UNSUPPORTED;

@@ -189,10 +189,22 @@ extern "C" int mpnhip_step_metrics(const void* graph_buf, int n_nodes, int64_t n
 namespace mpnhip {
 namespace {
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ skip) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ skip,
+                       int calls, int* __restrict__ skipped) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (skip && *skip != 0.f) {   // (a rank of the job reported an invalid graph: nobody steps -- mpnhip_adam_step_guarded)
+        // the skipped call does not count as an optimizer step: remembered on the device (no other thread of this launch reads
+        // the counter on this branch, and no thread writes it on the other one)
+        if (skipped && i == 0) skipped[0] += 1;
+        return;
+    }
     if (i >= n) return;
-    if (skip && *skip != 0.f) return;   // (a rank of the job reported an invalid graph: nobody steps -- mpnhip_adam_step_guarded)
+    if (skipped) {
+        // bias corrections of the t-th APPLIED update, t = calls so far - skipped ones (torch.optim.Adam counts applied steps)
+        const float t = (float)(calls - skipped[0]);
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     // torch.optim.Adam (not AdamW): L2 decay joins the gradient; m, v exponential averages; bias corrections
     const float pi = p[i];
     const float gi = g[i] + wd * pi;
@@ -206,26 +218,30 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 }  // namespace
 }  // namespace mpnhip
 
-extern "C" int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                                        float beta1, float beta2, float eps, float weight_decay, int step, const float* skip_flag,
-                                        void* stream_);
-extern "C" int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                                float beta1, float beta2, float eps, float weight_decay, int step, void* stream_) {
-    return mpnhip_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream_);
+extern "C" int mpnhip_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int calls, const float* skip_flag,
+                                        int* skipped_calls, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(n >= 0 && calls >= 1, "adam_step: bad size / step");
+    if (n == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adam_step: null pointer");
+    const float bc1 = 1.f - powf(beta1, (float)calls);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)calls));
+    hipLaunchKernelGGL(mpnhip::k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, skip_flag, calls, skipped_calls);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
 }
 
 extern "C" int mpnhip_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                         float beta1, float beta2, float eps, float weight_decay, int step, const float* skip_flag,
                                         void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    MPN_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size / step");
-    if (n == 0) return MPNHIP_OK;
-    MPN_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adam_step: null pointer");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(mpnhip::k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, skip_flag);
-    MPN_LAUNCH_CHECK();
-    return MPNHIP_OK;
+    return mpnhip_adam_step_counted(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, skip_flag, nullptr,
+                                    stream_);
 }
 
+extern "C" int mpnhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step, void* stream_) {
+    return mpnhip_adam_step_counted(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr,
+                                    stream_);
+}

@@ -639,7 +639,25 @@ void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched) {
     b->bytes = 0.0;
     b->nblocks = 0;
     b->nred = 0;
+    b->stream = nullptr;
+    b->has_stream = false;
     g_wp = b;
+}
+void wp_batch_set_stream(hipStream_t s) {
+    if (g_wp) { g_wp->stream = s; g_wp->has_stream = true; }
+}
+bool wp_batch_roll(int* status) {
+    WpBatch* b = g_wp;
+    *status = MPNHIP_OK;
+    if (!b || !b->has_stream || b->tab.njobs == 0) return false;
+    float* slab = b->slab;
+    const size_t fl = b->slab_floats;
+    const bool batched = b->batched;
+    const hipStream_t s = b->stream;
+    *status = wp_batch_flush(s);
+    wp_batch_begin(b, slab, fl, batched);
+    wp_batch_set_stream(s);
+    return *status == MPNHIP_OK;
 }
 bool wp_batch_open() { return g_wp != nullptr; }
 void wp_batch_abort() { g_wp = nullptr; }

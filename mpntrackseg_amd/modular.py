@@ -253,14 +253,17 @@ def node_model_forward(nm, x, edge_index, edge_attr):
     return _BnReluDropout.apply(z, None, None, None, True, 0.0, 0)
 
 
-def hot_path(model, x, edge_index, edge_attr):
-    """Encoder -> L x (reattach, MetaLayer, classifier): logits [max(L, 1), E] (mpn.py:349-392, the tracking branch)."""
+def hot_path(model, x, edge_index, edge_attr, holder=None, return_state=False):
+    """Encoder -> L x (reattach, MetaLayer, classifier): logits [max(L, 1), E] (mpn.py:349-392, the tracking branch);
+    ``return_state``: (logits, final node features, final edge features) like ``MOTMPNet.hot_path``."""
     capi.require_device(x, edge_index, edge_attr)
     x, ea = capi.f32c(x), capi.f32c(edge_attr)
     ei = edge_index.to(torch.int64)
     N = x.shape[0]
-    if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= N):
-        raise IndexError("edge_index out of range for %d nodes" % N)    # the reference's x[row] gather (mpn.py:69)
+    # the reference's x[row] gather raises IndexError (mpn.py:69): validated once per prepared graph through graph prep's flag
+    # (cached on the holder like the fused path's), not by a min / max host read per call
+    from .mpn import _prepared
+    _prepared(ei, N, holder).raise_if_invalid()
     e = mlp_forward(model.encoder.edge_model, ea)                        # mpn.py:356
     h = mlp_forward(model.encoder.node_model, x)
     e0, h0 = e, h
@@ -275,4 +278,5 @@ def hot_path(model, x, edge_index, edge_attr):
         logits.append(mlp_forward(model.classifier.edge_model, e).view(-1))   # mpn.py:377 -> classifier
     if not logits:
         logits.append(mlp_forward(model.classifier.edge_model, e).view(-1))
-    return torch.stack(logits, dim=0)
+    out = torch.stack(logits, dim=0)
+    return (out, h, e) if return_state else out

@@ -413,7 +413,7 @@ class MOTMPNet(nn.Module):
         m.num_enc_steps = int(self.num_enc_steps)
         # operand precision of the Linear products (include/mpnhip.h MPNHIP_PREC_*): 'fp32' (fp32 MFMAs), 'fp32_split'
         # (fp32 results from three-piece bf16 operands in the fused chain kernels: same accuracy, fewer MFMA cycles) or
-        # 'bf16' (inference only: operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs" mode)
+        # 'bf16' (operands rounded to bf16, fp32 accumulation -- BASELINE.json's "bf16 MLP GEMMs" mode; inference and training)
         m.precision = capi.PRECISIONS[self.operand_precision(n_edges)]
         m.enc_node = self.encoder.node_model.c_struct(keep, grads)
         m.enc_edge = self.encoder.edge_model.c_struct(keep, grads)
@@ -500,8 +500,7 @@ class MOTMPNet(nn.Module):
             # BatchNorm / Dropout (mlp.py:14,20) in TRAINING mode -- batch statistics rule the fused kernels out -- or their
             # gradients in eval mode (BatchNorm as the affine map of its running statistics): layer by layer
             from . import modular
-            logits = modular.hot_path(self, x, edge_index, edge_attr)
-            return (logits, None, None) if return_state else logits
+            return modular.hot_path(self, x, edge_index, edge_attr, holder=holder, return_state=return_state)
         if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
                                         any(p.requires_grad for p in self._hp_params())):
             from .autograd import mpn_hot_path_autograd

@@ -87,7 +87,15 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(bucket.flat_params)
         self.exp_avg_sq = torch.zeros_like(bucket.flat_params)
-        self.t = 0
+        self.t = 0   # calls of step()
+        # guarded calls that the device-side flag skipped: kept ON the device next to the moments (the host never reads the flag on
+        # the ranks whose own graph is fine), so that the bias corrections follow the number of APPLIED updates like torch's Adam
+        self.skipped = torch.zeros(4, dtype=torch.int32, device=bucket.flat_params.device)
+
+    @property
+    def applied_steps(self):
+        """Updates actually applied (a host read of the device-side counter; diagnostics / tests)."""
+        return self.t - int(self.skipped[0])
 
     def step(self, guarded=False):
         """``guarded``: skip the update (on the device, no host read) when the bucket's spare element ``flat[n]`` is non-zero."""
@@ -96,10 +104,11 @@ class FlatAdam:
         capi._weights_epoch[0] += 1   # raw-pointer update: invalidates packed weight images kept by MOTMPNet.hot_path
         b = self.bucket
         skip = C.c_void_p(b.flat.data_ptr() + 4 * b.n) if guarded else None
-        capi.check(capi.load().mpnhip_adam_step_guarded(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
+        capi.check(capi.load().mpnhip_adam_step_counted(capi.ptr(b.flat_params), capi.ptr(b.flat), capi.ptr(self.exp_avg),
                                                         capi.ptr(self.exp_avg_sq), b.n, C.c_float(self.lr),
                                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                                                        C.c_float(self.weight_decay), self.t, skip, capi.stream_ptr()),
+                                                        C.c_float(self.weight_decay), self.t, skip,
+                                                        capi.ptr(self.skipped) if guarded else None, capi.stream_ptr()),
                    "mpnhip_adam_step")
 
 
@@ -107,11 +116,15 @@ class TrainStep:
     """fwd (saving activations) -> loss gradient -> hand-written bwd into the flat bucket ->
     all-reduce(sum)/W over RCCL (world_size > 1) -> Adam.  Graph prep is cached on `holder`."""
 
-    def __init__(self, model, world_size=1, lr=1e-3, process_group=None, weight_decay=0.0):
+    def __init__(self, model, world_size=1, lr=1e-3, process_group=None, weight_decay=0.0, force_collectives=False):
+        """``force_collectives``: issue the step's collectives (and the guarded optimizer step) even at world_size 1 -- a 1-rank
+        process group exercises the whole data-parallel code path (RCCL communicator, the side stream as an ExternalStream, two
+        asynchronous bucket all-reduces, the join) where only one GPU is available; the result is the single-rank step's."""
         if not backward_available():
             raise capi.MpnhipError("TrainStep needs mpnhip_backward")
         self.model = model
         self.world_size = world_size
+        self.collectives = world_size > 1 or bool(force_collectives)
         self.pg = process_group
         self.bucket = FlatBucket(model.hot_path_parameters())
         # hot_path_parameters(): encoder.node_model, encoder.edge_model, then the message-passing modules and the classifier:
@@ -170,7 +183,7 @@ class TrainStep:
         self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0)
         self.bucket.zero_()
         lib = capi.load()
-        defer = self.world_size > 1 and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))
+        defer = self.collectives and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))
         native_backward(model, g, x, ea, glog, ws, self.bucket.views, defer_side_join=defer)
         # IndexError like the reference's x[row] gather for an edge_index outside [0, N) (graph prep clamps such entries and sets a
         # flag): read once per graph, BEFORE anything is done with the gradients of the clamped graph -- the prep finished long
@@ -180,7 +193,7 @@ class TrainStep:
             g.raise_if_invalid()
         except IndexError as exc:
             err = exc
-        if self.world_size > 1:
+        if self.collectives:
             # every rank must take part in this step's collectives; the flag rides in a spare element of the bucket, the reduced
             # element guards the optimizer step on every rank (nobody steps on bad gradients), then the offending rank raises
             if err is not None:
@@ -190,7 +203,7 @@ class TrainStep:
         elif err is not None:
             raise err
         if optimizer_step:
-            self.opt.step(guarded=self.world_size > 1)
+            self.opt.step(guarded=self.collectives)
         if err is not None:
             raise err
         return logits

@@ -85,15 +85,30 @@ class precision:
 # Sites: "enc_e.<i>", "enc_n.<i>", "s<step>.edge.<i>", "s<step>.flow.<i>" (both directions, full [E, w] arrays),
 # "s<step>.cls.<i>", "s<step>.node", and "s<step>.argmax" ([N, 2 dn] original edge ids, -1 = empty; [flow_in | flow_out]).
 class Decisions:
+    # "record" (tests only): run normally and KEEP every site's own ReLU decisions (bit-packed) together with the pre-activations
+    # that lie within NEAR x rms of zero -- everything a later compare_recorded(given) needs, so that one free-running float64
+    # forward serves the comparison of several HIP runs (the fp32 / fp32_split / fp32_wgsplit variants of one test case)
+    NEAR = 1e-3
+
     def __init__(self, given, mode):
-        assert mode in ("compare", "impose")
+        assert mode in ("compare", "impose", "record")
         self.given, self.mode = given, mode
         self.units = 0
         self.mismatches = 0
         self.worst_margin = 0.0      # largest |z| / rms(z) over the mismatching units
         self.per_site = {}
+        self.recorded = []           # record mode: (site, rows, packed own decisions, shape, rms, near indices, near |z|)
 
     def relu(self, z, site, rows=None):
+        if self.mode == "record":
+            import numpy as np
+            zd = z.detach()
+            scale = float(zd.double().pow(2).mean().sqrt())
+            flat = zd.reshape(-1)
+            near = torch.nonzero(flat.abs() < self.NEAR * max(scale, 1e-300)).view(-1)
+            self.recorded.append((site, None if rows is None else rows.clone(), np.packbits((zd > 0).numpy().reshape(-1)), tuple(zd.shape),
+                                  scale, near.numpy(), flat[near].abs().double().numpy()))
+            return torch.relu(z)
         mask = self.given[site]
         if rows is not None:
             mask = mask[rows]
@@ -110,6 +125,33 @@ class Decisions:
             self.worst_margin = max(self.worst_margin, margin)
             self.per_site[site] = self.per_site.get(site, 0) + nbad
         return torch.relu(z)
+
+    def compare_recorded(self, given):
+        """The statistics a "compare" run with `given` would have produced, from a "record" run's data (ReLU sites)."""
+        import numpy as np
+        out = Decisions(given, "compare")
+        for site, rows, packed, shape, scale, near_idx, near_abs in self.recorded:
+            mask = given[site]
+            if rows is not None:
+                mask = mask[rows]
+            n = int(np.prod(shape))
+            own = np.unpackbits(packed, count=n).astype(bool)
+            bad = np.nonzero(own != mask.numpy().reshape(-1))[0]
+            out.units += n
+            if bad.size:
+                if len(near_idx):
+                    pos = np.minimum(np.searchsorted(near_idx, bad), len(near_idx) - 1)
+                    found = near_idx[pos] == bad
+                else:
+                    pos, found = np.zeros(bad.shape, np.int64), np.zeros(bad.shape, bool)
+                # a differing unit outside the recorded band is at least NEAR x rms from zero: far beyond any accepted margin
+                margin = 0.0 if bool(np.all(found)) else self.NEAR
+                if bool(np.any(found)):
+                    margin = max(margin, float(near_abs[pos[found]].max()) / max(scale, 1e-300))
+                out.mismatches += int(bad.size)
+                out.worst_margin = max(out.worst_margin, margin)
+                out.per_site[site] = out.per_site.get(site, 0) + int(bad.size)
+        return out
 
 
 _DECISIONS = [None]

@@ -23,6 +23,10 @@ def main():
     what = sys.argv[3] if len(sys.argv) > 3 else "average"
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
+    if what == "nccl1":
+        # ONE rank, backend nccl (= RCCL): the communicator, stream and async-work plumbing of the data-parallel step on real RCCL
+        dist.init_process_group("nccl", device_id=dev)
+        return nccl_one_rank_check(L, d, dev)
     dist.init_process_group("gloo")
     if what == "overlap":
         return overlap_check(rank, world, L, d, dev)
@@ -95,6 +99,52 @@ def overlap_check(rank, world, L, d, dev):
     sys.exit(0 if ok else 4)
 
 
+def nccl_one_rank_check(L, d, dev):
+    """TrainStep(force_collectives=True) on a 1-rank RCCL group: the backward leaves its side stream un-joined
+    (MPNHIP_BWD_DEFER_SIDE_JOIN), the message-passing bucket's all-reduce is enqueued on that stream through an ExternalStream with
+    async_op=True, the encoder's bucket on the caller's stream, both are waited for, mpnhip_side_stream_join, / 1, guarded Adam --
+    and must give exactly the plain single-rank step: same gradients (bitwise: a 1-rank sum, / 1), same parameters after Adam."""
+    params = synth.model_params(d, L, "sum", node_in_dim=64)
+    W = synth.make_weights(params, seed=7, gain=0.6)
+
+    def fresh():
+        m = MOTMPNet(params)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+        return m.to(dev).train()
+
+    g = synth.make_graph(3000, 24000, seed=61, node_in_dim=64)
+    t = [torch.from_numpy(g[k]).to(dev) for k in ("x", "edge_index", "edge_attr")]
+    plain = TrainStep(fresh(), world_size=1, lr=1e-3)
+    coll = TrainStep(fresh(), world_size=1, lr=1e-3, force_collectives=True)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    ok = True
+    for it in range(3):
+        plain(*t)
+        coll(*t)
+        torch.cuda.synchronize()
+        same_g = bool(torch.equal(plain.bucket.flat[:plain.bucket.n], coll.bucket.flat[:coll.bucket.n]))
+        same_p = bool(torch.equal(plain.bucket.flat_params, coll.bucket.flat_params))
+        lead = coll.ev_mp_ready.elapsed_time(coll.ev_main_done) * 1e3 if L >= 4 else float("nan")
+        print("NCCL1 step %d same_grads %d same_params %d side_lead_us %.0f skipped %d" % (it, same_g, same_p, lead, coll.opt.t - coll.opt.applied_steps),
+              flush=True)
+        ok = ok and same_g and same_p and coll.opt.applied_steps == it + 1
+    moved = not torch.equal(coll.bucket.flat_params, TrainStep(fresh(), world_size=1).bucket.flat_params)
+    # an invalid graph: the flag rides through the RCCL all-reduce, the guarded Adam skips on the device, then IndexError
+    bad = t[1].clone()
+    bad[1, 5] = 3000
+    before = coll.bucket.flat_params.clone()
+    raised = False
+    try:
+        coll(t[0], bad, t[2])
+    except IndexError:
+        raised = True
+    torch.cuda.synchronize()
+    ok = ok and moved and raised and bool(torch.equal(before, coll.bucket.flat_params)) and coll.opt.applied_steps == 3
+    print("NCCL1 ok %d moved %d raised %d" % (ok, moved, raised), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 6)
+
+
 def bad_graph_check(rank, world, L, d, dev):
     """One rank's edge_index leaves [0, N): that rank raises IndexError like the reference's gather (mpn.py:69) AFTER taking part
     in the step's collectives, and NO rank applies the optimizer step (the flag rides in the bucket's spare element; guarded Adam)."""
@@ -110,15 +160,24 @@ def bad_graph_check(rank, world, L, d, dev):
     x, eit, ea = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(ei).to(dev), torch.from_numpy(g["edge_attr"]).to(dev)
     step = TrainStep(m, world_size=world, lr=1e-2)
     before = step.bucket.flat_params.detach().clone()
-    raised = False
-    try:
-        step(x, eit, ea)
-    except IndexError:
-        raised = True
+
+    class Holder:
+        pass
+    holder = Holder()   # (the prepared graph is cached here: the SECOND call finds it validated already and must raise again)
+    raised = []
+    for _ in range(2):
+        try:
+            step(x, eit, ea, holder=holder)
+            raised.append(False)
+        except IndexError:
+            raised.append(True)
     torch.cuda.synchronize()
     unchanged = bool(torch.equal(before, step.bucket.flat_params))
-    print("RANK %d badgraph raised %d unchanged %d" % (rank, raised, unchanged), flush=True)
-    ok = unchanged and raised == (rank == 1)
+    # both calls were skipped on the device on BOTH ranks: no optimizer step counted (the bias corrections of the next good
+    # step are those of step 1)
+    applied = step.opt.applied_steps
+    print("RANK %d badgraph raised %s unchanged %d applied %d" % (rank, raised, unchanged, applied), flush=True)
+    ok = unchanged and raised == [rank == 1] * 2 and applied == 0 and step.opt.t == 2
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 5)

@@ -65,6 +65,40 @@ def hip_run(model, g, r, dev):
     return logits.double().cpu().numpy(), out, given, counts
 
 
+_COMPARE_CACHE = {}   # one entry: key -> (float64 logits, Decisions in "record" mode)
+
+
+def oracle_compare(params, W, g, r, given):
+    """Statement (1): the free-running float64 oracle's logits and how its decisions compare with `given` -- forward only (no
+    autograd: nothing of it is used).  The oracle's forward does not depend on `given`, so for sum / mean aggregation ONE recorded
+    forward serves every operand-precision variant of a test case (the last case is kept; pytest runs a case's variants back to
+    back).  max: the arg-max comparison needs the given indices inside the forward -- run directly."""
+    import json
+    import zlib
+    if params["node_agg_fn"] == "max":
+        d = O.Decisions(given, "compare")
+        Wt = {k: torch.from_numpy(v).double() for k, v in W.items()}
+        with torch.no_grad(), O.decisions(d):
+            _, lg, _, _ = O.forward(params, Wt, torch.from_numpy(g["x"]).double(), torch.from_numpy(g["edge_index"]),
+                                    torch.from_numpy(g["edge_attr"]).double(), return_state=True)
+        return torch.stack([l.view(-1) for l in lg]).numpy(), d
+    h = 0
+    for a in [g["x"], g["edge_index"], g["edge_attr"]] + [W[k] for k in sorted(W)]:
+        h = zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1), h)
+    key = (json.dumps(params, sort_keys=True, default=str), h)
+    hit = _COMPARE_CACHE.get(key)
+    if hit is None:
+        rec = O.Decisions(None, "record")
+        Wt = {k: torch.from_numpy(v).double() for k, v in W.items()}
+        with torch.no_grad(), O.decisions(rec):
+            _, lg, _, _ = O.forward(params, Wt, torch.from_numpy(g["x"]).double(), torch.from_numpy(g["edge_index"]),
+                                    torch.from_numpy(g["edge_attr"]).double(), return_state=True)
+        hit = (torch.stack([l.view(-1) for l in lg]).numpy(), rec)
+        _COMPARE_CACHE.clear()
+        _COMPARE_CACHE[key] = hit
+    return hit[0], hit[1].compare_recorded(given)
+
+
 def oracle_run(params, W, g, r, given=None, mode=None, dtype=torch.float64):
     """float64 oracle forward + autograd; with `given` decisions in `mode` 'compare' or 'impose' (oracle.Decisions)."""
     Wt = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in W.items()}

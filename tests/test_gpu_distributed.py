@@ -52,6 +52,26 @@ def test_invalid_graph_on_one_rank_stops_every_ranks_optimizer_step():
     assert "RANK 1 badgraph raised 1 unchanged 1" in r.stdout and "RANK 0 badgraph raised 0 unchanged 1" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("L,d", [(6, 32), (5, 128)])
+def test_one_rank_rccl_group_runs_the_data_parallel_step(L, d):
+    """no second GPU is leased, so RCCL sees ONE rank -- but the real communicator: TrainStep's bucketed,
+    side-stream-ordered asynchronous all-reduces (ExternalStream + async_op + mpnhip_side_stream_join) and the guarded Adam on
+    backend "nccl", equal to the plain single-rank step; an invalid graph's flag through the RCCL all-reduce."""
+    r = run_ranks([os.path.join("tests", "dist_train_check.py"), str(L), str(d), "nccl1"], nproc=1)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "NCCL1 ok 1" in r.stdout and r.stdout.count("same_grads 1 same_params 1") == 3, r.stdout[-2000:]
+
+
+def test_bench_one_rank_rccl_group_reports_the_allreduce():
+    """bench.py --gpus 1 --backend nccl --force-collectives: a 1-rank RCCL group, the step's collectives issued, allreduce_ms printed."""
+    r = run_ranks(["bench.py", "--gpus", "1", "--backend", "nccl", "--force-collectives", "--config", "D", "--steps", "5", "--warmup", "3",
+                   "--no-cpu-baseline", "--no-split-line", "--no-extras"], nproc=1)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["allreduce_ms"] > 0 and d["allreduce_bytes"] > 0, d
+    assert "rccl" in d["config"]["parallelism"].lower() or "nccl" in d["config"]["parallelism"].lower(), d["config"]
+
+
 @pytest.mark.parametrize("cfg", ["A", "D"])
 def test_bench_two_ranks_on_one_gpu(cfg):
     """bench.py's N > 1 branch; cfg-D is the configuration BASELINE.json names for the 8-GPU run (one KITTIMOTS-like graph per rank)."""

@@ -83,6 +83,36 @@ def test_flat_adam_matches_torch_adam():
                 assert float((r.detach() - m.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
 
 
+def test_a_skipped_guarded_adam_step_does_not_count():
+    """Guarded step with the device-side flag set: nothing changes and the call is NOT counted as an optimizer step -- the next
+    good step is torch.optim.Adam's FIRST step (bias corrections of t = 1), the one after it the second."""
+    import torch
+    from mpntrackseg_amd.train import FlatAdam, FlatBucket
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    shapes = [(33, 7), (64,), (3, 3)]
+    ref = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().requires_grad_(True) for r in ref]
+    opt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-4)
+    bucket = FlatBucket(mine)
+    fopt = FlatAdam(bucket, lr=1e-2, weight_decay=1e-4)
+    before = bucket.flat_params.clone()
+    for skip in (1.0, 1.0, 0.0, 0.0, 1.0, 0.0):
+        grads = [torch.randn(s, device=dev) for s in shapes]
+        for r, m, g in zip(ref, mine, grads):
+            r.grad = g.clone()
+            bucket.views[id(m)].copy_(g)
+        bucket.flat[bucket.n:].fill_(skip)
+        if skip == 0.0:
+            opt.step()
+        fopt.step(guarded=True)
+        if skip and fopt.applied_steps == 0:
+            assert torch.equal(before, bucket.flat_params)
+        for r, m in zip(ref, mine):
+            assert float((r.detach() - m.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
+    assert fopt.t == 6 and fopt.applied_steps == 3
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_tracking_loss_against_reference_compute_loss(golden, tag):
     """csrc/loss.hip against MOTNeuralSolver._compute_loss of the reference itself (tests/golden/g9_loss_metrics.npz: loss value

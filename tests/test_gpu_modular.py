@@ -164,6 +164,16 @@ def test_model_with_batchnorm_trains_like_stock_torch(agg):
     d.x, d.edge_index, d.edge_attr = x.to(dev()), ei.to(dev()), ea.to(dev())
     out = model(d)
     assert len(out["classified_edges"]) == int(model.num_class_steps) and out["classified_edges"][0].shape == (ei.shape[1], 1)
+    # return_state on this path: the final node / edge features as tensors like the fused path's (not None), equal to
+    # the eval-free recomputation's shapes and finite; edge_index outside [0, N) raises IndexError on every call (prep flag)
+    lg2, xs, es = model.hot_path(d.x, d.edge_index, d.edge_attr, holder=d, return_state=True)
+    assert xs is not None and es is not None and xs.shape[0] == x.shape[0] and es.shape[0] == ei.shape[1]
+    assert bool(torch.isfinite(xs).all()) and bool(torch.isfinite(es).all()) and tuple(lg2.shape) == tuple(lr.shape)
+    bad_ei = d.edge_index.clone()
+    bad_ei[0, 3] = x.shape[0]
+    for _ in range(2):
+        with pytest.raises(IndexError):
+            model.hot_path(d.x, bad_ei, d.edge_attr, holder=d)
 
 
 @pytest.mark.parametrize("agg", ["sum", "mean", "max"])

@@ -527,6 +527,25 @@ def test_bf16_chain_fused_aggregation_is_exact_for_max_at_every_width(d, top_k, 
     assert np.array_equal(got, ref) and np.array_equal(xg, xr) and np.array_equal(eg, er)
 
 
+@pytest.mark.parametrize("d", [256, 128, 32])
+def test_bf16_chain_counted_barriers_equal_plain_barriers(d, monkeypatch):
+    """edge_chain_bf16_kernel ends a weight chunk with a hand-counted `s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier` (the N row gathers
+    issued behind the next chunk's LDS-DMA stay in flight) instead of __syncthreads().  A miscount would let a wave read a weight
+    chunk that has not landed: the counted build must equal the __syncthreads() fallback (MPNHIP_CHAIN_BF16_PLAIN_BARRIERS=1) BIT
+    FOR BIT, on a graph large enough that every CU holds blocks in different phases."""
+    g = synth.make_graph(6000, 90000, seed=17, node_in_dim=64)
+    params = synth.model_params(d, 2, "sum", node_in_dim=64)
+    model = make_model(params, synth.make_weights(params, seed=5, gain=0.7))
+    model.gemm_precision = 'bf16'
+    capi.path_counters(reset=True)
+    got, xg, eg = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert capi.path_counters(reset=True)["edge_chain_fwd_bf16"] == 2
+    monkeypatch.setenv("MPNHIP_CHAIN_BF16_PLAIN_BARRIERS", "1")
+    ref, xr, er = run_hot(model, g["x"], g["edge_index"], g["edge_attr"])
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref) and np.array_equal(xg, xr) and np.array_equal(eg, er)
+
+
 @pytest.mark.parametrize("d,N,E,L,agg", [(256, 900, 7000, 2, "mean"), (128, 1000, 8000, 3, "sum"), (32, 300, 2500, 4, "max")])
 def test_bf16_mode_trains_gradients_match_the_bf16_oracle(d, N, E, L, agg):
     """BASELINE.json configs[4] arithmetic under autograd: with mpnhip_model.precision = MPNHIP_PREC_BF16 the backward rounds the
@@ -712,6 +731,19 @@ def test_shape_and_index_errors_like_the_reference():
         step(x, ei, ea[:-2])
     with pytest.raises(IndexError):
         step(x[:-1], ei, ea)        # 59 nodes, but edge_index names node 59: the reference's x[row] would raise
+    # the reference raises on EVERY call: a cached (already validated) prepared graph must raise again, and nothing steps
+    holder = Data()
+    before = step.bucket.flat_params.clone()
+    for _ in range(3):
+        with pytest.raises(IndexError):
+            step(x, bad, ea, holder=holder)
+    assert torch.equal(before, step.bucket.flat_params)
+    with torch.no_grad():
+        model.eval()
+        for _ in range(2):
+            with pytest.raises(IndexError):
+                model.hot_path(x, bad, ea, holder=holder)
+        model.train()
     # a second backward through the same forward: a clear message, not an AttributeError
     xr = x.clone().requires_grad_(True)
     out = model.hot_path(xr, ei, ea)

@@ -336,3 +336,54 @@ def test_g15_stock_torch_replica_against_reference_batchnorm_training(golden, ag
     for k in z.files:
         if k.startswith(agg + ":after:"):
             assert np.abs(bufs[k[len(agg) + 7:]].double().numpy() - z[k]).max() < 1e-9, k
+
+
+def test_recorded_decisions_compare_like_a_direct_compare_run():
+    """tests/pinned.py::oracle_compare keeps ONE free-running float64 forward per test case ("record" mode: every site's own ReLU
+    decisions bit-packed + the pre-activations near zero) and compares the decisions of several HIP runs against it; the
+    statistics must be those of a direct "compare" run: same units, same mismatch counts per site, same worst margin while the
+    differing units lie inside the recorded band, and >= the band's edge (far beyond any accepted margin) otherwise."""
+    from mpntrackseg_amd import synth
+    g = synth.make_graph(60, 420, T=6, seed=3, node_in_dim=24)
+    params = synth.model_params(32, 3, "mean", node_in_dim=24)
+    W = synth.make_weights(params, seed=4)
+    Wt = {k: torch.from_numpy(v).double() for k, v in W.items()}
+    x, ei, ea = torch.from_numpy(g["x"]).double(), torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"]).double()
+    rec = O.Decisions(None, "record")
+    with torch.no_grad(), O.decisions(rec):
+        O.forward(params, Wt, x, ei, ea)
+    # "given" = the oracle's own decisions with some units flipped: those with the smallest |z| of a site (knife-edge) and,
+    # in the second variant, one unit far from zero
+    sites = {}
+    for site, rows, packed, shape, scale, near_idx, near_abs in rec.recorded:
+        own = torch.from_numpy(np.unpackbits(packed, count=int(np.prod(shape))).astype(bool)).view(shape)
+        full = sites.get(site)
+        if rows is None:
+            sites[site] = own.clone()
+        else:
+            if full is None:
+                full = sites[site] = torch.zeros((rows.shape[0], shape[1]), dtype=torch.bool)
+            full[rows] = own
+    for far in (False, True):
+        given = {k: v.clone() for k, v in sites.items()}
+        flipped = 0
+        for site, rows, packed, shape, scale, near_idx, near_abs in rec.recorded[:6]:
+            if len(near_idx) and rows is None:
+                j = int(near_idx[int(np.argmin(near_abs))])
+                given[site].view(-1)[j] = ~given[site].view(-1)[j]
+                flipped += 1
+        if far:
+            site, rows, packed, shape, scale, near_idx, near_abs = rec.recorded[0]
+            cand = np.setdiff1d(np.arange(int(np.prod(shape))), near_idx)
+            given[site].view(-1)[int(cand[0])] = ~given[site].view(-1)[int(cand[0])]
+            flipped += 1
+        assert flipped >= 2
+        direct = O.Decisions(given, "compare")
+        with torch.no_grad(), O.decisions(direct):
+            O.forward(params, Wt, x, ei, ea)
+        got = rec.compare_recorded(given)
+        assert got.units == direct.units and got.mismatches == direct.mismatches == flipped and got.per_site == direct.per_site
+        if far:
+            assert direct.worst_margin >= O.Decisions.NEAR and got.worst_margin >= O.Decisions.NEAR
+        else:
+            assert abs(got.worst_margin - direct.worst_margin) <= 1e-12 * max(1.0, direct.worst_margin)
