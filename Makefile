@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := mpntrackseg_amd/csrc
-SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_tn.hip $(CSRC)/wgrad_panel.hip $(CSRC)/edge_chain.hip $(CSRC)/edge_chain_bf16.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/node_chain.hip $(CSRC)/persist32.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/bn_dropout.hip $(CSRC)/attention.hip $(CSRC)/graph_build.hip $(CSRC)/tracker.hip
+SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_tn.hip $(CSRC)/wgrad_panel.hip $(CSRC)/edge_chain.hip $(CSRC)/edge_chain_bf16.hip $(CSRC)/edge_chain_bf16_bwd.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/node_chain.hip $(CSRC)/persist32.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/bn_dropout.hip $(CSRC)/attention.hip $(CSRC)/graph_build.hip $(CSRC)/tracker.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := $(CSRC)/libmpnhip.so
 # EXTRA=-DMPNHIP_CHAIN_TS builds the fused chain kernels with per-phase cycle stamps (tools/chain_stamps.py)
@@ -21,7 +21,7 @@ $(TORCH_LIB): $(CSRC)/torch_ops.cpp include/mpnhip.h $(LIB)
 	    -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
 	    $< -o $@ -L$(CSRC) -lmpnhip -L$(TORCH_DIR)/lib -lc10 -lc10_hip -ltorch_cpu -ltorch_hip -ltorch -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h include/mpnhip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h $(CSRC)/edge_chain_bf16_common.h include/mpnhip.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

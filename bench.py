@@ -632,7 +632,7 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                            "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
                            "traffic": pmc_traffic("gemm_edge_l1", args.config), "avg_us": gemm_us,
                            "empty_event_pair_us": empty_us, "launches": gemm_n,
-                           "algorithmic_flops": flops}
+                           "algorithmic_flops": flops, "ms_per_step": gemm_us * c["L"] / 1e3}
     if agg_n:
         # M (dn s + 4) + N dn s per direction (+ CSR offsets), both directions in one launch
         bytes_agg = E * (dn * 4 + 4) + 2 * N * dn * 4 + (2 * N + 1) * 4

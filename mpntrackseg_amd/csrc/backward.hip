@@ -112,6 +112,24 @@ __global__ void k_sum_blocks(const float* __restrict__ src, int64_t stride, int 
     *reinterpret_cast<float4*>(out + 4 * i) = acc;
 }
 
+// out[i] = sum_b src[b * stride + i] over bf16 blocks (n4 groups of four elements, ascending b), fp32 result
+__global__ void k_sum_blocks_bf16(const unsigned short* __restrict__ src, int64_t stride, int nb, int64_t n4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < nb; ++b) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src + (int64_t)b * stride + 4 * i);
+        acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
+        acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+    }
+    *reinterpret_cast<float4*>(out + 4 * i) = acc;
+}
+
+__global__ void k_bf16_to_f32(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __uint_as_float((unsigned)src[i] << 16);
+}
+
 // dst[i][:] = src[idx[i]][:]
 __global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
                               int64_t rows, int cols) {
@@ -204,6 +222,12 @@ struct BwdPlan {
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
     float* wt_scratch;                  // MPNHIP_PREC_BF16: transposed weight blocks of the activation-gradient products
     size_t wt_scratch_floats;
+    // bf16-operand training on the fused kernels (FwdPlan::b16): the dZ blocks above are bf16 rows (half the floats), the gradient
+    // w.r.t. e_s travels between the steps in two fp32 buffers, and the backward chain kernel has its own pair images
+    bool b16;
+    float* dEpp[2];                     // [E, de] fp32 ping-pong
+    char* cb16_img;                     // backward pair images (edge | classifier | flow_out | flow_in)
+    size_t cb16_off_cls, cb16_off_flow[2];
     float* slab;                        // split partials of the weight-gradient products (2 groups)
     float* slab_side;                   // the same for the products issued on the side stream
     size_t slab_floats_per_group;
@@ -249,9 +273,19 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     }
     p.dZn = a.f(L * N * d.dn);
     p.dP = a.f(L * N * d.pw);
-    for (int i = 0; i < m.flow_in.n_layers; ++i) p.dZfl[i] = a.f(L * E * m.flow_in.out_dims[i]);
-    for (int i = 0; i < m.edge.n_layers; ++i) p.dZed[i] = a.f(L * E * m.edge.out_dims[i]);
-    for (int i = 0; i + 1 < m.classifier.n_layers; ++i) p.dZcl[i] = a.f(L * E * m.classifier.out_dims[i]);
+    p.b16 = chain_bf16_train_ok(m, d);
+    auto dzb = [&](int width) { return a.f(p.b16 ? (L * E * width + 1) / 2 : L * E * width); };
+    for (int i = 0; i < m.flow_in.n_layers; ++i) p.dZfl[i] = dzb(m.flow_in.out_dims[i]);
+    for (int i = 0; i < m.edge.n_layers; ++i) p.dZed[i] = dzb(m.edge.out_dims[i]);
+    for (int i = 0; i + 1 < m.classifier.n_layers; ++i) p.dZcl[i] = dzb(m.classifier.out_dims[i]);
+    p.dEpp[0] = p.dEpp[1] = nullptr;
+    p.cb16_img = nullptr;
+    if (p.b16) {
+        for (int i = 0; i < 2; ++i) p.dEpp[i] = a.f((size_t)E * d.de);
+        const size_t bytes = chain_bf16_bwd_image_bytes(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], &p.cb16_off_cls, &p.cb16_off_flow[0],
+                                                        &p.cb16_off_flow[1]);
+        p.cb16_img = reinterpret_cast<char*>(a.f(bytes / 4));
+    }
     int mw = enc_maxw(m, d);
     if (mw < 52) mw = 52;   // (the fused reference edge encoder keeps dz2 | dz1 | dz0 side by side in T[0])
     for (int i = 0; i < 3; ++i) p.T[i] = a.f((size_t)E * mw);
@@ -302,7 +336,11 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     size_t wpmax = 0;
     for (int nb = 1; nb <= (int)L; ++nb) {
         size_t t = 0;
-        auto addw = [&](int n_out, int k_in, int64_t rows, bool ranged) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, nb, ranged, true); };
+        auto addw = [&](int n_out, int k_in, int64_t rows, bool ranged) {
+            if (rows <= 0) return;
+            const size_t f32 = wp_slab_floats(n_out, k_in, rows, nb, ranged, true), f16 = p.b16 ? wp_slab_floats(n_out, k_in, rows, nb, ranged, true, true) : 0;
+            t += f32 > f16 ? f32 : f16;
+        };
         addw(d.dn, 2 * d.dn, N, false);
         for (int i = 1; i < m.flow_in.n_layers; ++i) { addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); addw(m.flow_in.out_dims[i], m.flow_in.out_dims[i - 1], E, true); }
         addw(d.hn, d.de, E, true); addw(d.hn, d.de, E, true);
@@ -347,6 +385,9 @@ static thread_local bool g_wgrad_split = false;
 // gradients dH = dZ W through the K-contiguous bf16 GEMM (the weight block transposed into g_wt_scratch first: the kernel takes
 // nn.Linear-style [out][in] operands), the weight gradients through the row-panel kernel with ONE bf16 piece per operand
 static thread_local bool g_bwd_bf16 = false;
+// set around the products whose operands are bf16 rows (WpProduct::src16): the dZ blocks / saved activations of the fused bf16 chain
+static thread_local bool g_wg_src16 = false;
+struct Src16Scope { bool old; explicit Src16Scope(bool v) : old(g_wg_src16) { g_wg_src16 = v; } ~Src16Scope() { g_wg_src16 = old; } };
 static thread_local float* g_wt_scratch = nullptr;
 static thread_local size_t g_wt_scratch_floats = 0;
 
@@ -360,7 +401,8 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
         WpProduct wp[2];
         for (int q = 0; q < ngroups; ++q)
             wp[q] = {dZ.p, dZ.ld, dZ.bstride, H.p, H.ld, H.bstride, rr ? rr[q].begin : nullptr, rr ? rr[q].end : nullptr, rows, nbatch,
-                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit, g_bwd_bf16 ? 1 : 3};
+                     n_out, k_in, gw[q], ldw, gb ? gb[q] : nullptr, dz_idx, h_idx, H2.p, H2.ld, H2.bstride, csplit, g_bwd_bf16 ? 1 : 3,
+                     g_wg_src16 ? 1 : 0};
         if (wp_batch_open()) {
             if (wp_batch_add(wp, ngroups)) return MPNHIP_OK;
             bool eligible = true;
@@ -374,6 +416,7 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
             }
             // not a shape / alignment of the row-panel kernel (or the batch cannot be rolled): the fp32 kernel below, counted
             count_path(PC_TN_PANEL_FALLBACK);
+            if (g_wg_src16) { set_error("backward (bf16): a product over bf16 rows [%d x %d] is not covered by the row-panel kernel", n_out, k_in); return MPNHIP_ERR_UNSUPPORTED; }
         } else {
             WpBatch own;
             WpBatchGuard guard;
@@ -381,6 +424,7 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
             if (wp_batch_add(wp, ngroups)) return wp_batch_flush(s);
             wp_batch_abort();
             count_path(PC_TN_PANEL_FALLBACK);
+            if (g_wg_src16) { set_error("backward (bf16): a product over bf16 rows [%d x %d] is not covered by the row-panel kernel", n_out, k_in); return MPNHIP_ERR_UNSUPPORTED; }
         }
     }
     TnArgs a = {};
@@ -640,7 +684,10 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     if (grad_x_out) MPN_HIP(hipMemcpyAsync(p.dX[0], grad_x_out, xs * 4, hipMemcpyDeviceToDevice, s));
     else if (xs) MPN_HIP(hipMemsetAsync(p.dX[0], 0, xs * 4, s));
     // the gradient w.r.t. e_s lives in the LAST edge-layer dZ block of step s (it becomes that dZ once masked)
-    float* dE_last = L > 0 ? p.dZed[ne - 1] + (size_t)(L - 1) * es : p.dE0;
+    if (f.b16 != p.b16) { set_error("backward: the forward workspace was saved in another mode (bf16 fused training %d vs %d)", (int)f.b16, (int)p.b16); return MPNHIP_ERR_ARG; }
+    const bool use_b16 = p.b16 && E > 0 && L > 0;   // bf16-operand training on the fused kernels (plan.h: chain_bf16_train_ok)
+    int ce = 0;                                      // ... the gradient w.r.t. e_s travels in p.dEpp[ce]
+    float* dE_last = use_b16 ? p.dEpp[0] : (L > 0 ? p.dZed[ne - 1] + (size_t)(L - 1) * es : p.dE0);
     if (xs) MPN_HIP(hipMemsetAsync(p.dX0, 0, xs * 4, s));
     if (es) MPN_HIP(hipMemsetAsync(p.dE0, 0, es * 4, s));
     if (grad_e_out && es) {
@@ -653,6 +700,12 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
 
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
+    if (use_b16) {
+        const float* f0[2] = {m.flow_out.weight[0], m.flow_in.weight[0]};
+        const float* f1[2] = {m.flow_out.weight[1], m.flow_in.weight[1]};
+        MPN_TRY(pack_chain_bf16_bwd(m.edge.weight[0], m.edge.in_dim, 2 * kx + de, m.edge.weight[1], m.classifier.weight[0], f0, m.flow_out.in_dim, kx, f1,
+                                    he, de, hn, dn, m.classifier.out_dims[0], p.cb16_img, s));
+    }
     const bool use_chain = chain_shapes_ok(m, d) && E > 0 && L > 0 && !getenv("MPNHIP_NO_CHAIN_BWD");
     const bool bwd_split = use_chain && chain_split(m);
     if (use_chain) {
@@ -725,7 +778,10 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // through the edge MLP's first layer and the e0 columns of that layer's weight gradient are ONE product each with
     // S = sum_s dZ1_s after the loop -- 2 E he de MACs less in every step's backward chain and in every step's weight gradient
     // (2 x 2.05 of ~31 GFLOP per step at cfg-B), for one pass over the kept dZ1 blocks.
-    const bool hoist_e0 = use_chain && d.ef == 2 && L > 1 && pad32(de) == 64 && he % 4 == 0 && de % 4 == 0 && !getenv("MPNHIP_NO_DE0_HOIST");
+    // (the bf16 backward chain kernel never contracts the e0 columns: always hoisted there, also at L = 1)
+    const bool hoist_e0 = use_b16 || (use_chain && d.ef == 2 && L > 1 && pad32(de) == 64 && he % 4 == 0 && de % 4 == 0 && !getenv("MPNHIP_NO_DE0_HOIST"));
+    // bf16 rows: pointer `elems` unsigned shorts into a buffer the plans type as float*
+    auto u16 = [](const float* p0, int64_t elems) { return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p0) + elems); };
     // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per
     // weight (batch index = step - 1).  Issued on `st` with the slab buffer `slab`.
     auto mp_weight_grads = [&](int b0, int nb, hipStream_t st, float* slab) -> int {
@@ -743,7 +799,55 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             MPN_TRY(weight_grad(p, slab, 1, {p.dZn + zb * xs, dn, (int64_t)xs}, nullptr, {f.step0.AGG + zb * sstride, 2 * dn, sstride},
                                 {nullptr, 0, 0}, 2 * dn, nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, nb, st));
         }
-        if (E > 0) {
+        if (use_b16) {
+            // every operand of these products is a bf16 row block: the backward chain kernel's dZ outputs, the forward chain kernel's
+            // saved activations and the bf16 mirror of e_hist (WpProduct::src16: loaded as they are, one product per k block)
+            Src16Scope src16(true);
+            const int hcw = cls.out_dims[0];
+            const int64_t ss16 = 2 * sstride;   // unsigned shorts between two steps' saved activations
+            const float* dZF = u16(p.dZfl[0], zb * E * hn); const float* dZM = u16(p.dZfl[1], zb * E * dn);
+            const float* dZ1 = u16(p.dZed[0], zb * E * he); const float* dZ2 = u16(p.dZed[1], zb * E * de);
+            const float* dZc = u16(p.dZcl[0], zb * E * hcw);
+            const float* H1 = u16(f.step0.HE[0], zb * ss16); const float* HFb = u16(f.step0.HF[0], zb * ss16);
+            const float* HCb = u16(f.step0.HC[0], zb * ss16);
+            const float* eb_new = reinterpret_cast<const float*>(f.eb_hist + es * (zb + 1));
+            const float* eb_prev = reinterpret_cast<const float*>(f.eb_hist + es * zb);
+            const Operand none = {nullptr, 0, 0};
+            {   // flow layer 1, both directions
+                float* gw[2] = {m.flow_out.grad_weight[1], m.flow_in.grad_weight[1]};
+                float* gb[2] = {m.flow_out.grad_bias[1], m.flow_in.grad_bias[1]};
+                MPN_TRY(weight_grad(p, slab, 2, {dZM, dn, (int64_t)E * dn}, nullptr, {HFb, hn, ss16}, none, hn, nullptr, dn, hn, gw, hn, gb, dir_rr, E, nb, st));
+            }
+            {   // flow layer 0: e' columns [kx, kx + de) and the bias (folded into P in the forward)
+                float* gw[2] = {m.flow_out.grad_weight[0] + kx, m.flow_in.grad_weight[0] + kx};
+                float* gb[2] = {m.flow_out.grad_bias[0], m.flow_in.grad_bias[0]};
+                MPN_TRY(weight_grad(p, slab, 2, {dZF, hn, (int64_t)E * hn}, nullptr, {eb_new, de, (int64_t)es}, none, de, nullptr, hn, de, gw, m.flow_out.in_dim, gb,
+                                    dir_rr, E, nb, st));
+            }
+            {   // classifier output layer [1 x hc]: dZ = grad_logits (fp32, original order -> perm), H = HC rows (bf16)
+                float* gw[2] = {cls.grad_weight[1], nullptr};
+                float* gb[2] = {cls.grad_bias[1], nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {grad_logits + zb * E, 1, (int64_t)E}, g.perm, {HCb, hcw, ss16}, none, hcw, nullptr, 1, hcw, gw, hcw, gb, nullptr, E,
+                                    nb, st));
+            }
+            {   // classifier layer 0
+                float* gw[2] = {cls.grad_weight[0], nullptr};
+                float* gb[2] = {cls.grad_bias[0], nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {dZc, hcw, (int64_t)E * hcw}, nullptr, {eb_new, de, (int64_t)es}, none, de, nullptr, hcw, de, gw, de, gb, nullptr, E, nb,
+                                    st));
+            }
+            {   // edge layer 1
+                float* gw[2] = {m.edge.grad_weight[1], nullptr};
+                float* gb[2] = {m.edge.grad_bias[1], nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {dZ2, de, (int64_t)E * de}, nullptr, {H1, he, ss16}, none, he, nullptr, de, he, gw, he, gb, nullptr, E, nb, st));
+            }
+            {   // edge layer 0: the e_{s-1} columns and the bias (the e0 columns: one product with the summed dZ1 after the loop)
+                float* gw[2] = {m.edge.grad_weight[0] + 2 * kx + de, nullptr};
+                float* gb[2] = {m.edge.grad_bias[0], nullptr};
+                MPN_TRY(weight_grad(p, slab, 1, {dZ1, he, (int64_t)E * he}, nullptr, {eb_prev, de, (int64_t)es}, none, de, nullptr, he, de, gw, m.edge.in_dim, gb,
+                                    nullptr, E, nb, st));
+            }
+        } else if (E > 0) {
             float* dzfl_b[MPNHIP_MAX_LAYERS];
             float* dzed_b[MPNHIP_MAX_LAYERS];
             float* hf_b[MPNHIP_MAX_LAYERS];
@@ -891,7 +995,36 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         }
         dx_split = false;
         node_a_done = false;
-        if (use_chain) {
+        if (use_b16) {
+            // ---- B-E fused, bf16 operands: the mirror of the forward chain kernel (edge_chain_bf16_bwd.hip) ------------------
+            const int hcw = cls.out_dims[0];
+            auto w16 = [&](float* p0, int64_t elems) { return reinterpret_cast<unsigned short*>(p0) + elems; };
+            EdgeChainBf16BwdArgs a = {};
+            a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0;
+            a.he = he; a.de = de; a.hn = hn; a.dn = dn; a.hc = hcw;
+            a.header = g.header; a.srow = g.srow; a.perm = g.perm; a.seg_ptr = g.seg_ptr;
+            a.dAGG = p.dAGG; a.mask = reinterpret_cast<const unsigned*>(b.MK); a.ARG = b.ARG;
+            a.dlog = grad_logits + (size_t)b_ * E;
+            a.dE_in = p.dEpp[ce];
+            a.dZM = w16(p.dZfl[1], (int64_t)b_ * E * dn); a.dZF = w16(p.dZfl[0], (int64_t)b_ * E * hn);
+            a.dZc = w16(p.dZcl[0], (int64_t)b_ * E * hcw); a.dZ2 = w16(p.dZed[1], (int64_t)b_ * E * de);
+            a.dZ1 = w16(p.dZed[0], (int64_t)b_ * E * he);
+            a.dE0 = p.dE0; a.dEprev = p.dEpp[ce ^ 1];
+            a.img_edge = p.cb16_img; a.img_cls = p.cb16_img + p.cb16_off_cls;
+            a.img_flow[0] = p.cb16_img + p.cb16_off_flow[0]; a.img_flow[1] = p.cb16_img + p.cb16_off_flow[1];
+            a.wc2 = cls.weight[1];
+            prof_begin(PROF_CHAIN_BWD, s);
+            MPN_TRY(launch_edge_chain_bf16_bwd(a, s));
+            prof_end(PROF_CHAIN_BWD, s);
+            ce ^= 1;
+            // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69) over the bf16 dZ rows
+            const float* zf = reinterpret_cast<const float*>(a.dZF);
+            const float* z1 = reinterpret_cast<const float*>(a.dZ1);
+            const SegReduce2 c3[3] = {{zf, hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, 0, 0},
+                                      {z1, he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, 3, (int)N},
+                                      {z1, he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, 0, 0}};
+            MPN_TRY(segment_reduce_csr2_x3_bf16(c3, s));
+        } else if (use_chain) {
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
             EdgeChainBwdArgs a = {};
             a.E = (int)E; a.N = (int)N; a.agg = m.agg; a.first_step = step == 1 ? 1 : 0; a.cat_two = d.ef == 2 ? 1 : 0; a.split = bwd_split ? 1 : 0;
@@ -1049,7 +1182,9 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     if (hoist_e0) {
         // S = sum_s dZ1_s (the blocks are all kept for the weight gradients);  dE0 += S W1[:, e0 columns];  dW1[:, e0 columns] += S^T e0
         const int64_t n4 = E * he / 4;
-        hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dZed[0], E * he, (int)L, n4, p.dZ1sum);
+        if (use_b16) hipLaunchKernelGGL(k_sum_blocks_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
+                                        E * he, (int)L, n4, p.dZ1sum);
+        else hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dZed[0], E * he, (int)L, n4, p.dZ1sum);
         MPN_LAUNCH_CHECK();
         const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
         MPN_TRY(act_grad(1, p.dZ1sum, he, nullptr, Wa, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s));
@@ -1261,6 +1396,15 @@ extern "C" int mpnhip_debug_backward_saved(const mpnhip_model* model, int n_node
     }
     if (rows_out) *rows_out = rows;
     if (width_out) *width_out = width;
+    if (out && rows > 0 && p.b16 && (what == MPNHIP_BWD_SAVED_DZ_FLOW || what == MPNHIP_BWD_SAVED_DZ_EDGE || what == MPNHIP_BWD_SAVED_DZ_CLS)) {
+        // bf16-operand training on the fused kernels: the per-edge dZ blocks are bf16 rows (block b at b * E * width shorts)
+        const float* base = what == MPNHIP_BWD_SAVED_DZ_FLOW ? p.dZfl[layer] : (what == MPNHIP_BWD_SAVED_DZ_EDGE ? p.dZed[layer] : p.dZcl[layer]);
+        const unsigned short* s16 = reinterpret_cast<const unsigned short*>(base) + b * E * width;
+        const int64_t n = rows * width;
+        hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, s16, out, n);
+        MPN_LAUNCH_CHECK();
+        return MPNHIP_OK;
+    }
     if (out && rows > 0) MPN_HIP(hipMemcpyAsync(out, src, (size_t)rows * width * sizeof(float), hipMemcpyDeviceToDevice, s));
     return MPNHIP_OK;
 }

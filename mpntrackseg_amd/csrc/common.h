@@ -143,6 +143,8 @@ struct WpJob {             // one product (one direction group of it), as the ke
     int n_out, k_in, nbatch, csplit;
     int pieces;            // 3: fp32 operands as three bf16 pieces, six products (MPNHIP_PREC_FP32_SPLIT); 1: operands rounded to
                            // bf16, one product (MPNHIP_PREC_BF16)
+    int src16;             // 1: the operands are bf16 rows in memory (dZ / H point at unsigned shorts, leading dims and batch strides
+                           // count them); the [1 x k] form: H only (its dZ is the fp32 logit gradient)
     int chunk, nsplit;     // rows per chunk, chunks per batch
     int variant;           // block tile shape (wgrad_panel.hip kVariants)
     int tiles_o, tiles_c;  // output tiles of that shape
@@ -162,12 +164,13 @@ struct WpProduct {         // host-side description of one product
     const int* h_idx;
     const float* H2; int64_t ldh2, h2_bstride; int csplit;   // second column segment of H (nullptr: none)
     int pieces;            // 3 (fp32 from three bf16 pieces) or 1 (bf16-rounded operands); 0 = 3
+    int src16;             // bf16 source rows (WpJob::src16); needs pieces == 1
 };
 struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched;
                  hipStream_t stream; bool has_stream; };   // has_stream: the stream every flush of this batch goes to is known (wp_batch_roll)
 bool wp_eligible(const WpProduct& p);
 // (batched: the job shares its launch with the other products of a group of steps -- fewer row chunks per job)
-size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched);
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched, bool src16 = false);
 void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched);   // opens b for the calling thread
 void wp_batch_set_stream(hipStream_t s);     // the open batch will be flushed on `s` (allows wp_batch_roll)
 // the open batch is full (job table or slab space) for these eligible products: run what it holds on its stream and reopen it
@@ -277,6 +280,8 @@ struct SegReduce2 {
     int runs; int run_stride;   // (segment_reduce_csr2's `runs` form: a segment as the union of `runs` CSR runs; 0 / 1 = plain)
 };
 int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream);
+// the same over bf16 source rows (c[i].src points at unsigned shorts, c[i].lds counts them): short-segment kernel, one launch
+int segment_reduce_csr2_x3_bf16(const SegReduce2 c[3], hipStream_t stream);
 
 // in-stream event timing of two designated kernels (see mpnhip_profile_enable)
 enum { PROF_GEMM = 0, PROF_AGG = 1, PROF_CHAIN_BWD = 2, PROF_TN = 3, PROF_KINDS = 4 };
@@ -324,7 +329,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_COUNT
 };
 void count_path(int id);
 

@@ -150,7 +150,25 @@ struct EdgeChainBf16Args {
     int* start_row;
     int agg;                  // MPNHIP_AGG_*
     int plain_barriers;       // 1: __syncthreads() at the weight-chunk ends instead of the counted waits (A-B switch)
+    // training (all five or none): bf16 row-major copies of the hidden activations and of e_new for the weight-gradient
+    // products, and the ReLU decisions of H1 | e' | HC | HF | M as bits for the backward chain kernel (edge_chain_bf16_bwd.hip)
+    unsigned short* save_h1;  // [E, he] bf16
+    unsigned short* save_hc;  // [E, hc]
+    unsigned short* save_hf;  // [E, hn]
+    unsigned short* save_eb;  // [E, de]
+    unsigned* save_mask;      // chain_bf16_mask_ints(E, ...) words
 };
+// mask words per lane of one 32-edge wave tile (two 32-feature tiles per word; sections H1 | e' | HC | HF | M) and the size of one
+// step's mask buffer (every wave tile of the launch incl. its 3 spare blocks; `epb`-independent: 32-edge tiles)
+static inline int chain_bf16_mask_words(int he, int de, int hn, int dn, int hc) {
+    auto w = [](int v) { return ((v + 31) / 32 + 1) / 2; };
+    return w(he) + w(de) + w(hc) + w(hn) + w(dn);
+}
+static inline size_t chain_bf16_mask_ints(int64_t E, int he, int de, int hn, int dn, int hc) {
+    return (size_t)((E + 255) / 256 + 4) * 8 * 64 * (size_t)chain_bf16_mask_words(he, de, hn, dn, hc);
+}
+// bit of element r (0..15) of a tile with parity p inside its mask word
+__host__ __device__ static inline int chain_bf16_mask_bit(int p, int r) { return 8 * p + (r >> 1) + 16 * (r & 1); }
 // floats of the fused aggregation's scratch: piece [tiles][2][pad32(dn)] followed by start_row [tiles] (ints)
 size_t chain_bf16_agg_scratch_floats(int64_t E, int dn, size_t* off_start_row);
 bool edge_chain_bf16_supported(int he, int de, int hn, int dn, int hc, int ef);
@@ -162,5 +180,52 @@ int pack_chain_bf16(const float* w_edge0, int ld_edge0, int col0_edge, int ef, c
                     const float* const w_flow0[2], int ld_flow0, int col0_flow, const float* const w_flow1[2],
                     int he, int de, int hn, int dn, int hc, void* image, hipStream_t s);
 int launch_edge_chain_bf16(const EdgeChainBf16Args& a, hipStream_t s);
+// dst[i] = bf16(src[i]) (round to nearest even), n a multiple of 4, 16-byte aligned src
+int to_bf16_rows(const float* src, unsigned short* dst, int64_t n, hipStream_t s);
+// Test instrumentation (mpnhip_debug_saved): rows of a bf16 [E, width] save in ORIGINAL edge order as floats, and the ReLU
+// decisions of one mask section (0 H1, 1 e', 2 HC, 3 HF, 4 M) as 1.0 / 0.0 floats [E, width] in original order
+int chain_bf16_debug_rows(const unsigned short* src, const int* perm, int64_t E, int width, float* out, hipStream_t s);
+int chain_bf16_debug_mask(const unsigned* mask, int section, const int* header, const int* perm, int64_t E, int he, int de, int hn, int dn,
+                          int hc, float* out, hipStream_t s);
+// One pair image: nsec sections [KA first-layer units | 2 x TO second-layer units] of 1 KiB (edge_chain_bf16.hip); element
+// strides make the transposed (backward) images the same kernel
+int pack_pair_bf16_general(const float* Wa, int64_t sa_n, int64_t sa_k, int a_col0, int seg_real, int seg_pad, int nseg, int H,
+                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s);
+
+// ---- backward of the bf16-operand chain (edge_chain_bf16_bwd.hip) ----
+struct EdgeChainBf16BwdArgs {
+    int E, N, agg, first_step;
+    int he, de, hn, dn, hc;   // real widths
+    int plain_barriers;       // 1: __syncthreads() at the chunk ends (A-B switch)
+    const int* header;
+    const int* srow;
+    const int* perm;
+    const int* seg_ptr;
+    const float* dAGG;        // [N, 2 dn] gradient of the aggregated messages [flow_in | flow_out]
+    const unsigned* mask;     // ReLU decisions written by the forward kernel's SAVE variant of this step
+    const int* ARG;           // [N, 2 dn] arg max (max aggregation) or nullptr
+    const float* dlog;        // [E] gradient of this step's logits, ORIGINAL edge order
+    const float* dE_in;       // [E, de] gradient w.r.t. e_s arriving from the later step
+    unsigned short* dZM;      // outputs: bf16 rows [E, dn]
+    unsigned short* dZF;      // [E, hn]
+    unsigned short* dZc;      // [E, hc]
+    unsigned short* dZ2;      // [E, de]  dZ of the edge MLP's last layer
+    unsigned short* dZ1;      // [E, he]
+    float* dE0;               // [E, de] running gradient of the re-attached initial edge features (first step: += here)
+    float* dEprev;            // [E, de] out: gradient w.r.t. e_{s-1} (later steps)
+    const void* img_edge;     // backward pair images (pack_chain_bf16_bwd)
+    const void* img_cls;
+    const void* img_flow[2];
+    const float* wc2;         // [hc] (the model's tensor)
+};
+size_t chain_bf16_bwd_image_bytes(int he, int de, int hn, int dn, int hc, size_t* off_cls, size_t* off_flow0, size_t* off_flow1);
+// w_edge0 [he][ld_edge0] with the e_{s-1} columns starting at col_e; w_edge1 [de][he]; w_cls0 [hc][de]; w_flow0[q] [hn][ld_flow0], e'
+// columns from col0_flow; w_flow1[q] [dn][hn]
+int pack_chain_bf16_bwd(const float* w_edge0, int ld_edge0, int col_e, const float* w_edge1, const float* w_cls0,
+                        const float* const w_flow0[2], int ld_flow0, int col0_flow, const float* const w_flow1[2],
+                        int he, int de, int hn, int dn, int hc, void* image, hipStream_t s);
+int launch_edge_chain_bf16_bwd(const EdgeChainBf16BwdArgs& a, hipStream_t s);
+// edges per block / waves per block of the launch for these widths (forward and backward kernels share the mapping)
+void chain_bf16_geometry(int he, int de, int hn, int dn, int hc, int* epb, int* nw);
 
 }  // namespace mpnhip

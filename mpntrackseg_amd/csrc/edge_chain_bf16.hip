@@ -26,149 +26,20 @@
 // order).  A chunk = the sections of two hidden tiles, contiguous in the image, double buffered, one barrier per chunk.
 #include "common.h"
 #include "edge_chain.h"
-#include <type_traits>
+#include "edge_chain_bf16_common.h"
 
 namespace mpnhip {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-namespace {
-
-constexpr int bmax(int a, int b) { return a > b ? a : b; }
-constexpr int bmin(int a, int b) { return a < b ? a : b; }
-
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <bool EXACT>
-__device__ __forceinline__ float4 ldrow(const float* base, unsigned off, int n, int dim) {
-    if (EXACT) return ldg4(base + (size_t)off + n);
-    const bool ok = n < dim;
-    float4 v = ldg4(base + (size_t)off + (ok ? n : 0));
-    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-    return v;
-}
-template <bool EXACT>
-__device__ __forceinline__ void strow(float* base, unsigned off, int n, int dim, float4 v, bool ok) {
-    // (plain stores: a row's 128-byte lines are completed by several wave instructions and L2 merges the pieces; non-temporal
-    // stores / loads here took the kernel from 0.63 to 0.92 ms at cfg-E)
-    if (ok && (EXACT || n < dim)) *reinterpret_cast<float4*>(base + (size_t)off + n) = v;
-}
-__device__ __forceinline__ float4 get4(const f32x16& a, int g) {
-    return make_float4(a[4 * g + 0], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-}
-__device__ __forceinline__ void relu16(f32x16& a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
-}
-__device__ __forceinline__ bf16x8 pack8(float4 u, float4 v) {
-    return bf16x8{(__bf16)u.x, (__bf16)u.y, (__bf16)u.z, (__bf16)u.w, (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-}
-// registers 8c .. 8c+7 of a finished tile = the B operand of k block c of the next layer
-__device__ __forceinline__ bf16x8 pack_regs(const f32x16& s, int c) {
-    return c == 0 ? bf16x8{(__bf16)s[0], (__bf16)s[1], (__bf16)s[2], (__bf16)s[3], (__bf16)s[4], (__bf16)s[5], (__bf16)s[6], (__bf16)s[7]}
-                  : bf16x8{(__bf16)s[8], (__bf16)s[9], (__bf16)s[10], (__bf16)s[11], (__bf16)s[12], (__bf16)s[13], (__bf16)s[14], (__bf16)s[15]};
-}
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-// A operands come out of the LDS-DMA target by inline assembly (edge_chain.hip, lds_read3: a compiler-visible read of that
-// object is preceded by s_waitcnt vmcnt(0), which would drain the next chunk's DMA and the gathers in flight); the waits are
-// placed by hand (a wave's LDS operations complete in order).
-template <int OFF>
-__device__ __forceinline__ void lds_read(unsigned base, bf16x8& a) {
-    // (the unit's offset rides in the instruction: as register values the ~50 distinct addresses of a chunk stay live across
-    // the whole kernel and spill)
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(base), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(bf16x8& a) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// NU KiB of an image -> LDS by LDS-DMA: unit 8 q + wave is moved by wave `wave` (one 1 KiB wave instruction each)
-template <int NU, int NW = 8>
-__device__ __forceinline__ void chunk_fetch(const char* src, char* buf, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < (NU + NW - 1) / NW; ++q) {
-        if (NW * q + wave < NU)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(NW * q + wave) * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(buf + (NW * q + wave) * 1024), 16, 0, 0);
-    }
-}
-
-// Barrier at the end of a weight chunk WITHOUT draining the gathers in flight: __syncthreads() carries a fence, i.e.
-// s_waitcnt vmcnt(0), which also waits for the next tile's row gathers issued a moment ago -- once per chunk, the whole gather
-// latency exposed (ablation at cfg-E: 151 of the launch's 592 us).  What the barrier needs is the NEXT chunk's LDS-DMA (issued at
-// the top of this chunk, pinned there by a compiler barrier) and nothing younger: vmcnt(N) with N = the loads issued after it,
-// which the loop knows exactly (N row gathers of the next tile).  Other waves' DMA pieces are covered by their own waits.
-// lgkmcnt(0) rides along (free here): a wave must not cross the barrier with ds_reads of the current buffer outstanding while
-// another wave's DMA of the chunk after next overwrites it.  `plain` (EdgeChainBf16Args::plain_barriers, MPNHIP_CHAIN_BF16_PLAIN_BARRIERS=1):
-// the A-B fallback to __syncthreads() -- a test compares the two bit for bit (tests/test_gpu_parity.py).
-template <int N>
-__device__ __forceinline__ void chunk_barrier(bool plain) {
-    if (plain) __syncthreads();
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void pin_order() { asm volatile("" ::: "memory"); }
-
-constexpr int DEPTH = 4;   // A operands in flight per wave
-
-// NU units from LDS address wa + OFF0 (+ 1 KiB per unit), DEPTH reads in flight; use(u, a) consumes unit u's A operand
-template <int OFF0, int NU, class USE>
-__device__ __forceinline__ void stream_units(unsigned wa, USE&& use) {
-    bf16x8 a[DEPTH];
-    static_for<0, (DEPTH - 1 < NU ? DEPTH - 1 : NU)>([&](auto U) { lds_read<OFF0 + U.value * 1024>(wa, a[U.value]); });
-    static_for<0, NU>([&](auto U) {
-        constexpr int u = U.value;
-        if constexpr (u + DEPTH - 1 < NU) {
-            lds_read<OFF0 + (u + DEPTH - 1) * 1024>(wa, a[(u + DEPTH - 1) % DEPTH]);
-            lds_wait<DEPTH - 1>(a[u % DEPTH]);
-        } else {
-            lds_wait<0>(a[u % DEPTH]);
-        }
-        use(U, a[u % DEPTH]);
-    });
-}
-
-// One hidden tile: KA first-layer units against the k blocks xin[0 .. KA) into `acc`; ReLU; then 2 x TO second-layer units:
-// k block c of the finished tile (rounded to bf16) into out[o].  wa = LDS address of the chunk buffer (+ lane * 16), OFF0 = the
-// section's offset in it.
-template <int OFF0, int KA, int TO>
-__device__ __forceinline__ void hidden_tile(unsigned wa, const bf16x8* xin, f32x16& acc, f32x16* out) {
-    bf16x8 hb[2];
-    stream_units<OFF0, KA + 2 * TO>(wa, [&](auto U, const bf16x8& a) {
-        constexpr int u = U.value;
-        if constexpr (u < KA) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[u], acc, 0, 0, 0);
-        } else {
-            if constexpr (u == KA) {
-                relu16(acc);
-                hb[0] = pack_regs(acc, 0);
-                hb[1] = pack_regs(acc, 1);
-            }
-            constexpr int q = u - KA;
-            out[q % TO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[q / TO], out[q % TO], 0, 0, 0);
-        }
-    });
-}
-
-}  // namespace
 
 // T1 = ceil(he/32), T2 = ceil(de/32), TF = ceil(hn/32), TD = ceil(dn/32), TC = ceil(hc/32); EF = 1: first-layer input e,
 // 2: [e0 | e] (each half padded to 32 T2 columns in the image).
 // NW waves per block (8: 256 edges, one block per CU; 4: 128 edges, two independent blocks per CU whose serial phases -- the
 // first-layer input rows at the start, the aggregation at the end -- run under each other's MFMA phases, for twice the weight
 // stream), CTI hidden tiles per weight chunk.
-template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2>
+// SAVE (training): the hidden activations H1 / HC / HF and a bf16 copy of e' are written row-major as bf16 [E, width] (every consumer
+// -- the weight-gradient products -- rounds them to bf16 anyway: exact for this mode), and every ReLU decision (H1, e', HC, HF, M)
+// as one bit in a lane-private layout the backward chain kernel (edge_chain_bf16_bwd.hip) reads back with the same (block, wave,
+// lane) -> edge mapping: word w of wave tile wt at save_mask[(wt * NWORDS + w) * 64 + lane] (chain_bf16_mask_words()).
+template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2, bool SAVE = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kernel(EdgeChainBf16Args A) {
     constexpr int EPB = 32 * NW;           // edges per block
     constexpr int DE = 32 * T2, DN = 32 * TD, HC = 32 * TC;
@@ -228,6 +99,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     const unsigned pro = (unsigned)row * (unsigned)A.pw;
     const unsigned pco = (unsigned)col * (unsigned)A.pw + (unsigned)he;
     const unsigned pfo = pco + (unsigned)(he + (grp == 1 ? hn : 0));
+    // training saves: mask words of this wave tile (sections H1 | e' | HC | HF | M, two tiles per word)
+    constexpr int WB_E = (T1 + 1) / 2, WB_C = WB_E + (T2 + 1) / 2, WB_F = WB_C + (TC + 1) / 2, WB_M = WB_F + (TF + 1) / 2;
+    constexpr int NWORDS = WB_M + (TD + 1) / 2;
+    unsigned mw = 0;
+    const unsigned ones = 0x00010001u;
+    unsigned* const mask_wt = SAVE ? A.save_mask + ((size_t)(blockIdx.x * NW + wave) * NWORDS) * 64 + lane : nullptr;
+    auto mask_put = [&](int wbase, int t, int T, unsigned bits) {
+        mw = (t & 1) ? (mw | (bits << 8)) : bits;
+        if ((t & 1) || t + 1 == T) mask_wt[(size_t)(wbase + (t >> 1)) * 64] = mw;
+    };
+    auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
+        // four 8-byte pieces of the edge's bf16 row: features 32 t + 8 g + 4 lh + (0..3)
+        if (!edge_ok) return;
+        const u32x4 a = __builtin_bit_cast(u32x4, h0), b = __builtin_bit_cast(u32x4, h1);
+        unsigned short* q = base + (size_t)edge * width + 32 * t + 4 * lh;
+        const int f = 32 * t + 4 * lh;
+        if (EXACT || f < width) *reinterpret_cast<uint2*>(q) = make_uint2(a[0], a[1]);
+        if (EXACT || f + 8 < width) *reinterpret_cast<uint2*>(q + 8) = make_uint2(a[2], a[3]);
+        if (EXACT || f + 16 < width) *reinterpret_cast<uint2*>(q + 16) = make_uint2(b[0], b[1]);
+        if (EXACT || f + 24 < width) *reinterpret_cast<uint2*>(q + 24) = make_uint2(b[2], b[3]);
+    };
     // ---- first-layer input: this lane's edge row(s), k = 16 kb + 4h + (0..3), 16 kb + 8 + 4h + (0..3) per k block ------
     bf16x8 X[KB1];
 #pragma unroll
@@ -293,8 +185,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }   // (acc is formed before the DMA goes out)
                 if (t + 1 < T1) cin_issue(t + 1);
                 else if (flow) pf_issue(0);
-                if (tt == 0) hidden_tile<0, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en);
-                else hidden_tile<SEC1 * 1024, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en);
+                auto fin = [&](const bf16x8& h0, const bf16x8& h1) {
+                    if constexpr (SAVE) {
+                        save_tile(A.save_h1, he, t, h0, h1);
+                        mask_put(0, t, T1, tile_mask_bits(h0, h1, ones));
+                    }
+                };
+                auto act = [](f32x16& v) { relu16(v); };
+                if (tt == 0) hidden_tile<0, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
+                else hidden_tile<SEC1 * 1024, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
             }
         }
         // (the chunk's last tile issued the 8 gathers of the tile after it -- except the very last one: 4 or none, drain)
@@ -318,6 +217,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             for (int g = 0; g < 4; ++g) strow<EXACT>(A.e_new, eo, 32 * o + 8 * g + 4 * lh, de, get4(en[o], g), edge_ok);
             eb[2 * o] = pack_regs(en[o], 0);
             eb[2 * o + 1] = pack_regs(en[o], 1);
+            if constexpr (SAVE) {
+                save_tile(A.save_eb, de, o, eb[2 * o], eb[2 * o + 1]);
+                mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
+            }
         }
     }
     // ---- phase 3: classifier (its image is in the current buffer) -------------------------------------------------------
@@ -341,6 +244,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if (q == 0) cls_tile(std::integral_constant<int, 0>{});
             else cls_tile(std::integral_constant<int, (TC > 1 ? 1 : 0)>{});
             static_assert(TC <= 2, "classifier hidden width up to 64");
+            if constexpr (SAVE) {
+                relu16(acc);
+                const bf16x8 h0 = pack_regs(acc, 0), h1 = pack_regs(acc, 1);
+                save_tile(A.save_hc, hc, q, h0, h1);
+                mask_put(WB_C, q, TC, tile_mask_bits(h0, h1, ones));
+            }
             // layer 1 (out dim 1): the same operand rounding, fp32 accumulation over this lane's 16 features
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -383,13 +292,38 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = pf[g].x; acc[4 * g + 1] = pf[g].y; acc[4 * g + 2] = pf[g].z; acc[4 * g + 3] = pf[g].w; }
                 if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }
                 if (t + 1 < TF) pf_issue(t + 1);
-                if (tt == 0) hidden_tile<0, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm);
-                else hidden_tile<SECF * 1024, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm);
+                auto fin = [&](const bf16x8& h0, const bf16x8& h1) {
+                    if constexpr (SAVE) {
+                        save_tile(A.save_hf, hn, t, h0, h1);
+                        mask_put(WB_F, t, TF, tile_mask_bits(h0, h1, ones));
+                    }
+                };
+                auto act = [](f32x16& v) { relu16(v); };
+                if (tt == 0) hidden_tile<0, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
+                else hidden_tile<SECF * 1024, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
             }
         }
         if (ch + 1 < NCHF) {
             chunk_barrier<PF_LOADS>(A.plain_barriers != 0);   // (the Pf gathers of the next tile stay in flight)
             ++c;
+        }
+    }
+    if constexpr (SAVE) {
+        // ReLU decisions of the messages (the backward of node_agg_fn needs nothing else of them for sum / mean)
+#pragma unroll
+        for (int o = 0; o < TD; ++o) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *reinterpret_cast<const float4*>(sbias + DE + 2 * HC + 32 * o + 8 * g + 4 * lh);
+                const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g + i;
+                    bits |= (mm[o][r] + bv[i] > 0.f) ? (1u << ((r >> 1) + 16 * (r & 1))) : 0u;
+                }
+            }
+            mask_put(WB_M, o, TD, bits);
         }
     }
     if (!A.agg_out) {
@@ -518,8 +452,8 @@ __global__ __launch_bounds__(64) void k_agg_fixup(const int* __restrict__ header
 // padded input: nseg segments of seg_real columns, each padded to seg_pad), then 2 x TO units of the second layer: k block
 // (2 t + c) of its input, output tile o, at index c * TO + o.
 struct PairPack {
-    const float* Wa; int lda, a_col0, seg_real, seg_pad, nseg, H;   // first layer: W[n][a_col0 + seg * seg_real + k], n < H
-    const float* Wb; int ldb, O;                                   // second layer: W[o][k], o < O, k < H
+    const float* Wa; int64_t sa_n, sa_k; int a_col0, seg_real, seg_pad, nseg, H;   // first layer: Wa[n sa_n + (a_col0 + seg seg_real + k) sa_k], n < H
+    const float* Wb; int64_t sb_o, sb_k; int O;                                    // second layer: Wb[o sb_o + k sb_k], o < O, k < H
     int KA, TO;
     __bf16* dst;
 };
@@ -534,15 +468,26 @@ __global__ __launch_bounds__(64) void k_pack_pair_bf16(PairPack p) {
         float x = 0.f;
         if (r < p.KA) {
             const int kp = 16 * r + kk, sg = kp / p.seg_pad, k = kp % p.seg_pad, n = 32 * t + m;
-            if (n < p.H && sg < p.nseg && k < p.seg_real) x = p.Wa[(int64_t)n * p.lda + p.a_col0 + sg * p.seg_real + k];
+            if (n < p.H && sg < p.nseg && k < p.seg_real) x = p.Wa[(int64_t)n * p.sa_n + (int64_t)(p.a_col0 + sg * p.seg_real + k) * p.sa_k];
         } else {
             const int q = r - p.KA, cblk = q / p.TO, o = q % p.TO;
             const int k = 32 * t + 16 * cblk + kk, n = 32 * o + m;
-            if (n < p.O && k < p.H) x = p.Wb[(int64_t)n * p.ldb + k];
+            if (n < p.O && k < p.H) x = p.Wb[(int64_t)n * p.sb_o + (int64_t)k * p.sb_k];
         }
         v[i] = (__bf16)x;
     }
     *reinterpret_cast<bf16x8*>(p.dst + ((int64_t)blockIdx.x * 64 + lane) * 8) = v;
+}
+
+int pack_pair_bf16_general(const float* Wa, int64_t sa_n, int64_t sa_k, int a_col0, int seg_real, int seg_pad, int nseg, int H,
+                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s) {
+    PairPack p = {};
+    p.Wa = Wa; p.sa_n = sa_n; p.sa_k = sa_k; p.a_col0 = a_col0; p.seg_real = seg_real; p.seg_pad = seg_pad > 0 ? seg_pad : 32; p.nseg = nseg; p.H = H;
+    p.Wb = Wb; p.sb_o = sb_o; p.sb_k = sb_k; p.O = O; p.KA = KA; p.TO = TO; p.dst = static_cast<__bf16*>(dst);
+    if (nsec * (KA + 2 * TO) <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_pack_pair_bf16, dim3(nsec * (KA + 2 * TO)), dim3(64), 0, s, p);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
 }
 
 static int chain_bf16_variant(int he, int de, int hn, int dn, int hc) {
@@ -576,21 +521,11 @@ int pack_chain_bf16(const float* w_edge0, int ld_edge0, int col0_edge, int ef, c
     size_t oc, of0, of1;
     chain_bf16_image_bytes(he, de, hn, dn, hc, ef, &oc, &of0, &of1);
     char* base = static_cast<char*>(image);
-    PairPack p = {};
-    p.Wa = w_edge0; p.lda = ld_edge0; p.a_col0 = col0_edge; p.seg_real = de; p.seg_pad = 32 * T2; p.nseg = ef; p.H = he;
-    p.Wb = w_edge1; p.ldb = he; p.O = de; p.KA = 2 * T2 * ef; p.TO = T2; p.dst = reinterpret_cast<__bf16*>(base);
-    hipLaunchKernelGGL(k_pack_pair_bf16, dim3(T1 * (p.KA + 2 * p.TO)), dim3(64), 0, s, p);
-    p = {};
-    p.Wa = w_cls0; p.lda = de; p.a_col0 = 0; p.seg_real = de; p.seg_pad = 32 * T2; p.nseg = 1; p.H = hc;
-    p.Wb = nullptr; p.ldb = 0; p.O = 0; p.KA = 2 * T2; p.TO = 0; p.dst = reinterpret_cast<__bf16*>(base + oc);
-    hipLaunchKernelGGL(k_pack_pair_bf16, dim3(TC * p.KA), dim3(64), 0, s, p);
-    for (int q = 0; q < 2; ++q) {
-        p = {};
-        p.Wa = w_flow0[q]; p.lda = ld_flow0; p.a_col0 = col0_flow; p.seg_real = de; p.seg_pad = 32 * T2; p.nseg = 1; p.H = hn;
-        p.Wb = w_flow1[q]; p.ldb = hn; p.O = dn; p.KA = 2 * T2; p.TO = TD; p.dst = reinterpret_cast<__bf16*>(base + (q == 0 ? of0 : of1));
-        hipLaunchKernelGGL(k_pack_pair_bf16, dim3(TF * (p.KA + 2 * p.TO)), dim3(64), 0, s, p);
-    }
-    MPN_LAUNCH_CHECK();
+    MPN_TRY(pack_pair_bf16_general(w_edge0, ld_edge0, 1, col0_edge, de, 32 * T2, ef, he, w_edge1, he, 1, de, 2 * T2 * ef, T2, T1, base, s));
+    MPN_TRY(pack_pair_bf16_general(w_cls0, de, 1, 0, de, 32 * T2, 1, hc, nullptr, 0, 0, 0, 2 * T2, 0, TC, base + oc, s));
+    for (int q = 0; q < 2; ++q)
+        MPN_TRY(pack_pair_bf16_general(w_flow0[q], ld_flow0, 1, col0_flow, de, 32 * T2, 1, hn, w_flow1[q], hn, 1, dn, 2 * T2, TD, TF,
+                                       base + (q == 0 ? of0 : of1), s));
     return MPNHIP_OK;
 }
 
@@ -603,33 +538,117 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
         return MPNHIP_ERR_UNSUPPORTED;
     }
     // 256-d: 4-wave blocks, two per CU (cfg-E: 643 -> 581 us per launch; A-B switch MPNHIP_CHAIN_BF16_NW=8 for one 8-wave block)
-    static const int nw_env = [] { const char* e = getenv("MPNHIP_CHAIN_BF16_NW"); return e ? atoi(e) : 0; }();
     const int variant = chain_bf16_variant(a.he, a.de, a.hn, a.dn, a.hc);
-    const bool four = variant == 256 && nw_env != 8;
-    const int epb = four ? 128 : 256;
+    int epb, nwv;
+    chain_bf16_geometry(a.he, a.de, a.hn, a.dn, a.hc, &epb, &nwv);
+    const bool four = nwv == 4;
     const unsigned blocks = (unsigned)((a.E + epb - 1) / epb + 3);
     count_path(PC_CHAIN_FWD_BF16);
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0;
+    const bool save = a.save_mask != nullptr;
+    if (save && !(a.save_h1 && a.save_hc && a.save_hf && a.save_eb)) { set_error("edge_chain_bf16: incomplete save buffers"); return MPNHIP_ERR_ARG; }
+#define MPN_CB16(SV, ...) do { if (SV) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<__VA_ARGS__, true>), dim3(blocks), dim3(four ? 256 : 512), s, a); \
+                              else MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<__VA_ARGS__, false>), dim3(blocks), dim3(four ? 256 : 512), s, a); } while (0)
     switch (variant) {
         case 256:
             // (widths that are multiples of 32 only: the masked form of this variant does not fit the register budget)
-            if (four) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1>), dim3(blocks), dim3(256), s, a);
-            else MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true>), dim3(blocks), dim3(512), s, a);
+            if (four) MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 4, 1);
+            else MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 8, 2);
             break;
         case 128:
-            if (exact) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<10, 2, 7, 4, 1, 2, true>), dim3(blocks), dim3(512), s, a);
-            else MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<10, 2, 7, 4, 1, 2, false>), dim3(blocks), dim3(512), s, a);
+            if (exact) MPN_CB16(save, 10, 2, 7, 4, 1, 2, true, 8, 2);
+            else MPN_CB16(save, 10, 2, 7, 4, 1, 2, false, 8, 2);
             break;
-        case 64: MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<5, 1, 4, 2, 1, 2, false>), dim3(blocks), dim3(512), s, a); break;
-        case 32: MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<3, 1, 2, 1, 1, 2, false>), dim3(blocks), dim3(512), s, a); break;
+        case 64: MPN_CB16(save, 5, 1, 4, 2, 1, 2, false, 8, 2); break;
+        case 32: MPN_CB16(save, 3, 1, 2, 1, 1, 2, false, 8, 2); break;
         default: set_error("edge_chain_bf16: unsupported widths"); return MPNHIP_ERR_UNSUPPORTED;
     }
+#undef MPN_CB16
     MPN_LAUNCH_CHECK();
     if (a.agg_out) {
         hipLaunchKernelGGL(k_agg_fixup, dim3(blocks * (four ? 4 : 8)), dim3(64), 0, s, a.header, a.seg_ptr, a.start_row, a.piece, a.agg_out,
                            a.N, a.dn, (a.dn + 31) / 32 * 32, a.agg, four ? 4 : 8);
         MPN_LAUNCH_CHECK();
     }
+    return MPNHIP_OK;
+}
+
+void chain_bf16_geometry(int he, int de, int hn, int dn, int hc, int* epb, int* nw) {
+    static const int nw_env = [] { const char* e = getenv("MPNHIP_CHAIN_BF16_NW"); return e ? atoi(e) : 0; }();
+    const bool four = chain_bf16_variant(he, de, hn, dn, hc) == 256 && nw_env != 8;
+    *epb = four ? 128 : 256;
+    *nw = four ? 4 : 8;
+}
+
+__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<uint2*>(dst + 4 * i) = __builtin_bit_cast(uint2, o);
+}
+int to_bf16_rows(const float* src, unsigned short* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(n % 4 == 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0, "to_bf16_rows: alignment");
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, src, dst, n / 4);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_bf16_debug_rows(const unsigned short* __restrict__ src, const int* __restrict__ perm, int64_t E, int width,
+                                                       float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E * width) return;
+    const int64_t r = i / width;
+    const int c = (int)(i - r * width);
+    out[(int64_t)perm[r] * width + c] = __uint_as_float((unsigned)src[i] << 16);
+}
+int chain_bf16_debug_rows(const unsigned short* src, const int* perm, int64_t E, int width, float* out, hipStream_t s) {
+    if (E * width <= 0) return MPNHIP_OK;
+    hipLaunchKernelGGL(k_bf16_debug_rows, dim3((unsigned)((E * width + 255) / 256)), dim3(256), 0, s, src, perm, E, width, out);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+// one thread per (wave tile, lane): the lane's decisions of one section, 16 per 32-feature tile, to out[perm[edge]][feature]
+__global__ __launch_bounds__(64) void k_bf16_debug_mask(const unsigned* __restrict__ mask, int wbase, int nwords, int ntiles, int width, int flow_section,
+                                                      const int* __restrict__ header, const int* __restrict__ perm, int E, int epb, int nw,
+                                                      float* __restrict__ out) {
+    const int wt = blockIdx.x, blk = wt / nw, wave = wt - blk * nw, lane = threadIdx.x;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int e_out = header[1], e_in = header[2];
+    const int nb0 = (e_out + epb - 1) / epb, nb1 = (e_in + epb - 1) / epb;
+    int beg, end, bl = blk;
+    if (bl < nb0) { beg = 0; end = e_out; }
+    else if (bl < nb0 + nb1) { bl -= nb0; beg = e_out; end = e_out + e_in; }
+    else { bl -= nb0 + nb1; beg = e_out + e_in; end = E; if (flow_section) return; }   // (self loops: no flow MLPs, words never written)
+    const int edge = beg + bl * epb + wave * 32 + lj;
+    if (edge >= end) return;
+    float* o = out + (int64_t)perm[edge] * width;
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned w = mask[((size_t)wt * nwords + wbase + (t >> 1)) * 64 + lane];
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (f < width) o[f] = (w >> chain_bf16_mask_bit(t & 1, r)) & 1u ? 1.f : 0.f;
+        }
+    }
+}
+int chain_bf16_debug_mask(const unsigned* mask, int section, const int* header, const int* perm, int64_t E, int he, int de, int hn, int dn,
+                          int hc, float* out, hipStream_t s) {
+    if (E <= 0) return MPNHIP_OK;
+    const int widths[5] = {he, de, hc, hn, dn};
+    MPN_CHECK_ARG(section >= 0 && section < 5, "chain_bf16_debug_mask: section %d", section);
+    int wbase = 0;
+    for (int i = 0; i < section; ++i) wbase += ((widths[i] + 31) / 32 + 1) / 2;
+    int epb, nw;
+    chain_bf16_geometry(he, de, hn, dn, hc, &epb, &nw);
+    const unsigned blocks = (unsigned)((E + epb - 1) / epb + 3);
+    // (self-loop edges take no part in the flow MLPs: their HF / M words are never written -- zero the output first)
+    MPN_HIP(hipMemsetAsync(out, 0, (size_t)E * widths[section] * sizeof(float), s));
+    hipLaunchKernelGGL(k_bf16_debug_mask, dim3(blocks * nw), dim3(64), 0, s, mask, wbase, chain_bf16_mask_words(he, de, hn, dn, hc),
+                       (widths[section] + 31) / 32, widths[section], section >= 3 ? 1 : 0, header, perm, (int)E, epb, nw, out);
+    MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
 

@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback", "edge_chain_bwd_bf16"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -353,7 +353,7 @@ struct StepIO {
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
 static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, const float* Wnode, const float* bnode,
                     const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s, const ChainWeights* cw = nullptr,
-                    bool save_acts = false, const ChainBf16* cb = nullptr) {
+                    bool save_acts = false, const ChainBf16* cb = nullptr, unsigned short* save_eb = nullptr) {
     const int64_t N = g.N, E = g.E;
     const int he = d.he, hn = d.hn;
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
@@ -378,7 +378,9 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     }
     const bool chain = cw && cw->ok && E > 0 && io.logits && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
     bool agg_done = false;   // the chain kernel aggregated the messages itself
-    const bool chain_bf16 = !chain && cb && cb->ok && !save_acts && E > 0 && io.logits && io.eb && !io.e_idx && !io.e_new_idx && !io.e_new_read_idx;
+    // (training: only with the bf16 save buffers of FwdPlan::b16 -- save_eb is given exactly then)
+    const bool chain_bf16 = !chain && cb && cb->ok && (!save_acts || save_eb) && E > 0 && io.logits && io.eb && !io.e_idx && !io.e_new_idx &&
+                            !io.e_new_read_idx;
     if (chain_bf16) {
         // (2)-(4) fused, bf16 operands / fp32 accumulation (edge_chain_bf16.hip)
         EdgeChainBf16Args a = {};
@@ -391,7 +393,15 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         a.bf2_out = m.flow_out.bias[1]; a.bf2_in = m.flow_in.bias[1];
         a.e_new = io.e_new; a.msg = b.M; a.logits = io.logits;
         // the aggregation of the messages inside the kernel (they never reach HBM); MPNHIP_NO_AGG_FUSION=1: k_aggregate as before
-        agg_done = cb->piece && !io.fuse_node && !getenv("MPNHIP_NO_AGG_FUSION");
+        // (training with max keeps the separate kernel: it records the arg max the backward needs)
+        agg_done = cb->piece && !io.fuse_node && !save_arg && !getenv("MPNHIP_NO_AGG_FUSION");
+        if (save_acts) {
+            a.save_h1 = reinterpret_cast<unsigned short*>(b.HE[0]);
+            a.save_hc = reinterpret_cast<unsigned short*>(b.HC[0]);
+            a.save_hf = reinterpret_cast<unsigned short*>(b.HF[0]);
+            a.save_eb = save_eb;
+            a.save_mask = reinterpret_cast<unsigned*>(b.MK);
+        }
         if (agg_done) {
             a.seg_ptr = g.seg_ptr; a.agg_out = b.AGG; a.piece = cb->piece; a.start_row = cb->start_row; a.agg = m.agg;
             MPN_HIP(hipMemsetAsync(b.AGG, 0, (size_t)N * 2 * d.dn * sizeof(float), s));   // (empty segments)
@@ -705,6 +715,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     }
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
+    if (p.b16 && es) MPN_TRY(to_bf16_rows(e0, p.eb_hist, (int64_t)es, s));   // the encoder output as the step-0 slot of the bf16 mirror
     const bool hoist = d.nf == 2 && d.L > 1;
     // few nodes at the reference's width: P0 and the first step's projections by one small kernel (decided with fuse_node below)
     const bool proj_small = hoist && d.dn == 32 && N > 0 && N <= 4096 && d.kx == 2 * d.dn && m.precision != MPNHIP_PREC_BF16 &&
@@ -792,7 +803,8 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.p_ready = (fuse_node && step > 0) || (proj_small && step == 0) ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
-        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb));
+        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb,
+                         p.b16 ? p.eb_hist + es * cur : nullptr));
         prev = cur;
     }
     if (d.L == 0 && E > 0) {
@@ -978,6 +990,15 @@ extern "C" int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_b
     if (rows_out) *rows_out = rows;
     if (width_out) *width_out = width;
     if (!out || rows * width == 0) return MPNHIP_OK;
+    if (p.b16 && step_ok && E > 0) {
+        // bf16-operand training on the fused kernels: the hidden activations are bf16 rows (returned as floats), and for sum / mean
+        // the messages themselves are never stored -- their ReLU decisions are (returned as 1.0 / 0.0: what a test reads them for)
+        if (what == MPNHIP_SAVED_EDGE_HIDDEN || what == MPNHIP_SAVED_CLS_HIDDEN || what == MPNHIP_SAVED_FLOW_HIDDEN)
+            return chain_bf16_debug_rows(reinterpret_cast<const unsigned short*>(src), g.perm, E, width, out, s);
+        if (what == MPNHIP_SAVED_MSG && m.agg != MPNHIP_AGG_MAX)
+            return chain_bf16_debug_mask(reinterpret_cast<const unsigned*>(b.MK), 4, g.header, g.perm, E, d.he, d.de, d.hn, d.dn,
+                                         m.classifier.out_dims[0], out, s);
+    }
     if (what == MPNHIP_SAVED_ARGMAX) {
         const int64_t n = rows * width;
         hipLaunchKernelGGL(k_arg_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const int*>(src), g.perm, out, n);

@@ -82,6 +82,21 @@ static inline int64_t sum_hidden(const mpnhip_mlp& m) {
     return s;
 }
 
+// the bf16-operand chain kernels (edge_chain_bf16.hip, edge_chain_bf16_bwd.hip) cover this model's per-edge modules
+static inline bool chain_bf16_ok(const mpnhip_model& m, const Dims& d) {
+    if (getenv("MPNHIP_NO_CHAIN") || getenv("MPNHIP_NO_CHAIN_BF16")) return false;
+    return m.precision == MPNHIP_PREC_BF16 && m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 &&
+           m.classifier.out_dims[1] == 1 && edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.ef);
+}
+// TRAINING in that mode on the fused kernels (round 4): the forward chain kernel saves the hidden activations as bf16 rows and
+// the ReLU decisions as bits, the backward is one fused chain kernel per step writing bf16 dZ blocks, the weight-gradient and
+// scatter-add kernels read bf16 sources.  One predicate for the forward's and the backward's plans (MPNHIP_NO_CHAIN_BF16_TRAIN=1:
+// round 3's unfused training path, A-B switch).
+static inline bool chain_bf16_train_ok(const mpnhip_model& m, const Dims& d) {
+    return chain_bf16_ok(m, d) && d.L >= 1 && d.he % 8 == 0 && d.de % 8 == 0 && d.hn % 8 == 0 && d.dn % 8 == 0 &&
+           m.classifier.out_dims[0] % 8 == 0 && !getenv("MPNHIP_NO_CHAIN_BF16_TRAIN");
+}
+
 // ------------------------------------------------------------------------------------ workspace
 struct Arena {
     char* base;
@@ -103,7 +118,8 @@ struct StepBufs {
     float* M;                          // [E, dn]   messages (post-ReLU), sorted order
     float* AGG;                        // [N, 2dn]  [flow_in | flow_out]
     int* ARG;                          // [N, 2dn]  argmax (max aggregation, training only)
-    int* MK;                           // ReLU masks of the fused chain kernels as bits (edge_chain.h: chain_mask_ints)
+    int* MK;                           // ReLU masks of the fused chain kernels as bits (edge_chain.h: chain_mask_ints / chain_bf16_mask_ints)
+    // (FwdPlan::b16 -- bf16-operand training on the fused kernels: HE[0] / HC[0] / HF[0] hold bf16 [E, width] rows, not floats)
 };
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
@@ -147,21 +163,26 @@ struct FwdPlan {
     size_t step_stride_bytes;  // 0 when the step buffers are reused (inference)
     float* splitk;             // scratch of the split-K form of the node encoder's layers (few rows, long K), or nullptr
     size_t splitk_floats;
+    bool b16;                  // training in the bf16-operand mode on the fused kernels (chain_bf16_train_ok): bf16 saves
+    unsigned short* eb_hist;   // b16: [(L+1)][E, de] bf16 copies of e_hist (operands of the weight-gradient products)
     size_t total;
 };
 
 static inline void carve_step(Arena& a, const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, bool with_cls, bool with_arg,
-                       StepBufs* sb) {
+                       StepBufs* sb, bool b16 = false) {
     StepBufs s = {};
     s.P = a.f((size_t)N * d.pw);
-    for (int i = 0; i + 1 < m.edge.n_layers; ++i) s.HE[i] = a.f((size_t)E * m.edge.out_dims[i]);
+    // (b16: the hidden activations are kept as bf16 rows -- half the floats)
+    auto hid = [&](int64_t rows, int width) { return a.f(b16 ? ((size_t)rows * width + 1) / 2 : (size_t)rows * width); };
+    for (int i = 0; i + 1 < m.edge.n_layers; ++i) s.HE[i] = hid(E, m.edge.out_dims[i]);
     if (with_cls)
-        for (int i = 0; i + 1 < m.classifier.n_layers; ++i) s.HC[i] = a.f((size_t)E * m.classifier.out_dims[i]);
-    for (int i = 0; i + 1 < m.flow_in.n_layers; ++i) s.HF[i] = a.f((size_t)E * m.flow_in.out_dims[i]);
+        for (int i = 0; i + 1 < m.classifier.n_layers; ++i) s.HC[i] = hid(E, m.classifier.out_dims[i]);
+    for (int i = 0; i + 1 < m.flow_in.n_layers; ++i) s.HF[i] = hid(E, m.flow_in.out_dims[i]);
     s.M = a.f((size_t)E * d.dn);
     s.AGG = a.f((size_t)N * 2 * d.dn);
     s.ARG = with_arg ? a.i((size_t)N * 2 * d.dn) : nullptr;
-    s.MK = a.i(chain_mask_ints(E, d.he, d.de, d.hn, d.dn));
+    s.MK = a.i(b16 ? chain_bf16_mask_ints(E, d.he, d.de, d.hn, d.dn, m.classifier.n_layers >= 1 ? m.classifier.out_dims[0] : 1)
+                   : chain_mask_ints(E, d.he, d.de, d.hn, d.dn));
     if (sb) *sb = s;
 }
 
@@ -230,8 +251,10 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.hist_slots = save ? d.L + 1 : 3;
     p.x_hist = a.f((size_t)p.hist_slots * N * d.dn);
     p.e_hist = a.f((size_t)p.hist_slots * E * d.de);
+    p.b16 = save && cb_shapes && chain_bf16_train_ok(m, d);
+    p.eb_hist = p.b16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)p.hist_slots * E * d.de + 1) / 2)) : nullptr;
     size_t before = a.off;
-    carve_step(a, m, d, N, E, true, save && m.agg == MPNHIP_AGG_MAX, &p.step0);
+    carve_step(a, m, d, N, E, true, save && m.agg == MPNHIP_AGG_MAX, &p.step0, p.b16);
     p.step_stride_bytes = 0;
     if (save && d.L > 1) {
         p.step_stride_bytes = a.off - before;
@@ -246,7 +269,7 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
         p.splitk_floats = sk;
         p.splitk = sk ? a.f(sk) : nullptr;
     }
-    if (cb_shapes && !save) {
+    if (cb_shapes && (!save || p.b16)) {
         size_t off = 0;
         const size_t fl = chain_bf16_agg_scratch_floats(E, d.dn, &off);
         p.cb.piece = a.f(fl);
@@ -275,13 +298,6 @@ static inline bool chain_shapes_ok(const mpnhip_model& m, const Dims& d) {
     if (m.precision == MPNHIP_PREC_BF16) return false;  // the fused chain kernels compute fp32 results (FP32 / FP32_SPLIT)
     return m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 && m.classifier.out_dims[1] == 1 &&
            edge_chain_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.de, d.ef == 2 ? d.de : 0);
-}
-
-// the bf16-operand chain kernel (edge_chain_bf16.hip) covers this model's per-edge modules
-static inline bool chain_bf16_ok(const mpnhip_model& m, const Dims& d) {
-    if (getenv("MPNHIP_NO_CHAIN") || getenv("MPNHIP_NO_CHAIN_BF16")) return false;
-    return m.precision == MPNHIP_PREC_BF16 && m.edge.n_layers == 2 && m.flow_in.n_layers == 2 && m.classifier.n_layers == 2 &&
-           m.classifier.out_dims[1] == 1 && edge_chain_bf16_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0], d.ef);
 }
 
 // split (three-piece bf16) weight images and six-product MFMAs in the fused chain kernels: mpnhip_model.precision ==

@@ -67,8 +67,13 @@ __device__ inline void vmax(float& a, int* ia, const float& b, int id) {
     if (b > a) { a = b; ia[0] = id; }
 }
 
-template <int VEC>
+// B16: the source rows are bf16 (a.src points at unsigned shorts, a.lds counts them); sums stay fp32
+template <int VEC, bool B16 = false>
 __device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid);
+__device__ __forceinline__ float4 load_bf16x4(const float* base, int64_t elem) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_segment_reduce(SegArgs a) {
@@ -85,7 +90,15 @@ __global__ __launch_bounds__(256) void k_segment_reduce3(SegArgs a0, SegArgs a1,
     else seg_short_body<4>(a2, (b - b1) * 256 + threadIdx.x);
 }
 
-template <int VEC>
+// the same three reductions over bf16 source rows (the dZ blocks of the bf16-operand backward chain, edge_chain_bf16_bwd.hip)
+__global__ __launch_bounds__(256) void k_segment_reduce3_b16(SegArgs a0, SegArgs a1, SegArgs a2, int b0, int b1) {
+    const int b = blockIdx.x;
+    if (b < b0) seg_short_body<4, true>(a0, b * 256 + threadIdx.x);
+    else if (b < b1) seg_short_body<4, true>(a1, (b - b0) * 256 + threadIdx.x);
+    else seg_short_body<4, true>(a2, (b - b1) * 256 + threadIdx.x);
+}
+
+template <int VEC, bool B16>
 __device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid) {
     typedef typename Vec<VEC>::T V;
     const int nblk = a.nblk > 1 ? a.nblk : 1;
@@ -113,7 +126,10 @@ __device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid)
                     id[u] = a.list ? a.list[jj] : jj;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
+                for (int u = 0; u < 8; ++u) {
+                    if constexpr (B16 && VEC == 4) v[u] = load_bf16x4(a.src, (int64_t)id[u] * a.lds + c);
+                    else v[u] = Vec<VEC>::load(a.src + (int64_t)id[u] * a.lds + c);
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (j + u < rend) {
@@ -658,6 +674,27 @@ int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_
     for (int i = 0; i < 3; ++i)
         MPN_TRY(segment_reduce_csr2(c[i].src, c[i].lds, c[i].list, c[i].ptr, c[i].nseg, c[i].dim, c[i].out, c[i].ldo, c[i].nmod, c[i].off0,
                                     c[i].off1, stream, total_rows, c[i].runs > 1 ? c[i].runs : 1, c[i].run_stride));
+    return MPNHIP_OK;
+}
+
+// the three scatter-adds of a backward step over bf16 source rows: always the short-segment kernel, one launch
+int segment_reduce_csr2_x3_bf16(const SegReduce2 c[3], hipStream_t stream) {
+    SegArgs a[3] = {seg_args2(c[0]), seg_args2(c[1]), seg_args2(c[2])};
+    unsigned nb[3];
+    for (int i = 0; i < 3; ++i) {
+        bool v = false;
+        // (the geometry's 16-byte source alignment test is the fp32 kernels'; bf16 rows need 8 bytes per 4 columns)
+        MPN_CHECK_ARG(a[i].dim % 4 == 0 && a[i].lds % 4 == 0 && a[i].ldo % 4 == 0 && a[i].off0 % 4 == 0 && a[i].off1 % 4 == 0 &&
+                      (((uintptr_t)a[i].src) & 7) == 0 && (((uintptr_t)a[i].out) & 15) == 0, "segment_reduce (bf16 rows): alignment");
+        const float* keep = a[i].src;
+        a[i].src = reinterpret_cast<const float*>(((uintptr_t)keep) & ~(uintptr_t)15);   // (only for the geometry's alignment test)
+        nb[i] = a[i].nseg > 0 && a[i].dim > 0 ? seg_short_geometry(a[i], &v) : 0;
+        a[i].src = keep;
+    }
+    if (nb[0] + nb[1] + nb[2] == 0) return MPNHIP_OK;
+    count_path(PC_SEG_SHORT3);
+    hipLaunchKernelGGL(k_segment_reduce3_b16, dim3(nb[0] + nb[1] + nb[2]), dim3(256), 0, stream, a[0], a[1], a[2], (int)nb[0], (int)(nb[0] + nb[1]));
+    MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }
 

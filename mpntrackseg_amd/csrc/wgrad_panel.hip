@@ -95,9 +95,13 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const b
 }
 
 // One block: output tile (tile_o, tile_c) of BO = 64 TM x BC = 64 TN, row chunk `by` of job J.
-template <int TM, int TN>
+// B16: both operands are bf16 rows in memory (the dZ blocks and saved activations of the bf16-operand chain kernels,
+// edge_chain_bf16*.hip): a stage is loaded as 8-byte pieces (4 columns) and stored to LDS as it is -- one piece, no split.
+template <int TM, int TN, bool B16 = false>
 __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const int by, char* lds) {
     constexpr int BO = 64 * TM, BC = 64 * TN;
+    constexpr int ES = B16 ? 2 : 4;   // bytes per source element
+    using StageT = std::conditional_t<B16, uint2, f32x4>;
     constexpr int P = wp_pitch(BO, BC), PIECE = WP_KB * P;
     constexpr int PZ = wp_passes(BO), PH = wp_passes(BC);
     constexpr bool NEG_Z = BO <= BC;   // the sign of odd chunks goes onto the narrower operand (fewer XORs)
@@ -131,21 +135,21 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     const bool hseg2 = J.H2 && c0 + hcol >= J.csplit;
     const int64_t ldz = J.ldz, ldh = hseg2 ? J.ldh2 : J.ldh;
     // uniform bases (SGPRs) + 32-bit per-thread byte offsets: the row of pass j clamped into the stage (clamped lanes do not store)
-    const char* zbase = reinterpret_cast<const char*>(J.dZ + (int64_t)batch * J.z_bstride + o0);
-    const char* hbase = hseg2 ? reinterpret_cast<const char*>(J.H2 + (int64_t)batch * J.h2_bstride + (c0 - J.csplit))
-                              : reinterpret_cast<const char*>(J.H + (int64_t)batch * J.h_bstride + c0);
+    const char* zbase = reinterpret_cast<const char*>(J.dZ) + ((int64_t)batch * J.z_bstride + o0) * ES;
+    const char* hbase = hseg2 ? reinterpret_cast<const char*>(J.H2) + ((int64_t)batch * J.h2_bstride + (c0 - J.csplit)) * ES
+                              : reinterpret_cast<const char*>(J.H) + ((int64_t)batch * J.h_bstride + c0) * ES;
     unsigned zoff[PZ], hoff[PH];
 #pragma unroll
     for (int j = 0; j < PZ; ++j) {
         int r = zrow + rpz * j;
         r = (zact && r < WP_KB) ? r : WP_KB - 1;
-        zoff[j] = (unsigned)(((int64_t)r * ldz + (zact ? zcol : 0)) * 4);
+        zoff[j] = (unsigned)(((int64_t)r * ldz + (zact ? zcol : 0)) * ES);
     }
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
         int r = hrow + rph * j;
         r = (hact && r < WP_KB) ? r : WP_KB - 1;
-        hoff[j] = (unsigned)(((int64_t)r * ldh + hcol) * 4);   // (hcol < wc for every thread: in bounds in either segment)
+        hoff[j] = (unsigned)(((int64_t)r * ldh + hcol) * ES);   // (hcol < wc for every thread: in bounds in either segment)
     }
     char* zdst = lds + zrow * P + zcol * 2;
     char* hdst = lds + hrow * P + (BO + hcol) * 2;
@@ -164,7 +168,7 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     // two or four for the narrow ones (a <1, 1> stage is 16 rows x 128 columns = 8 KB per block: with one in flight the kernel waits out
     // the HBM latency every 16 rows -- 1.4 TB/s on the 32-d products of the reference's configuration)
     constexpr int D = TM + TN <= 2 ? 4 : (TM + TN <= 5 && TM * TN <= 4 ? 2 : 1);
-    f32x4 zreg[D][PZ], hreg[D][PH];
+    StageT zreg[D][PZ], hreg[D][PH];
 
     // full stages: rows m0 .. m0 + 15 all inside the chunk.  (Compiler-visible loads on purpose.  Inline-assembly loads into TWO
     // stage buffers with hand-counted s_waitcnt kept two whole stages in flight -- hipcc's own placement waits for every
@@ -174,12 +178,13 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     // a since-removed <2, 4> variant.  Not worth 3 %.)
 #define WP_LOAD(ZR, HR, m0)                                                                                              \
     do {                                                                                                                 \
-        const char* zb_ = zbase + (int64_t)(m0) * ldz * 4;                                                               \
-        const char* hb_ = hbase + (int64_t)(m0) * ldh * 4;                                                               \
-        _Pragma("unroll") for (int j = 0; j < PZ; ++j) ZR[j] = *reinterpret_cast<const f32x4*>(zb_ + zoff[j]);           \
-        _Pragma("unroll") for (int j = 0; j < PH; ++j) HR[j] = *reinterpret_cast<const f32x4*>(hb_ + hoff[j]);           \
+        const char* zb_ = zbase + (int64_t)(m0) * ldz * ES;                                                              \
+        const char* hb_ = hbase + (int64_t)(m0) * ldh * ES;                                                              \
+        _Pragma("unroll") for (int j = 0; j < PZ; ++j) ZR[j] = *reinterpret_cast<const StageT*>(zb_ + zoff[j]);          \
+        _Pragma("unroll") for (int j = 0; j < PH; ++j) HR[j] = *reinterpret_cast<const StageT*>(hb_ + hoff[j]);          \
     } while (0)
-    const bool one = J.pieces == 1;   // MPNHIP_PREC_BF16: operands rounded to bf16 (the first piece alone), one product per k block
+    const bool one = B16 || J.pieces == 1;   // MPNHIP_PREC_BF16: operands rounded to bf16 (the first piece alone), one product per k block
+    const unsigned sx16 = sx ? 0x80008000u : 0u;   // (the sign of two packed bf16)
     auto put = [&](char* d, float4 v, bool negate) {
         if (negate) { v.x = fneg_if(v.x, sx); v.y = fneg_if(v.y, sx); v.z = fneg_if(v.z, sx); v.w = fneg_if(v.w, sx); }
         const Pk3 s = split4(v);
@@ -196,19 +201,35 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
         for (int j = 0; j < PZ; ++j) {
             const int row = zrow + rpz * j;
             if (zact && row < WP_KB) {
-                float4 v = make_float4(zreg[B][j][0], zreg[B][j][1], zreg[B][j][2], zreg[B][j][3]);
-                if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                put(zdst + rpz * j * P, v, NEG_Z);
+                if constexpr (B16) {
+                    uint2 v = zreg[B][j];
+                    if (row >= nrows) v = make_uint2(0u, 0u);
+                    bsum.x += __uint_as_float(v.x << 16); bsum.y += __uint_as_float(v.x & 0xffff0000u);
+                    bsum.z += __uint_as_float(v.y << 16); bsum.w += __uint_as_float(v.y & 0xffff0000u);
+                    if (NEG_Z) { v.x ^= sx16; v.y ^= sx16; }
+                    *reinterpret_cast<uint2*>(zdst + rpz * j * P) = v;
+                } else {
+                    float4 v = make_float4(zreg[B][j][0], zreg[B][j][1], zreg[B][j][2], zreg[B][j][3]);
+                    if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+                    put(zdst + rpz * j * P, v, NEG_Z);
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < PH; ++j) {
             const int row = hrow + rph * j;
             if (hact && row < WP_KB) {
-                float4 v = make_float4(hreg[B][j][0], hreg[B][j][1], hreg[B][j][2], hreg[B][j][3]);
-                if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                put(hdst + rph * j * P, v, !NEG_Z);
+                if constexpr (B16) {
+                    uint2 v = hreg[B][j];
+                    if (row >= nrows) v = make_uint2(0u, 0u);
+                    if (!NEG_Z) { v.x ^= sx16; v.y ^= sx16; }
+                    *reinterpret_cast<uint2*>(hdst + rph * j * P) = v;
+                } else {
+                    float4 v = make_float4(hreg[B][j][0], hreg[B][j][1], hreg[B][j][2], hreg[B][j][3]);
+                    if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    put(hdst + rph * j * P, v, !NEG_Z);
+                }
             }
         }
     };
@@ -307,13 +328,13 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
             for (int j = 0; j < PZ; ++j) {
                 int r = zrow + rpz * j;
                 r = (zact && r < tail) ? r : tail - 1;
-                zreg[0][j] = *reinterpret_cast<const f32x4*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * 4);
+                zreg[0][j] = *reinterpret_cast<const StageT*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * ES);
             }
     #pragma unroll
             for (int j = 0; j < PH; ++j) {
                 int r = hrow + rph * j;
                 r = (hact && r < tail) ? r : tail - 1;
-                hreg[0][j] = *reinterpret_cast<const f32x4*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * 4);
+                hreg[0][j] = *reinterpret_cast<const StageT*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * ES);
             }
             store(B0{}, tail);
             __syncthreads();
@@ -321,8 +342,12 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
             __syncthreads();
         }
     };
-    if (one) run(products1);
-    else run(products6);
+    if constexpr (B16) {
+        run(products1);
+    } else {
+        if (one) run(products1);
+        else run(products6);
+    }
 
     // ---- the partial output tile into this chunk's slab (odd chunks negated as a whole: the slab sum subtracts them) ----
     const int kpad = tn_kpad(J.k_in);
@@ -378,7 +403,15 @@ __device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char*
     if (rlane < rl) {
         for (int r = r0 + rlane; r < r1; r += rl) {
             float zz = z[(int64_t)(zi ? zi[r] : r) * J.ldz];
-            float4 hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+            float4 hv;
+            if (J.src16) {   // H as bf16 rows (J.H points at unsigned shorts; ldh / h_bstride count them); dZ stays fp32 here
+                const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(J.H) + (int64_t)batch * J.h_bstride +
+                                                                4 * cg + (int64_t)r * J.ldh);
+                hv = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                 __uint_as_float(q.y & 0xffff0000u));
+            } else {
+                hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+            }
             if (J.pieces == 1) {   // (MPNHIP_PREC_BF16: the same operand rounding as the MFMA jobs)
                 zz = (float)(__bf16)zz;
                 hv = make_float4((float)(__bf16)hv.x, (float)(__bf16)hv.y, (float)(__bf16)hv.z, (float)(__bf16)hv.w);
@@ -437,13 +470,17 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
         for (int i = threadIdx.x; i < ROWS * n_out; i += WP_NT) {
             const int r = i / n_out, o = i - r * n_out;
             const int64_t row = r < nr ? (zi ? zi[m0 + r] : m0 + r) : 0;
-            float v = r < nr ? dZ[row * J.ldz + o] : 0.f;
+            float v = 0.f;
+            if (r < nr) v = J.src16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(J.dZ)[(int64_t)batch * J.z_bstride + row * J.ldz + o] << 16)
+                                    : dZ[row * J.ldz + o];
             zs[r * zp + o] = v;
         }
         for (int i = threadIdx.x; i < ROWS * kc; i += WP_NT) {
             const int r = i / kc, c = i - r * kc;
             const int64_t row = r < nr ? (hi ? hi[m0 + r] : m0 + r) : 0;
-            float v = c == k_in ? (r < nr ? 1.f : 0.f) : (r < nr ? H[row * J.ldh + c] : 0.f);
+            float v = c == k_in ? (r < nr ? 1.f : 0.f) : 0.f;
+            if (c != k_in && r < nr) v = J.src16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(J.H)[(int64_t)batch * J.h_bstride + row * J.ldh + c] << 16)
+                                                 : H[row * J.ldh + c];
             hs[r][c] = J.pieces == 1 ? (float)(__bf16)v : v;
         }
         __syncthreads();
@@ -488,6 +525,15 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
         case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
         case 6: wp_block_vec(J, by, wp_lds); break;
         case 7: wp_block_small(J, by, wp_lds); break;
+        // bf16 source rows (one piece: ten accumulator tiles per wave fit): the shapes of the 256-d / 128-d / narrower models
+        case 8: wp_block<5, 2, true>(J, tile, by, wp_lds); break;
+        case 9: wp_block<2, 5, true>(J, tile, by, wp_lds); break;
+        case 10: wp_block<4, 2, true>(J, tile, by, wp_lds); break;
+        case 11: wp_block<2, 4, true>(J, tile, by, wp_lds); break;
+        case 12: wp_block<1, 2, true>(J, tile, by, wp_lds); break;
+        case 13: wp_block<2, 1, true>(J, tile, by, wp_lds); break;
+        case 14: wp_block<1, 1, true>(J, tile, by, wp_lds); break;
+        case 15: wp_block<2, 2, true>(J, tile, by, wp_lds); break;
         default: wp_block<2, 2>(J, tile, by, wp_lds); break;
     }
 }
@@ -563,9 +609,21 @@ const WpVariant kVariants[6] = {{5, 1}, {1, 5}, {4, 1}, {1, 1}, {2, 4}, {2, 2}};
 bool wp_is_small(int n_out, int k_in) {   // wp_block_small's shapes
     return k_in <= 32 && (n_out <= 32 || (n_out <= 96 && k_in % 4 != 0));
 }
-void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c) {
+const WpVariant kVariants16[8] = {{5, 2}, {2, 5}, {4, 2}, {2, 4}, {1, 2}, {2, 1}, {1, 1}, {2, 2}};   // kernel cases 8 .. 15
+
+void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bool src16 = false) {
     if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
     if (wp_is_small(n_out, k_in)) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                   // wp_block_small
+    if (src16) {
+        long best = -1;
+        for (int v = 0; v < 8; ++v) {
+            const int bo = 64 * kVariants16[v].tm, bc = 64 * kVariants16[v].tn;
+            const int to = (n_out + bo - 1) / bo, tc = (k_in + bc - 1) / bc;
+            const long cost = (long)to * tc * (bo + bc) * 64 + to * tc;
+            if (best < 0 || cost < best) { best = cost; *variant = 8 + v; *tiles_o = to; *tiles_c = tc; }
+        }
+        return;
+    }
     long best = -1;
     for (int v = 0; v < 6; ++v) {
         if (v == 4) continue;   // (<2, 4>: 128 accumulator registers + a stage in flight spill; 128 x 224 takes two <2, 2> tiles)
@@ -613,6 +671,16 @@ size_t wp_lds_bytes() {
 bool wp_eligible(const WpProduct& p) {
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     if (p.rows <= 0 || p.rows >= (int64_t)1 << 31 || p.nbatch < 1 || !p.dZ || !p.H || p.n_out < 1 || p.k_in < 1) return false;
+    if (p.src16) {
+        // bf16 source rows: H (and, except for the [1 x k] form whose dZ is the fp32 logit gradient, dZ) are unsigned shorts
+        auto al8 = [](const void* q) { return (((uintptr_t)q) & 7) == 0; };
+        if (p.pieces != 1 || p.H2 || p.h_idx) return false;
+        if (p.n_out == 1 && p.k_in % 4 == 0 && p.k_in <= 64) return al8(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0;
+        if (p.dz_idx) return false;
+        if (wp_is_small(p.n_out, p.k_in)) return p.n_out * (p.k_in + 1) <= 5 * WP_NT;
+        return p.n_out % 4 == 0 && p.k_in % 4 == 0 && al8(p.dZ) && al8(p.H) && p.ldz % 4 == 0 && p.ldh % 4 == 0 && p.z_bstride % 4 == 0 &&
+               p.h_bstride % 4 == 0;
+    }
     if (p.n_out == 1 && p.k_in % 4 == 0 && p.k_in <= 64 && !p.h_idx && !p.H2 && al16(p.H) && p.ldh % 4 == 0 && p.h_bstride % 4 == 0)
         return true;   // wp_block_vec: gathered dZ allowed
     if (wp_is_small(p.n_out, p.k_in))   // wp_block_small: any alignment, gathers allowed
@@ -622,9 +690,9 @@ bool wp_eligible(const WpProduct& p) {
            (!p.H2 || (al16(p.H2) && p.ldh2 % 4 == 0 && p.h2_bstride % 4 == 0 && p.csplit % 4 == 0 && p.csplit > 0 && p.csplit < p.k_in));
 }
 
-size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched) {
+size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched, bool src16) {
     int v, to, tc, chunk, nsplit;
-    wp_choose(n_out, k_in, &v, &to, &tc);
+    wp_choose(n_out, k_in, &v, &to, &tc, src16);
     wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit);
     return ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
 }
@@ -669,7 +737,7 @@ bool wp_batch_add(const WpProduct* ps, int n) {
     size_t need = 0;
     for (int i = 0; i < n; ++i) {
         if (!wp_eligible(ps[i])) return false;
-        need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end, b->batched);
+        need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end, b->batched, ps[i].src16 != 0);
     }
     if (b->used + need > b->slab_floats) return false;
     for (int i = 0; i < n; ++i) {
@@ -677,7 +745,8 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         const bool ranged = p.row_begin || p.row_end;
         WpJob& J = b->tab.job[b->tab.njobs];
         J = WpJob{};
-        wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c);
+        wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c, p.src16 != 0);
+        J.src16 = p.src16 ? 1 : 0;
         wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
         J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
@@ -690,9 +759,9 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         J.red_block0 = b->nred;
         b->nblocks += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
         b->nred += (int)(((int64_t)p.n_out * tn_kpad(p.k_in) / 4 + 31) / 32);
-        b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged, b->batched);
+        b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged, b->batched, p.src16 != 0);
         b->flops += 2.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * p.n_out * p.k_in;
-        b->bytes += 4.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * (p.n_out + p.k_in);
+        b->bytes += (p.src16 ? 2.0 : 4.0) * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * (p.n_out + p.k_in);
         ++b->tab.njobs;
         count_path(PC_TN_PANEL);
     }

@@ -103,7 +103,7 @@ def nccl_one_rank_check(L, d, dev):
     """TrainStep(force_collectives=True) on a 1-rank RCCL group: the backward leaves its side stream un-joined
     (MPNHIP_BWD_DEFER_SIDE_JOIN), the message-passing bucket's all-reduce is enqueued on that stream through an ExternalStream with
     async_op=True, the encoder's bucket on the caller's stream, both are waited for, mpnhip_side_stream_join, / 1, guarded Adam --
-    and must give exactly the plain single-rank step: same gradients (bitwise: a 1-rank sum, / 1), same parameters after Adam."""
+    and must give the plain single-rank step: the same gradients (a 1-rank sum, / 1) and parameters after Adam, to summation noise."""
     params = synth.model_params(d, L, "sum", node_in_dim=64)
     W = synth.make_weights(params, seed=7, gain=0.6)
 
@@ -122,8 +122,14 @@ def nccl_one_rank_check(L, d, dev):
         plain(*t)
         coll(*t)
         torch.cuda.synchronize()
-        same_g = bool(torch.equal(plain.bucket.flat[:plain.bucket.n], coll.bucket.flat[:coll.bucket.n]))
-        same_p = bool(torch.equal(plain.bucket.flat_params, coll.bucket.flat_params))
+        # (not bitwise: with the deferred join the encoder's weight-gradient products stay on the caller's stream instead of riding in
+        # the tail batch -- other row chunks, another fp32 summation order)
+        gp, gc = plain.bucket.flat[:plain.bucket.n].double(), coll.bucket.flat[:coll.bucket.n].double()
+        pp, pc = plain.bucket.flat_params.double(), coll.bucket.flat_params.double()
+        dg = float((gp - gc).abs().max() / gp.abs().max().clamp(min=1e-30))
+        dp = float((pp - pc).abs().max() / pp.abs().max().clamp(min=1e-30))
+        same_g, same_p = dg < 1e-5, dp < 1e-5
+        print("NCCL1 step %d grad diff %.2e param diff %.2e" % (it, dg, dp), flush=True)
         lead = coll.ev_mp_ready.elapsed_time(coll.ev_main_done) * 1e3 if L >= 4 else float("nan")
         print("NCCL1 step %d same_grads %d same_params %d side_lead_us %.0f skipped %d" % (it, same_g, same_p, lead, coll.opt.t - coll.opt.applied_steps),
               flush=True)
