@@ -247,6 +247,13 @@ int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out,
  * what mpnhip_backward uses for a model in that precision). */
 int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, int precision, float* grad_w,
                             float* grad_b, void* workspace, size_t workspace_bytes, void* stream);
+/* The same product over operands that are ALREADY bf16 rows in memory (round 4: what the bf16-operand training path keeps -- the
+ * backward chain kernel's dZ blocks, the forward chain kernel's saved activations; mlp.py:27-28 under autograd in BASELINE.json's
+ * configs[4] arithmetic): dZ [nbatch][rows][n_out], H [nbatch][rows][k_in] as bfloat16 bit patterns, n_out and k_in multiples of 4
+ * (or a narrow shape, k_in <= 32 and n_out <= 32), fp32 accumulation; grad_w / grad_b fp32, "+=". */
+size_t mpnhip_weight_grad_bf16_rows_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch);
+int mpnhip_weight_grad_bf16_rows(const uint16_t* dZ, const uint16_t* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
+                                 float* grad_b, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The gradient of node_agg_fn (models/mpn.py:266-273; torch_scatter's scatter_add / scatter_mean / scatter_max backward), gather
  * form: grad_src[j] = grad_out[row[j]] (sum), / count[row[j]] (mean; count int32 [x_size]), or only where argmax[row[j]][d] == j

@@ -84,6 +84,8 @@ SIGNATURES = {
     "mpnhip_weight_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "mpnhip_time_weight_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _I, C.POINTER(C.c_float), _P]),
     "mpnhip_weight_grad_prec": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "mpnhip_weight_grad_bf16_rows_workspace_bytes": (_Z, [_I, _I, _L, _I]),
+    "mpnhip_weight_grad_bf16_rows": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "mpnhip_time_weight_grad_prec": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _Z, _I, C.POINTER(C.c_float), _P]),
     "mpnhip_mlp_workspace_bytes": (_Z, [C.POINTER(Mlp), _L]),
     "mpnhip_mlp_forward": (_I, [C.POINTER(Mlp), _P, _P, _L, _P, _Z, _P]),

@@ -112,17 +112,34 @@ __global__ void k_sum_blocks(const float* __restrict__ src, int64_t stride, int 
     *reinterpret_cast<float4*>(out + 4 * i) = acc;
 }
 
-// out[i] = sum_b src[b * stride + i] over bf16 blocks (n4 groups of four elements, ascending b), fp32 result
-__global__ void k_sum_blocks_bf16(const unsigned short* __restrict__ src, int64_t stride, int nb, int64_t n4, float* __restrict__ out) {
+// out[i] = sum_b src[b * stride + i] over bf16 blocks (n8 groups of eight elements, ascending b), fp32 result; up to 12 blocks'
+// 16-byte loads are in flight per lane at once (a serial chain of 8-byte loads ran at 1.9 TB/s at cfg-E)
+__global__ __launch_bounds__(256) void k_sum_blocks_bf16(const unsigned short* __restrict__ src, int64_t stride, int nb, int64_t n8,
+                                                         float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < nb; ++b) {
-        const uint2 v = *reinterpret_cast<const uint2*>(src + (int64_t)b * stride + 4 * i);
-        acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
-        acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+    if (i >= n8) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < nb; b0 += 12) {
+        uint4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int b = b0 + u < nb ? b0 + u : nb - 1;   // clamped, unconditional loads
+            v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)b * stride + 8 * i);
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            if (b0 + u < nb) {
+                const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] += __uint_as_float(w[q] << 16);
+                    acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+                }
+            }
+        }
     }
-    *reinterpret_cast<float4*>(out + 4 * i) = acc;
+    *reinterpret_cast<float4*>(out + 8 * i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(out + 8 * i + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
 __global__ void k_bf16_to_f32(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
@@ -1182,8 +1199,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     if (hoist_e0) {
         // S = sum_s dZ1_s (the blocks are all kept for the weight gradients);  dE0 += S W1[:, e0 columns];  dW1[:, e0 columns] += S^T e0
         const int64_t n4 = E * he / 4;
-        if (use_b16) hipLaunchKernelGGL(k_sum_blocks_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
-                                        E * he, (int)L, n4, p.dZ1sum);
+        if (use_b16) hipLaunchKernelGGL(k_sum_blocks_bf16, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
+                                        E * he, (int)L, n4 / 2, p.dZ1sum);   // (he % 8 == 0: chain_bf16_train_ok)
         else hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dZed[0], E * he, (int)L, n4, p.dZ1sum);
         MPN_LAUNCH_CHECK();
         const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};

@@ -110,15 +110,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
         if ((t & 1) || t + 1 == T) mask_wt[(size_t)(wbase + (t >> 1)) * 64] = mw;
     };
     auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
-        // four 8-byte pieces of the edge's bf16 row: features 32 t + 8 g + 4 lh + (0..3)
-        if (!edge_ok) return;
-        const u32x4 a = __builtin_bit_cast(u32x4, h0), b = __builtin_bit_cast(u32x4, h1);
-        unsigned short* q = base + (size_t)edge * width + 32 * t + 4 * lh;
-        const int f = 32 * t + 4 * lh;
-        if (EXACT || f < width) *reinterpret_cast<uint2*>(q) = make_uint2(a[0], a[1]);
-        if (EXACT || f + 8 < width) *reinterpret_cast<uint2*>(q + 8) = make_uint2(a[2], a[3]);
-        if (EXACT || f + 16 < width) *reinterpret_cast<uint2*>(q + 16) = make_uint2(b[0], b[1]);
-        if (EXACT || f + 24 < width) *reinterpret_cast<uint2*>(q + 24) = make_uint2(b[2], b[3]);
+        // 32 contiguous bytes of the edge's bf16 row per lane: features 32 t + 16 lh .. + 15 (tile_rows16)
+        // (the lane exchange needs every lane: predicate the stores only)
+        uint4 lo, hi;
+        tile_rows16(h0, h1, lo, hi);
+        const int f = 32 * t + 16 * lh;
+        unsigned short* q = base + (size_t)edge * width + f;
+        if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
+        if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
     };
     // ---- first-layer input: this lane's edge row(s), k = 16 kb + 4h + (0..3), 16 kb + 8 + 4h + (0..3) per k block ------
     bf16x8 X[KB1];

@@ -28,7 +28,7 @@ namespace {
 // counted wait below must not count on them)
 template <int N>
 __device__ __forceinline__ void bwd_chunk_end(bool counted, bool wave_live) {
-    // the next chunk's LDS-DMA was issued before this chunk's tiles; behind it only the tiles' N row stores (exec-masked, but
+    // the next chunk's LDS-DMA was issued before this chunk's tiles; behind it only the tiles' N row stores (two per tile) (exec-masked, but
     // issued whenever the wave has a live lane).  vmcnt(N) therefore covers the DMA and leaves the stores in flight.
     if (counted && wave_live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
     else __syncthreads();
@@ -83,16 +83,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
     for (int i = tid; i < HC; i += 64 * NW) swc2[i] = i < hc ? A.wc2[i] : 0.f;
 
     const unsigned* const mask_wt = A.mask + ((size_t)(blockIdx.x * NW + wave) * NWORDS) * 64 + lane;
-    // a finished dZ tile as four 8-byte pieces of the edge's bf16 row (features 32 t + 8 g + 4 lh + (0..3))
+    // a finished dZ tile as 32 contiguous bytes of the edge's bf16 row per lane (features 32 t + 16 lh .. + 15; tile_rows16)
     auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
-        if (!edge_ok) return;
-        const u32x4 a = __builtin_bit_cast(u32x4, h0), b = __builtin_bit_cast(u32x4, h1);
-        unsigned short* q = base + (size_t)edge * width + 32 * t + 4 * lh;
-        const int f = 32 * t + 4 * lh;
-        if (EXACT || f < width) *reinterpret_cast<uint2*>(q) = make_uint2(a[0], a[1]);
-        if (EXACT || f + 8 < width) *reinterpret_cast<uint2*>(q + 8) = make_uint2(a[2], a[3]);
-        if (EXACT || f + 16 < width) *reinterpret_cast<uint2*>(q + 16) = make_uint2(b[0], b[1]);
-        if (EXACT || f + 24 < width) *reinterpret_cast<uint2*>(q + 24) = make_uint2(b[2], b[3]);
+        // (the lane exchange needs every lane: predicate the stores only)
+        uint4 lo, hi;
+        tile_rows16(h0, h1, lo, hi);
+        const int f = 32 * t + 16 * lh;
+        unsigned short* q = base + (size_t)edge * width + f;
+        if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
+        if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
     };
     const float dl = A.dlog[A.perm[edge]];
 
@@ -167,8 +166,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
                     else hidden_tile<SECF * 1024, KBM, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, dEa, act, fin);
                 }
             }
-            if (nt == CT) bwd_chunk_end<4 * CT>(counted, wave_live);
-            else bwd_chunk_end<4>(counted, wave_live);
+            if (nt == CT) bwd_chunk_end<2 * CT>(counted, wave_live);
+            else bwd_chunk_end<2>(counted, wave_live);
             ++c;
         }
     } else {
@@ -275,8 +274,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
             }
         }
         if (ch + 1 < NCH1) {
-            if (nt == CT) bwd_chunk_end<4 * CT>(counted, wave_live);
-            else bwd_chunk_end<4>(counted, wave_live);
+            if (nt == CT) bwd_chunk_end<2 * CT>(counted, wave_live);
+            else bwd_chunk_end<2>(counted, wave_live);
             ++c;
         }
     }

@@ -147,6 +147,21 @@ __device__ __forceinline__ void hidden_tile(unsigned wa, const bf16x8* xin, f32x
 // of four consecutive features; as bf16 that is four 8-byte pieces of the edge's row.  Row-major bf16 [E, width] is what the
 // consumers want (the weight-gradient kernel streams whole rows, the scatter-adds gather rows).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// A finished tile as two 16-byte pieces per lane: lanes (edge, 0) and (edge, 1) each hold four runs of 4 features (8 g + 4 h ..);
+// four v_permlane32_swap exchange runs between the two halves so that lane (edge, h) ends up with the 16 CONSECUTIVE features
+// 32 t + 16 h .. + 15 of the edge's row -- two dwordx4 stores to 32 contiguous bytes instead of four dwordx2 stores to 8-byte
+// pieces (store issue, not bandwidth, is what a row-per-lane epilogue pays: cdna_hip_programming.md T21)
+__device__ __forceinline__ void tile_rows16(const bf16x8& h0, const bf16x8& h1, uint4& lo, uint4& hi) {
+    const u32x4 a = __builtin_bit_cast(u32x4, h0), b = __builtin_bit_cast(u32x4, h1);
+    // swap(x, y): x keeps its lanes 0..31 and takes y's lanes 0..31 into its lanes 32..63; y takes x's lanes 32..63 into its lanes 0..31
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(a[2], b[2], false, false);
+    const auto r3 = __builtin_amdgcn_permlane32_swap(a[3], b[3], false, false);
+    lo = make_uint4(r0[0], r1[0], r0[1], r1[1]);   // h = 0: features 0..7   (run g = 0 of both halves); h = 1: 16..23 (g = 2)
+    hi = make_uint4(r2[0], r3[0], r2[1], r3[1]);   // h = 0: features 8..15  (g = 1);                     h = 1: 24..31 (g = 3)
+}
+
 // ReLU decisions of a finished tile as 16 bits: register pair i (elements 2i, 2i+1 of the tile = bf16 halves lo, hi of packed
 // register i) -> bits i and 16 + i, shifted by 8 for the odd tile of a pair: one 32-bit word per two tiles
 // (bit of element r of tile parity p: 8 p + (r >> 1) + 16 (r & 1); chain_bf16_mask_bit).  min(x, 1) on the bf16 bit patterns

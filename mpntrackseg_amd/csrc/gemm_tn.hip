@@ -560,6 +560,33 @@ extern "C" int mpnhip_weight_grad_prec(const float* dZ, const float* H, int64_t 
     return weight_grad_run(a, precision, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int mpnhip_weight_grad_bf16_rows(const uint16_t* dZ, const uint16_t* H, int64_t rows, int n_out, int k_in, int nbatch,
+                                            float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
+    MPN_CHECK_ARG(n_out >= 1 && k_in >= 1 && rows >= 0 && nbatch >= 1, "weight_grad_bf16_rows: bad sizes");
+    if (rows == 0) return MPNHIP_OK;
+    MPN_CHECK_ARG(dZ && H && grad_w, "weight_grad_bf16_rows: null pointer");
+    const size_t need = align_up(wp_slab_floats(n_out, k_in, rows, nbatch, false, false, true) * sizeof(float), 256) + 256;
+    if (!workspace || workspace_bytes < need) {
+        set_error("weight_grad_bf16_rows: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    WpProduct p = {reinterpret_cast<const float*>(dZ), n_out, rows * n_out, reinterpret_cast<const float*>(H), k_in, rows * k_in, nullptr, nullptr,
+                   rows, nbatch, n_out, k_in, grad_w, k_in, grad_b, nullptr, nullptr, nullptr, 0, 0, 0, 1, 1};
+    WpBatch b;
+    WpBatchGuard guard;
+    wp_batch_begin(&b, slab, (workspace_bytes - 256) / sizeof(float), false);
+    if (wp_batch_add(p)) return wp_batch_flush(static_cast<hipStream_t>(stream));
+    wp_batch_abort();
+    set_error("weight_grad_bf16_rows: [%d x %d] over bf16 rows is not a shape of the row-panel kernel (multiples of 4, 8-byte aligned rows)", n_out, k_in);
+    return MPNHIP_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t mpnhip_weight_grad_bf16_rows_workspace_bytes(int n_out, int k_in, int64_t rows, int nbatch) {
+    if (n_out < 1 || k_in < 1 || rows < 0) return 0;
+    return align_up((rows > 0 ? wp_slab_floats(n_out, k_in, rows, nbatch < 1 ? 1 : nbatch, false, false, true) : 0) * sizeof(float), 256) + 256;
+}
+
 extern "C" int mpnhip_weight_grad(const float* dZ, const float* H, int64_t rows, int n_out, int k_in, int nbatch, float* grad_w,
                                   float* grad_b, void* workspace, size_t workspace_bytes, void* stream) {
     return mpnhip_weight_grad_prec(dZ, H, rows, n_out, k_in, nbatch, MPNHIP_PREC_FP32, grad_w, grad_b, workspace, workspace_bytes, stream);

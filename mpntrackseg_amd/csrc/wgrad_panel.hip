@@ -167,7 +167,8 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     // the edge-level products, the step unchanged -- the kernel is not bound by its bytes in flight),
     // two or four for the narrow ones (a <1, 1> stage is 16 rows x 128 columns = 8 KB per block: with one in flight the kernel waits out
     // the HBM latency every 16 rows -- 1.4 TB/s on the 32-d products of the reference's configuration)
-    constexpr int D = TM + TN <= 2 ? 4 : (TM + TN <= 5 && TM * TN <= 4 ? 2 : 1);
+    // (bf16 source rows: a stage is half the registers -- two in flight up to eight accumulator tiles; with ten they spill)
+    constexpr int D = B16 ? (TM + TN <= 3 ? 4 : (TM * TN <= 8 ? 2 : 1)) : (TM + TN <= 2 ? 4 : (TM + TN <= 5 && TM * TN <= 4 ? 2 : 1));
     StageT zreg[D][PZ], hreg[D][PH];
 
     // full stages: rows m0 .. m0 + 15 all inside the chunk.  (Compiler-visible loads on purpose.  Inline-assembly loads into TWO
