@@ -225,7 +225,7 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
         torch.cuda.empty_cache()
 
 
-def extras(dev, budget_s=40.0):
+def extras(dev, budget_s=60.0):
     """Short labelled measurements of the other BASELINE.json configurations: configs[4] (cfg-E, bf16-operand
     forward, plus its aggregation kernel as a separate launch -- the HBM-streaming figure), the configs[2] / configs[3] stand-ins
     (cfg-C / cfg-D training step, cfg-D forward).  Each is its own model and graph; a failure or the time budget drops the rest."""
@@ -234,6 +234,7 @@ def extras(dev, budget_s=40.0):
             ("cfgC_train", ("C", "train", "auto", 30, 8), None),
             ("cfgC_fwd", ("C", "fwd", "auto", 60, 10), None),
             ("cfgE_bf16_fwd", ("E", "fwd", "bf16", 5, 2), None),
+            ("cfgE_bf16_train", ("E", "train", "bf16", 3, 1), None),
             ("cfgE_bf16_fwd_unfused_aggregation", ("E", "fwd", "bf16", 3, 1), {"MPNHIP_NO_AGG_FUSION": "1"})]
     res, t_start, cache = {}, time.time(), {}
     for name, (cfg, mode, prec, steps, warm), env in plan:
@@ -573,10 +574,15 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         # (the kernel aggregates the messages itself -- they never reach HBM -- unless MPNHIP_NO_AGG_FUSION is set: then M is written)
         fused_agg = not os.environ.get("MPNHIP_NO_AGG_FUSION")
         alg_bytes = E * (2 * de * 4 + de * 4 + 12 + 4) + N * (2 * he + 2 * hn) * 4 + (N * 2 * dn * 4 if fused_agg else E * dn * 4)
+        mask_words = sum(((w + 31) // 32 + 1) // 2 for w in (he, de, hc, hn, dn))
+        if mode == "train":
+            # the SAVE variant also writes, per edge, the bf16 rows of H1 / HF / HC and of e' and the ReLU decision bits (8 bytes per
+            # mask word: 64 lanes x 4 bytes per 32-edge wave tile) -- every one of them is read again by the backward
+            alg_bytes += E * ((he + hn + hc + de) * 2 + mask_words * 8)
         ach = alg_bytes / (gemm_us * 1e-6) / 1e9
         traffic = pmc_traffic("edge_chain_bf16", args.config, args.precision)
         res["roofline"] = {"bound": "hbm",
-                           "kernel": "edge_chain_bf16_kernel<20,4,14,8,2> (two 4-wave blocks per CU): fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
+                           "kernel": "edge_chain_bf16_kernel<20,4,14,8,2> (two 4-wave blocks per CU" + (", SAVE variant" if mode == "train" else "") + "): fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
                                      "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers, node_agg_fn in the kernel; bound by the per-edge "
                                      "gathers of the projection table (%d B per edge from a %d MB table, uniformly random columns)"
                                      % ((2 * he + hn) * 4, N * (2 * he + 2 * hn) * 4 // 1000000),
@@ -648,7 +654,22 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         res["roofline_fwd_chain"] = res.pop("roofline")
         cand = {"roofline_fwd_chain": res["roofline_fwd_chain"]["ms_per_step"]}
         bu, bn, _ = extra.get("chain_bwd", (0.0, 0, 0.0))
-        if bn and chain:
+        if bn and chain == 2 and per_step.get("edge_chain_bwd_bf16", 0) > 0:
+            # edge_chain_bf16_bwd_kernel: what it must move at least per launch -- in: the gradient w.r.t. e_s (fp32), the ReLU decision
+            # bits, the logit gradient and the row index per edge, the aggregate's gradient once per node; out: the five dZ blocks as
+            # bf16 rows and the gradient w.r.t. e_{s-1} (fp32)
+            mask_words = sum(((w + 31) // 32 + 1) // 2 for w in (he, de, hc, hn, dn))
+            bytes_b = E * (de * 4 + mask_words * 8 + 4 + 8 + (dn + hn + hc + de + he) * 2 + de * 4) + N * 2 * dn * 4
+            macs_b = hn * dn + de * hn + hc * de + hc + he * de + de * he      # B2 .. B6 (the re-attached e0's share of B6 is hoisted)
+            fl = 2.0 * E * macs_b
+            ach = bytes_b / (bu * 1e-6) / 1e9
+            res["roofline_bwd_chain"] = {"bound": "hbm", "kernel": "edge_chain_bf16_bwd_kernel: fused activation-gradient chain of one MP step, bf16 operands, "
+                                                                   "bf16 dZ rows out; %d edges x %d MACs" % (E, macs_b),
+                                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": bu, "launches": bn,
+                                         "traffic": None, "algorithmic_bytes": bytes_b, "algorithmic_flops": fl,
+                                         "mfma_frac_of_bf16_peak": fl / (bu * 1e-6) / 1e12 / 2516.6, "ms_per_step": bu * c["L"] / 1e3}
+            cand["roofline_bwd_chain"] = res["roofline_bwd_chain"]["ms_per_step"]
+        elif bn and chain:
             ke = 2 * de
             macs_b = hn * dn + de * hn + hc * de + hc + he * de + ke * he      # B2 .. B6 of the backward chain (csrc/edge_chain.hip)
             fl = 2.0 * E * macs_b
@@ -669,8 +690,9 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
             ach = tw / (tu * 1e-6) / 1e9
             # the same launches' products as fp32-equivalent flops (12 steps x edge-level + node-level + hoisted + encoder)
             res["roofline_weight_grad"] = {"bound": "hbm", "kernel": "wgrad_panel_kernel: dW += dZ^T H for all products of a group of steps in one launch "
-                                                                     "(row-panel blocks, three-piece bf16 operands split in the loader, ds_read_b64_tr_b16 "
-                                                                     "operands, v_mfma_f32_32x32x16_bf16), side stream",
+                                                                     "(row-panel blocks, %s, ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16), side stream"
+                                                                     % ("bf16 source rows as stored by the chain kernels, one product per k block" if chain == 2 else
+                                                                        "three-piece bf16 operands split in the loader"),
                                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": tu, "launches": tn_,
                                            "traffic": pmc_traffic("wgrad_panel", args.config, args.precision),
                                            "algorithmic_bytes": tw, "launches_per_step": launches, "ms_per_step": tu * launches / 1e3}

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_sum_blocks_bf16(const unsigned short* _
         uint4 v[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
-            const int b = b0 + u < nb ? b0 + u : nb - 1;   // clamped, unconditional loads
+            const int b = b0 + u < nb ? b0 + u : nb - 1;   // clamped, unconditional loads (summed in ascending b below)
             v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)b * stride + 8 * i);
         }
 #pragma unroll

@@ -157,6 +157,8 @@ struct EdgeChainBf16Args {
     unsigned short* save_hf;  // [E, hn]
     unsigned short* save_eb;  // [E, de]
     unsigned* save_mask;      // chain_bf16_mask_ints(E, ...) words
+    int debug_skip;           // MPNHIP_CHAIN_BF16_DEBUG_SKIP, timing ablations: 1 no row saves, 2 no mask words (results wrong); 4: plain
+                              // instead of non-temporal row stores (A-B)
 };
 // mask words per lane of one 32-edge wave tile (two 32-feature tiles per word; sections H1 | e' | HC | HF | M) and the size of one
 // step's mask buffer (every wave tile of the launch incl. its 3 spare blocks; `epb`-independent: 32-edge tiles)
@@ -217,6 +219,7 @@ struct EdgeChainBf16BwdArgs {
     const void* img_cls;
     const void* img_flow[2];
     const float* wc2;         // [hc] (the model's tensor)
+    int debug_skip;           // MPNHIP_CHAIN_BF16_DEBUG_SKIP, timing ablations: 1 no dZ row stores (results wrong); 4: non-temporal row stores (A-B)
 };
 size_t chain_bf16_bwd_image_bytes(int he, int de, int hn, int dn, int hc, size_t* off_cls, size_t* off_flow0, size_t* off_flow1);
 // w_edge0 [he][ld_edge0] with the e_{s-1} columns starting at col_e; w_edge1 [de][he]; w_cls0 [hc][de]; w_flow0[q] [hn][ld_flow0], e'

@@ -86,10 +86,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
     // a finished dZ tile as 32 contiguous bytes of the edge's bf16 row per lane (features 32 t + 16 lh .. + 15; tile_rows16)
     auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
         // (the lane exchange needs every lane: predicate the stores only)
+        if (A.debug_skip & 1) return;
         uint4 lo, hi;
         tile_rows16(h0, h1, lo, hi);
         const int f = 32 * t + 16 * lh;
         unsigned short* q = base + (size_t)edge * width + f;
+        // (plain stores: the scatter-adds and the weight-gradient products read these rows right away -- non-temporal stores took
+        // the launch from 611 to 756 us at cfg-E; MPNHIP_CHAIN_BF16_DEBUG_SKIP=4 selects them, A-B)
+        if (A.debug_skip & 4) {
+            const u32x4 l4 = {lo.x, lo.y, lo.z, lo.w}, h4 = {hi.x, hi.y, hi.z, hi.w};
+            if (edge_ok && (EXACT || f < width)) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(q));
+            if (edge_ok && (EXACT || f + 8 < width)) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(q + 8));
+            return;
+        }
         if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
         if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
     };
@@ -322,6 +331,7 @@ int launch_edge_chain_bf16_bwd(const EdgeChainBf16BwdArgs& a_in, hipStream_t s) 
     if (a_in.E <= 0) return MPNHIP_OK;
     EdgeChainBf16BwdArgs a = a_in;
     if (const char* e = getenv("MPNHIP_CHAIN_BF16_PLAIN_BARRIERS")) a.plain_barriers = e[0] == '1' ? 1 : 0;
+    if (const char* e = getenv("MPNHIP_CHAIN_BF16_DEBUG_SKIP")) a.debug_skip = atoi(e);
     const int wmax = a.he > a.dn ? a.he : a.dn;
     if ((int64_t)a.E * wmax >= ((int64_t)1 << 32) || (int64_t)a.N * 2 * a.dn >= ((int64_t)1 << 32)) {
         set_error("edge_chain_bf16_bwd: graph too large for 32-bit row offsets");
