@@ -130,7 +130,7 @@ def cpu_baseline(params, W, g, train, budget_s=20.0):
                       % ("forward+backward" if train else "forward", torch.__version__, nthreads, nruns, t * 1e3, note)}
 
 
-def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=1, env=None, profile=True):
+def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=1, env=None, profile=True, n_batch=1):
     """One short, self-contained measurement of another BASELINE.json configuration (own model, own graph): ms per step,
     edges/ms and the rooflines of its profiled kernels.  Used for the labelled objects appended to the default line; never
     touches the headline's `value`."""
@@ -146,7 +146,13 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
         c = dict(synth.CONFIGS[cfg_name])
         params = synth.model_params(c["d"], c["L"], agg)
         W = synth.make_weights(params, seed=7)
-        if c.get("knn"):
+        if n_batch > 1:
+            # n_batch graphs (the seeds the ranks of a data-parallel run would take) as ONE block-diagonal batch with the reference's
+            # per-graph loss: accumulate_grad_batches optimizer micro-steps (configs/tracking_cfg.yaml:3-4) in one launch sequence
+            gs = [synth.make_knn_graph(seed=seed + i, **c["knn"]) if c.get("knn") else synth.make_graph(c["N"], c["E"], seed=seed + i) for i in range(n_batch)]
+            g = synth.batch_graphs(gs)
+            c["E"], c["N"] = int(g["edge_index"].shape[1]), int(g["x"].shape[0])
+        elif c.get("knn"):
             g = synth.make_knn_graph(seed=seed, **c["knn"])
             c["E"] = int(g["edge_index"].shape[1])
         else:
@@ -172,9 +178,10 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
                     return model.hot_path(x, ei, ea, holder=holder)
         else:
             stepper = mtrain.TrainStep(model, world_size=1)
+            eg = torch.from_numpy(g["edge_graph"]).to(dev) if n_batch > 1 else None
 
             def step():
-                return stepper(x, ei, ea, holder=holder)
+                return stepper(x, ei, ea, holder=holder, edge_graph=eg, n_graphs=n_batch)
         lib = capi.load()
         t_warm = time.perf_counter()
         for _ in range(warmup):
@@ -196,8 +203,9 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / steps
         counts = capi.path_counters(reset=True)
-        out = {"workload": "cfg-%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, %s" % (
-                   cfg_name, N, E, c["d"], c["L"], agg, "training step (fwd+bwd+Adam)" if mode == "train" else "inference forward"),
+        out = {"workload": "cfg-%s%s: %d nodes / %d directed edges / %d-d feats / %d MP steps, node_agg_fn=%s, %s" % (
+                   cfg_name, " x %d graphs as one block-diagonal batch, per-graph loss" % n_batch if n_batch > 1 else "", N, E, c["d"], c["L"], agg,
+                   "training step (fwd+bwd+Adam)" if mode == "train" else "inference forward"),
                "precision": prec, "ms_per_step": ms, "value": E / ms, "unit": "edges/ms", "steps": steps, "warmup": warmup}
         if profile:
             extra = {}
@@ -231,6 +239,7 @@ def extras(dev, budget_s=60.0):
     (cfg-C / cfg-D training step, cfg-D forward).  Each is its own model and graph; a failure or the time budget drops the rest."""
     plan = [("cfgD_fwd", ("D", "fwd", "auto", 200, 20), None),
             ("cfgD_train", ("D", "train", "auto", 40, 10), None),
+            ("cfgD_train_x8", ("D", "train", "auto", 30, 8), {"__n_batch": "8"}),
             ("cfgC_train", ("C", "train", "auto", 30, 8), None),
             ("cfgC_fwd", ("C", "fwd", "auto", 60, 10), None),
             ("cfgE_bf16_fwd", ("E", "fwd", "bf16", 5, 2), None),
@@ -242,7 +251,12 @@ def extras(dev, budget_s=60.0):
             res[name] = {"skipped": "time budget of the extra measurements (%.0f s) used up" % budget_s}
             continue
         try:
-            res[name] = measure_case(cfg, mode, prec, steps, warm, dev, env=env)
+            nb = 1
+            if env and "__n_batch" in env:
+                nb, env = int(env["__n_batch"]), None
+            res[name] = measure_case(cfg, mode, prec, steps, warm, dev, env=env, n_batch=nb)
+            if nb > 1 and "cfgD_train" in res and "value" in res["cfgD_train"]:
+                res[name]["edges_per_ms_over_one_graph_per_step"] = res[name]["value"] / res["cfgD_train"]["value"]
             if env:
                 res[name]["env"] = env
                 # only the separately launched aggregation kernel's line is of interest here

@@ -301,6 +301,15 @@ int mpnhip_tracking_loss(const float* logits, const float* labels, int n_steps, 
                          float weight, float* loss_out, float* grad_logits, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same loss over the n_graphs graphs of ONE block-diagonal batch (torch_geometric's Batch; edge_graph[e] = graph of edge e, int32,
+ * edge_index order): every graph its own pos_weight and its own mean, as the reference computes them graph by graph with
+ * batch_size 1, and the n_graphs losses AVERAGED -- what accumulate_grad_batches = n_graphs backward passes add up to
+ * (configs/tracking_cfg.yaml:3-4, pl_module.py:88-107).  loss_out [1 + n_steps]; grad_logits [n_steps, E]. */
+size_t mpnhip_tracking_loss_graphs_workspace_bytes(int n_steps, int64_t n_edges, int n_graphs);
+int mpnhip_tracking_loss_graphs(const float* logits, const float* labels, const int32_t* edge_graph, int n_graphs, int n_steps,
+                                int64_t n_edges, int first_step, float weight, float* loss_out, float* grad_logits, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* compute_perform_metrics (utils/evaluation.py:416-437) on the last step's logits [E] (edge_index order):
  * counts[0..3] = TP, FP, TN, FN of (logit > 0) vs labels (fast_compute_class_metric, :340-366);
  * counts[4..5] = nodes whose outgoing / incoming flow exceeds 1, counts[6..7] = nodes that have an outgoing /

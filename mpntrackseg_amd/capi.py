@@ -91,6 +91,8 @@ SIGNATURES = {
     "mpnhip_mlp_forward": (_I, [C.POINTER(Mlp), _P, _P, _L, _P, _Z, _P]),
     "mpnhip_tracking_loss_workspace_bytes": (_Z, [_I, _L]),
     "mpnhip_tracking_loss": (_I, [_P, _P, _I, _L, _I, C.c_float, _P, _P, _P, _Z, _P]),
+    "mpnhip_tracking_loss_graphs_workspace_bytes": (_Z, [_I, _L, _I]),
+    "mpnhip_tracking_loss_graphs": (_I, [_P, _P, _P, _I, _I, _L, _I, C.c_float, _P, _P, _P, _Z, _P]),
     "mpnhip_step_metrics": (_I, [_P, _I, _L, _P, _P, _P, _P]),
     "mpnhip_attention_aggregate": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
     "mpnhip_attention_aggregate_backward": (_I, [_P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P]),

@@ -94,6 +94,58 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p
     if (threadIdx.x == 0) loss_out[0] = (float)total;
 }
 
+// ---- the same loss over K graphs of one block-diagonal batch: each graph its own pos_weight and its own mean, the K losses averaged
+// (accumulate_grad_batches executed in space: configs/tracking_cfg.yaml:3-4, pl_module.py:88-107 per graph) ------------------------
+// counts[g] = {edges, positive labels} of graph g (exact integers); K <= 1024
+__global__ __launch_bounds__(256) void k_graph_counts(const float* __restrict__ labels, const int* __restrict__ edge_graph, int64_t E, int K,
+                                                      int* __restrict__ counts) {
+    extern __shared__ int sc[];   // [2 K]
+    for (int i = threadIdx.x; i < 2 * K; i += 256) sc[i] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < E) {
+        const int g = edge_graph[i];
+        if (g >= 0 && g < K) {
+            atomicAdd(&sc[2 * g], 1);
+            if (labels[i] == 1.f) atomicAdd(&sc[2 * g + 1], 1);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * K; j += 256)
+        if (sc[j]) atomicAdd(&counts[j], sc[j]);
+}
+
+// grid (ceil(E / 256), L): the per-edge term divided by its graph's edge count; partial[step][block] = sum of those
+__global__ __launch_bounds__(256) void k_bce_graphs(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                    const int* __restrict__ edge_graph, int64_t E, int K, int first_step, float weight,
+                                                    const int* __restrict__ counts, float* __restrict__ dlogits, float* __restrict__ partial) {
+    const int step = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f;
+    if (i < E) {
+        float gr = 0.f;
+        const int g = edge_graph[i];
+        if (step >= first_step && g >= 0 && g < K) {
+            const float Eg = (float)counts[2 * g], P = (float)counts[2 * g + 1];
+            const float pw = P > 0.f ? (Eg - P) / P : 0.f;  // pl_module.py:92-96, per graph
+            const float z = logits[(int64_t)step * E + i], y = labels[i];
+            const float lw = 1.f + (pw - 1.f) * y;
+            term = ((1.f - y) * z + lw * (log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f))) / Eg;
+            const float sg = z >= 0.f ? 1.f / (1.f + expf(-z)) : expf(z) / (1.f + expf(z));
+            gr = (sg * lw - pw * y) * (weight / (Eg * (float)K));
+        }
+        dlogits[(int64_t)step * E + i] = gr;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)step * gridDim.x + blockIdx.x] = red[0];
+}
+
 __global__ void k_confusion(const float* __restrict__ logits, const float* __restrict__ labels, int64_t E, int* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
@@ -165,6 +217,42 @@ extern "C" int mpnhip_tracking_loss(const float* logits, const float* labels, in
     hipLaunchKernelGGL(k_bce, dim3(nblk, n_steps), dim3(256), 0, s, logits, labels, n_edges, first_step, weight, pos, grad_logits, partial);
     MPN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, s, partial, nblk, n_steps, n_edges, weight, loss_out);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+extern "C" size_t mpnhip_tracking_loss_graphs_workspace_bytes(int n_steps, int64_t n_edges, int n_graphs) {
+    return mpnhip_tracking_loss_workspace_bytes(n_steps, n_edges) + align_up((size_t)2 * (n_graphs > 0 ? n_graphs : 1) * sizeof(int), 256);
+}
+
+extern "C" int mpnhip_tracking_loss_graphs(const float* logits, const float* labels, const int32_t* edge_graph, int n_graphs, int n_steps,
+                                           int64_t n_edges, int first_step, float weight, float* loss_out, float* grad_logits,
+                                           void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    MPN_CHECK_ARG(n_steps >= 1 && n_edges >= 0 && first_step >= 0 && n_graphs >= 1 && n_graphs <= 1024, "tracking_loss_graphs: bad sizes");
+    MPN_CHECK_ARG(loss_out, "tracking_loss_graphs: null loss_out");
+    if (n_edges == 0) {
+        MPN_HIP(hipMemsetAsync(loss_out, 0, (size_t)(1 + n_steps) * sizeof(float), s));
+        return MPNHIP_OK;
+    }
+    MPN_CHECK_ARG(logits && labels && grad_logits && edge_graph, "tracking_loss_graphs: null tensor");
+    const size_t need = mpnhip_tracking_loss_graphs_workspace_bytes(n_steps, n_edges, n_graphs);
+    if (!workspace || workspace_bytes < need) {
+        set_error("tracking_loss_graphs: workspace %zu < %zu", workspace_bytes, need);
+        return MPNHIP_ERR_WORKSPACE;
+    }
+    const size_t base = mpnhip_tracking_loss_workspace_bytes(n_steps, n_edges);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    int* counts = reinterpret_cast<int*>(static_cast<char*>(workspace) + base);
+    const int nblk = (int)((n_edges + 255) / 256);
+    MPN_HIP(hipMemsetAsync(counts, 0, (size_t)2 * n_graphs * sizeof(int), s));
+    hipLaunchKernelGGL(k_graph_counts, dim3(nblk), dim3(256), (size_t)2 * n_graphs * sizeof(int), s, labels, edge_graph, n_edges, n_graphs, counts);
+    MPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bce_graphs, dim3(nblk, n_steps), dim3(256), 0, s, logits, labels, edge_graph, n_edges, n_graphs, first_step, weight, counts,
+                       grad_logits, partial);
+    MPN_LAUNCH_CHECK();
+    // (the per-edge terms were divided by their graph's edge count: E = 1 here; the mean over the graphs goes into the weight)
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, s, partial, nblk, n_steps, (int64_t)1, weight / (float)n_graphs, loss_out);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -8,9 +8,16 @@ import torch
 from . import capi
 
 
-def tracking_loss_and_grad(logits, edge_labels, first_step=0, weight=1.0):
+def edge_graph_ids(batch, edge_index):
+    """Graph id of every edge of a block-diagonal batch (torch_geometric ``Batch.batch`` is per NODE): int32 [E]."""
+    return batch.to(torch.int32)[edge_index[0]].contiguous()
+
+
+def tracking_loss_and_grad(logits, edge_labels, first_step=0, weight=1.0, edge_graph=None, n_graphs=1):
     """logits [L, E] (all steps), edge_labels [E] -> (loss_vec [1 + L] on device: total then per step,
-    grad_logits [L, E]).  No host synchronisation."""
+    grad_logits [L, E]).  No host synchronisation.  ``edge_graph`` (int32 [E], with ``n_graphs``): the edges belong to the graphs of
+    one block-diagonal batch -- per-graph pos_weight and mean, averaged over the graphs (``mpnhip_tracking_loss_graphs``: the
+    reference's accumulate_grad_batches executed in space)."""
     capi.require_device(logits, edge_labels)
     lib = capi.load()
     lg = capi.f32c(logits)
@@ -18,6 +25,17 @@ def tracking_loss_and_grad(logits, edge_labels, first_step=0, weight=1.0):
     L, E = lg.shape
     loss = torch.empty(1 + L, dtype=torch.float32, device=lg.device)
     grad = torch.empty_like(lg)
+    if edge_graph is not None:
+        capi.require_device(edge_graph)
+        eg = edge_graph.to(torch.int32).contiguous().view(-1)
+        if eg.numel() != E:
+            raise capi.MpnhipError("edge_graph must name the graph of each of the %d edges" % E)
+        with torch.cuda.device(lg.device):
+            ws = capi.workspace(lib.mpnhip_tracking_loss_graphs_workspace_bytes(L, E, int(n_graphs)), lg.device, "loss")
+            capi.check(lib.mpnhip_tracking_loss_graphs(capi.ptr(lg), capi.ptr(y), capi.ptr(eg), int(n_graphs), L, E, int(first_step),
+                                                       float(weight), capi.ptr(loss), capi.ptr(grad), capi.ptr(ws), ws.numel(),
+                                                       capi.stream_ptr()), "mpnhip_tracking_loss_graphs")
+        return loss, grad
     with torch.cuda.device(lg.device):
         ws = capi.workspace(lib.mpnhip_tracking_loss_workspace_bytes(L, E), lg.device, "loss")
         capi.check(lib.mpnhip_tracking_loss(capi.ptr(lg), capi.ptr(y), L, E, int(first_step), float(weight), capi.ptr(loss),

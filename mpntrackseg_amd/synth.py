@@ -268,8 +268,11 @@ def batch_graphs(graphs):
     for g in graphs:
         xs.append(g["x"]); eas.append(g["edge_attr"]); eis.append(g["edge_index"] + off); frs.append(g["frame"])
         off += g["x"].shape[0]
+    # `batch` / `edge_graph`: torch_geometric's per-node graph id, and the graph id of every edge (int32)
     return {"x": np.concatenate(xs), "edge_index": np.concatenate(eis, axis=1),
-            "edge_attr": np.concatenate(eas), "frame": np.concatenate(frs)}
+            "edge_attr": np.concatenate(eas), "frame": np.concatenate(frs),
+            "batch": np.concatenate([np.full(g["x"].shape[0], i, np.int64) for i, g in enumerate(graphs)]),
+            "edge_graph": np.concatenate([np.full(g["edge_index"].shape[1], i, np.int32) for i, g in enumerate(graphs)])}
 
 
 def checksum(a):

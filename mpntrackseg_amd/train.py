@@ -163,7 +163,10 @@ class TrainStep:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
             flat.mul_(1.0 / self.world_size)
 
-    def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True):
+    def __call__(self, x, edge_index, edge_attr, labels=None, holder=None, optimizer_step=True, edge_graph=None, n_graphs=1):
+        """``edge_graph`` / ``n_graphs``: (x, edge_index, edge_attr) is a block-diagonal batch of ``n_graphs`` graphs (int32 graph id per
+        edge, ``loss.edge_graph_ids``): ONE forward / backward over the batch with the reference's per-graph loss averaged over the
+        graphs -- ``accumulate_grad_batches`` optimizer micro-steps (configs/tracking_cfg.yaml:3-4) executed in space on one GPU."""
         from .mpn import _prepared, check_hot_path_inputs
         model = self.model
         g = _prepared(edge_index, x.shape[0], holder)
@@ -180,7 +183,7 @@ class TrainStep:
             labels = self._default_labels
         # reference loss (pl_module.py:88-107) and its gradient w.r.t. every step's logits, natively
         from .loss import tracking_loss_and_grad
-        self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0)
+        self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0, edge_graph=edge_graph, n_graphs=n_graphs)
         self.bucket.zero_()
         lib = capi.load()
         defer = self.collectives and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))

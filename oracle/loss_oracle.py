@@ -25,6 +25,19 @@ def tracking_loss(classified_edges, edge_labels, weight=1.0):
     return loss
 
 
+def tracking_loss_graphs(classified_edges, edge_labels, edge_ptr, weight=1.0):
+    """accumulate_grad_batches graphs (configs/tracking_cfg.yaml:3-4) as ONE block-diagonal batch: the reference evaluates
+    ``_compute_loss`` per graph (pl_module.py:88-107: the graph's own pos_weight and mean) and the accumulated backward passes are
+    averaged -- the mean over the graphs of ``tracking_loss`` on each graph's slice [edge_ptr[g], edge_ptr[g+1]) of the edges.
+    Pinned by tests/golden/g16_loss_graphs.npz (tools/make_golden.py gen_g16: the reference's _compute_loss per graph)."""
+    K = len(edge_ptr) - 1
+    total = 0
+    for g in range(K):
+        a, b = int(edge_ptr[g]), int(edge_ptr[g + 1])
+        total = total + tracking_loss([c.view(-1)[a:b] for c in classified_edges], edge_labels.view(-1)[a:b], weight)
+    return total / K
+
+
 def fast_compute_class_metric(test_preds, test_sols):
     """utils/evaluation.py:340-366."""
     TP = ((test_sols == 1) & (test_preds == 1)).sum().float()

@@ -148,3 +148,69 @@ def test_step_metrics_against_reference(golden, tag):
     want = z[f"{tag}:metrics"]
     for i, k in enumerate(("accuracy", "recall", "precision", "constr_sr")):
         assert abs(got[k] - float(want[i])) < 1e-6, k
+
+
+@pytest.mark.parametrize("tag", ["g3", "g8"])
+def test_graph_batched_loss_against_the_reference_per_graph_loss(golden, tag):
+    """mpnhip_tracking_loss_graphs against the reference's _compute_loss evaluated graph by graph and averaged (g16 fixture:
+    3 graphs of different sizes incl. one without a positive label; 8 graphs = the shipped accumulate_grad_batches)."""
+    z = golden("g16_loss_graphs.npz")
+    logits = torch.from_numpy(z[f"{tag}:logits"]).to(dev())
+    labels = torch.from_numpy(z[f"{tag}:labels"]).to(dev())
+    ptr = z[f"{tag}:edge_ptr"]
+    K = len(ptr) - 1
+    eg = torch.from_numpy(np.repeat(np.arange(K, dtype=np.int32), np.diff(ptr))).to(dev())
+    loss, grad = tracking_loss_and_grad(logits, labels, 0, float(z[f"{tag}:weight"]), edge_graph=eg, n_graphs=K)
+    ref = float(z[f"{tag}:loss"])
+    assert abs(float(loss[0]) - ref) <= 1e-5 * max(1.0, abs(ref))
+    assert float(np.abs(grad.cpu().numpy() - z[f"{tag}:grad"]).max()) <= 1e-6 * max(1.0, float(np.abs(z[f"{tag}:grad"]).max()))
+    # one graph: the plain loss
+    l1, g1 = tracking_loss_and_grad(logits, labels, 0, 0.75)
+    l2, g2 = tracking_loss_and_grad(logits, labels, 0, 0.75, edge_graph=torch.zeros_like(eg), n_graphs=1)
+    assert abs(float(l1[0]) - float(l2[0])) <= 1e-6 * max(1.0, abs(float(l1[0]))) and float((g1 - g2).abs().max()) <= 1e-7 * float(g1.abs().max())
+
+
+def test_train_step_over_a_batch_of_graphs_is_the_mean_of_the_single_graph_steps():
+    """TrainStep on the block-diagonal batch of the 8 cfg-D graphs (configs[3]: one KITTIMOTS-like graph per accumulate_grad_batches
+    micro-step) with the per-graph loss: ONE forward / backward whose gradient equals the mean of the 8 single-graph gradients
+    (relative L2 per tensor <= 1e-5: the sub-graphs do not interact; only fp32 summation order differs), i.e. the reference's
+    optimizer step (configs/tracking_cfg.yaml:3-4) from one launch sequence."""
+    from mpntrackseg_amd import synth
+    from mpntrackseg_amd.mpn import MOTMPNet
+    from mpntrackseg_amd.train import TrainStep
+    c = synth.CONFIGS["D"]
+    graphs = [synth.make_knn_graph(seed=1 + r, node_in_dim=64, **c["knn"]) for r in range(8)]
+    params = synth.model_params(c["d"], c["L"], "sum", num_class_steps=3, node_in_dim=64)
+    W = synth.make_weights(params, seed=7, gain=0.5)
+
+    def fresh():
+        m = MOTMPNet(params)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+        return m.to(dev()).train()
+
+    def labels_of(g, seed):
+        return torch.from_numpy((synth.uniform01(seed, g["edge_index"].shape[1]) < 0.15).astype(np.float32)).to(dev())
+
+    singles = []
+    for i, g in enumerate(graphs):
+        st = TrainStep(fresh())
+        st(*(torch.from_numpy(g[k]).to(dev()) for k in ("x", "edge_index", "edge_attr")), labels=labels_of(g, 30 + i), optimizer_step=False)
+        torch.cuda.synchronize()
+        singles.append(st.bucket.flat.double().cpu().numpy().copy())
+    want = sum(singles) / 8
+    b = synth.batch_graphs(graphs)
+    st = TrainStep(fresh())
+    lab = torch.cat([labels_of(g, 30 + i) for i, g in enumerate(graphs)])
+    st(*(torch.from_numpy(b[k]).to(dev()) for k in ("x", "edge_index", "edge_attr")), labels=lab, optimizer_step=False,
+       edge_graph=torch.from_numpy(b["edge_graph"]).to(dev()), n_graphs=8)
+    torch.cuda.synchronize()
+    got = st.bucket.flat.double().cpu().numpy()
+    bad = []
+    for p_ in st.bucket.params:
+        o, n = st.bucket.offsets[id(p_)], p_.numel()
+        ref = want[o:o + n]
+        if np.linalg.norm(ref) > 0:
+            err = float(np.linalg.norm(got[o:o + n] - ref) / np.linalg.norm(ref))
+            if err > 1e-5:
+                bad.append((tuple(p_.shape), err))
+    assert not bad, bad

@@ -387,3 +387,24 @@ def test_recorded_decisions_compare_like_a_direct_compare_run():
             assert direct.worst_margin >= O.Decisions.NEAR and got.worst_margin >= O.Decisions.NEAR
         else:
             assert abs(got.worst_margin - direct.worst_margin) <= 1e-12 * max(1.0, direct.worst_margin)
+
+
+@pytest.mark.parametrize("tag", ["g3", "g8"])
+def test_g16_graph_batched_loss_oracle_against_the_reference_per_graph_loss(golden, tag):
+    """oracle/loss_oracle.py::tracking_loss_graphs against the reference's _compute_loss evaluated graph by graph and averaged
+    (accumulate_grad_batches in space; tests/golden/g16_loss_graphs.npz): value, per-graph values and autograd gradient."""
+    from oracle import loss_oracle as LO
+    z = golden("g16_loss_graphs.npz")
+    logits = torch.from_numpy(z[f"{tag}:logits"]).clone().requires_grad_(True)
+    labels = torch.from_numpy(z[f"{tag}:labels"])
+    ptr = z[f"{tag}:edge_ptr"]
+    k, E = logits.shape
+    w = float(z[f"{tag}:weight"])
+    loss = LO.tracking_loss_graphs([logits[s].view(E, 1) for s in range(k)], labels, ptr, weight=w)
+    loss.backward()
+    assert abs(float(loss) - float(z[f"{tag}:loss"])) <= 1e-6 * max(1.0, abs(float(z[f"{tag}:loss"])))
+    assert float(np.abs(logits.grad.numpy() - z[f"{tag}:grad"]).max()) <= 1e-7 * max(1.0, float(np.abs(z[f"{tag}:grad"]).max()))
+    for g in range(len(ptr) - 1):
+        a, b = int(ptr[g]), int(ptr[g + 1])
+        li = LO.tracking_loss([logits.detach()[s, a:b] for s in range(k)], labels[a:b], weight=w)
+        assert abs(float(li) - float(z[f"{tag}:per_graph"][g])) <= 1e-6 * max(1.0, abs(float(z[f"{tag}:per_graph"][g])))

@@ -692,6 +692,40 @@ def gen_g9():
     print("g9 ok:", {k: float(v) for k, v in rec.items() if k.endswith(":loss")}, rec["m1:metrics"])
 
 
+def gen_g16():
+    """accumulate_grad_batches (configs/tracking_cfg.yaml:3-4) executed in space on ONE device: K graphs as one block-diagonal batch.
+    The reference calls MOTNeuralSolver._compute_loss (pl_module/pl_module.py:88-107) once per graph -- its own pos_weight, its own
+    mean -- and Lightning averages the K backward passes: expected loss = mean over the graphs of the reference's loss on the graph's
+    slice of the logits, gradient = its autograd.  Cases: 3 graphs of different sizes, one of them without a positive label; 8 equal
+    graphs (the shipped accumulate_grad_batches)."""
+    EV, TR, PL = _import_tracking_stack()
+    rec = {}
+    for tag, sizes, k, fracs in (("g3", [700, 1900, 333], 3, [0.15, 0.0, 0.4]), ("g8", [500] * 8, 4, [0.05 * (i + 1) for i in range(8)])):
+        E = sum(sizes)
+        logits = synth.normal(7, (k, E), std=2.5)
+        labels = np.concatenate([(synth.uniform01(11 + i, n) < f).astype(np.float32) for i, (n, f) in enumerate(zip(sizes, fracs))])
+        ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        lg = torch.from_numpy(logits).clone().requires_grad_(True)
+        solver = types.SimpleNamespace(hparams={"train_params": {"loss_weights": {"tracking": 0.75, "segmentation": 1.0}}})
+        total = 0
+        per_graph = []
+        for i in range(len(sizes)):
+            a, b = int(ptr[i]), int(ptr[i + 1])
+            outputs = {"classified_edges": [lg[s, a:b].view(b - a, 1) for s in range(k)],
+                       "mask_predictions": [torch.zeros((2, 1, 4, 4)) for _ in range(k)]}
+            batch = types.SimpleNamespace(edge_labels=torch.from_numpy(labels[a:b]), mask_labels=torch.zeros((2, 1, 4, 4)),
+                                          mask_gt_ixs=torch.zeros(0, dtype=torch.long))
+            li = PL.MOTNeuralSolver._compute_loss(solver, outputs, batch)
+            per_graph.append(float(li))
+            total = total + li
+        loss = total / len(sizes)
+        loss.backward()
+        rec.update({f"{tag}:logits": logits, f"{tag}:labels": labels, f"{tag}:edge_ptr": ptr, f"{tag}:loss": np.float64(float(loss)),
+                    f"{tag}:per_graph": np.array(per_graph, np.float64), f"{tag}:grad": lg.grad.numpy(), f"{tag}:weight": np.float64(0.75)})
+    np.savez_compressed(os.path.join(GOLD, "g16_loss_graphs.npz"), **rec)
+    print("g16 ok:", {k: float(v) for k, v in rec.items() if k.endswith(":loss")})
+
+
 def gen_g10():
     """MPNTracker._evaluate_graph_in_batches + _predict_edges_and_masks (tracker/mpn_tracker.py:96-210) on a synthetic sequence,
     driven with the REFERENCE model (mask branch included) on CPU.  Two redirections, because the code hard-codes the device:
@@ -830,6 +864,7 @@ def main():
     if "g13" in only: gen_g13(mpn)
     if "g14" in only: gen_g14()
     if "g15" in only: gen_g15(mpn)
+    if "g16" in only: gen_g16()
 
 
 if __name__ == "__main__":
