@@ -155,8 +155,14 @@ struct EdgeChainBf16Args {
     unsigned short* save_h1;  // [E, he] bf16
     unsigned short* save_hc;  // [E, hc]
     unsigned short* save_hf;  // [E, hn]
-    unsigned short* save_eb;  // [E, de]
+    unsigned short* save_eb;  // [E, de]  (= e16_out)
     unsigned* save_mask;      // chain_bf16_mask_ints(E, ...) words
+    // bf16 copies of the edge features between the steps (round 4): the kernel rounds its first-layer input to bf16 anyway, so reading
+    // [e0 | e] as bf16 rows gives IDENTICAL results for half the bytes; e16_out: e_new as bf16 rows for the next step (and, in
+    // training, the weight-gradient products); e_new (fp32) may then be NULL (every step but the one whose features are returned)
+    const unsigned short* xa16;   // [E, de] or nullptr (then xa / ldxa, fp32)
+    const unsigned short* xb16;
+    unsigned short* e16_out;      // [E, de] or nullptr
     int debug_skip;           // MPNHIP_CHAIN_BF16_DEBUG_SKIP, timing ablations: 1 no row saves, 2 no mask words (results wrong); 4: plain
                               // instead of non-temporal row stores (A-B)
 };

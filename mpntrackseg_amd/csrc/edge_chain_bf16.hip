@@ -132,10 +132,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     bf16x8 X[KB1];
 #pragma unroll
     for (int sg = 0; sg < EF; ++sg) {
-        const float* xr = sg == 0 ? A.xa + (int64_t)edge * A.ldxa : A.xb + (int64_t)edge * A.ldxb;
+        const unsigned short* x16 = sg == 0 ? A.xa16 : A.xb16;
+        if (x16) {
+            // bf16 rows: the same values the fp32 path rounds to, as two 8-byte pieces per k block
+            const unsigned short* xr = x16 + (size_t)edge * de;
 #pragma unroll
-        for (int kb = 0; kb < KBE; ++kb)
-            X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 4 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 + 4 * lh, de));
+            for (int kb = 0; kb < KBE; ++kb) {
+                const int n0 = 16 * kb + 4 * lh, n1 = n0 + 8;
+                uint2 a = *reinterpret_cast<const uint2*>(xr + (EXACT || n0 < de ? n0 : 0));
+                uint2 b = *reinterpret_cast<const uint2*>(xr + (EXACT || n1 < de ? n1 : 0));
+                if (!EXACT && n0 >= de) a = make_uint2(0u, 0u);
+                if (!EXACT && n1 >= de) b = make_uint2(0u, 0u);
+                const u32x4 v = {a.x, a.y, b.x, b.y};
+                X[sg * KBE + kb] = __builtin_bit_cast(bf16x8, v);
+            }
+        } else {
+            const float* xr = sg == 0 ? A.xa + (int64_t)edge * A.ldxa : A.xb + (int64_t)edge * A.ldxb;
+#pragma unroll
+            for (int kb = 0; kb < KBE; ++kb)
+                X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 4 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 + 4 * lh, de));
+        }
     }
     // gathered C-in of one H1 tile: Pr[row] and Pc[col], 4 row pieces each; fetched one tile ahead
     // (CIN_LOADS / PF_LOADS: the vector-memory operations cin_issue / pf_issue put behind a chunk's LDS-DMA -- what the counted
@@ -221,14 +237,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 en[o][4 * g + 0] += b.x; en[o][4 * g + 1] += b.y; en[o][4 * g + 2] += b.z; en[o][4 * g + 3] += b.w;
             }
             relu16(en[o]);
+            if (A.e_new) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(A.e_new, eo, 32 * o + 8 * g + 4 * lh, de, get4(en[o], g), edge_ok);
+                for (int g = 0; g < 4; ++g) strow<EXACT>(A.e_new, eo, 32 * o + 8 * g + 4 * lh, de, get4(en[o], g), edge_ok);
+            }
             eb[2 * o] = pack_regs(en[o], 0);
             eb[2 * o + 1] = pack_regs(en[o], 1);
-            if constexpr (SAVE) {
-                save_tile(A.save_eb, de, o, eb[2 * o], eb[2 * o + 1]);
-                mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
+            if (A.e16_out) {
+                // (plain stores: the next step's launch reads these rows)
+                uint4 lo, hi;
+                tile_rows16(eb[2 * o], eb[2 * o + 1], lo, hi);
+                const int f = 32 * o + 16 * lh;
+                unsigned short* q = A.e16_out + (size_t)edge * de + f;
+                if (edge_ok && (EXACT || f < de)) *reinterpret_cast<uint4*>(q) = lo;
+                if (edge_ok && (EXACT || f + 8 < de)) *reinterpret_cast<uint4*>(q + 8) = hi;
             }
+            if constexpr (SAVE) mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
         }
     }
     // ---- phase 3: classifier (its image is in the current buffer) -------------------------------------------------------
@@ -556,6 +580,8 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0;
     const bool save = a.save_mask != nullptr;
     if (save && !(a.save_h1 && a.save_hc && a.save_hf && a.save_eb)) { set_error("edge_chain_bf16: incomplete save buffers"); return MPNHIP_ERR_ARG; }
+    if (save) a.e16_out = a.save_eb;
+    if (!a.e_new && !a.e16_out) { set_error("edge_chain_bf16: no output for the edge features"); return MPNHIP_ERR_ARG; }
 #define MPN_CB16(SV, ...) do { if (SV) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<__VA_ARGS__, true>), dim3(blocks), dim3(four ? 256 : 512), s, a); \
                               else MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<__VA_ARGS__, false>), dim3(blocks), dim3(four ? 256 : 512), s, a); } while (0)
     switch (variant) {

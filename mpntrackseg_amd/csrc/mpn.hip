@@ -351,9 +351,14 @@ struct StepIO {
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
+// e16: bf16 mirror of the edge features of this step (FwdPlan::eb_hist): [0] the re-attached initial ones, [1] the current ones,
+// [2] where the new ones go; write_e32: the fp32 features of this step are needed (the last step's are returned / kept)
+struct StepE16 { const unsigned short* e0; const unsigned short* cur; unsigned short* out; bool write_e32; };
+
 static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, const float* Wnode, const float* bnode,
                     const StepIO& io, const StepBufs& b, bool save_arg, hipStream_t s, const ChainWeights* cw = nullptr,
-                    bool save_acts = false, const ChainBf16* cb = nullptr, unsigned short* save_eb = nullptr) {
+                    bool save_acts = false, const ChainBf16* cb = nullptr, const StepE16* e16 = nullptr) {
+    unsigned short* const save_eb = e16 ? e16->out : nullptr;
     const int64_t N = g.N, E = g.E;
     const int he = d.he, hn = d.hn;
     // (1) per-node projections P = [xa | xb] Wnode^T + bnode
@@ -381,6 +386,7 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
     // (training: only with the bf16 save buffers of FwdPlan::b16 -- save_eb is given exactly then)
     const bool chain_bf16 = !chain && cb && cb->ok && (!save_acts || save_eb) && E > 0 && io.logits && io.eb && !io.e_idx && !io.e_new_idx &&
                             !io.e_new_read_idx;
+    if (e16 && !chain_bf16) { set_error("forward: the bf16 mirror of the edge features needs the bf16 chain kernel"); return MPNHIP_ERR_ARG; }
     if (chain_bf16) {
         // (2)-(4) fused, bf16 operands / fp32 accumulation (edge_chain_bf16.hip)
         EdgeChainBf16Args a = {};
@@ -395,6 +401,10 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         // the aggregation of the messages inside the kernel (they never reach HBM); MPNHIP_NO_AGG_FUSION=1: k_aggregate as before
         // (training with max keeps the separate kernel: it records the arg max the backward needs)
         agg_done = cb->piece && !io.fuse_node && !save_arg && !getenv("MPNHIP_NO_AGG_FUSION");
+        if (e16) {
+            a.xa16 = e16->e0; a.xb16 = e16->cur; a.e16_out = e16->out;
+            if (!e16->write_e32) a.e_new = nullptr;
+        }
         if (save_acts) {
             a.save_h1 = reinterpret_cast<unsigned short*>(b.HE[0]);
             a.save_hc = reinterpret_cast<unsigned short*>(b.HC[0]);
@@ -715,7 +725,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
     }
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
-    if (p.b16 && es) MPN_TRY(to_bf16_rows(e0, p.eb_hist, (int64_t)es, s));   // the encoder output as the step-0 slot of the bf16 mirror
+    if (p.eb_hist && p.cb.ok && (!save || p.b16) && es && d.L > 0) MPN_TRY(to_bf16_rows(e0, p.eb_hist, (int64_t)es, s));   // the encoder output as slot 0 of the bf16 mirror
     const bool hoist = d.nf == 2 && d.L > 1;
     // few nodes at the reference's width: P0 and the first step's projections by one small kernel (decided with fuse_node below)
     const bool proj_small = hoist && d.dn == 32 && N > 0 && N <= 4096 && d.kx == 2 * d.dn && m.precision != MPNHIP_PREC_BF16 &&
@@ -803,8 +813,11 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.p_ready = (fuse_node && step > 0) || (proj_small && step == 0) ? 1 : 0;
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
-        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb,
-                         p.b16 ? p.eb_hist + es * cur : nullptr));
+        // (bf16-operand chain: the edge features travel between the steps as bf16 rows; the fp32 ones only where they are returned)
+        const bool e16_on = p.eb_hist && p.cb.ok && (!save || p.b16);
+        const StepE16 e16 = {p.eb_hist, p.eb_hist ? p.eb_hist + es * prev : nullptr, p.eb_hist ? p.eb_hist + es * cur : nullptr,
+                             step + 1 == d.L || getenv("MPNHIP_CHAIN_BF16_KEEP_E32") != nullptr};
+        MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb, e16_on ? &e16 : nullptr));
         prev = cur;
     }
     if (d.L == 0 && E > 0) {
@@ -995,6 +1008,8 @@ extern "C" int mpnhip_debug_saved(const mpnhip_model* model, const void* graph_b
         // the messages themselves are never stored -- their ReLU decisions are (returned as 1.0 / 0.0: what a test reads them for)
         if (what == MPNHIP_SAVED_EDGE_HIDDEN || what == MPNHIP_SAVED_CLS_HIDDEN || what == MPNHIP_SAVED_FLOW_HIDDEN)
             return chain_bf16_debug_rows(reinterpret_cast<const unsigned short*>(src), g.perm, E, width, out, s);
+        if (what == MPNHIP_SAVED_E && step >= 1 && step < d.L)   // (only the last step's fp32 features are written)
+            return chain_bf16_debug_rows(p.eb_hist + es * step, g.perm, E, width, out, s);
         if (what == MPNHIP_SAVED_MSG && m.agg != MPNHIP_AGG_MAX)
             return chain_bf16_debug_mask(reinterpret_cast<const unsigned*>(b.MK), 4, g.header, g.perm, E, d.he, d.de, d.hn, d.dn,
                                          m.classifier.out_dims[0], out, s);

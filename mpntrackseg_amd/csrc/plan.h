@@ -164,7 +164,8 @@ struct FwdPlan {
     float* splitk;             // scratch of the split-K form of the node encoder's layers (few rows, long K), or nullptr
     size_t splitk_floats;
     bool b16;                  // training in the bf16-operand mode on the fused kernels (chain_bf16_train_ok): bf16 saves
-    unsigned short* eb_hist;   // b16: [(L+1)][E, de] bf16 copies of e_hist (operands of the weight-gradient products)
+    unsigned short* eb_hist;   // [hist_slots][E, de] bf16 copies of e_hist: the chain kernel's first-layer input (b16 training and
+                               // bf16 inference) and, in training, operands of the weight-gradient products; or nullptr
     size_t total;
 };
 
@@ -252,7 +253,10 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.x_hist = a.f((size_t)p.hist_slots * N * d.dn);
     p.e_hist = a.f((size_t)p.hist_slots * E * d.de);
     p.b16 = save && cb_shapes && chain_bf16_train_ok(m, d);
-    p.eb_hist = p.b16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)p.hist_slots * E * d.de + 1) / 2)) : nullptr;
+    // (inference in the bf16-operand mode keeps the same mirror over its three history slots: the chain kernel reads its first-layer
+    // input as bf16 rows -- the values it rounds to anyway -- and writes the new features as bf16 for the next step)
+    const bool eb_inf = !save && cb_shapes && chain_bf16_ok(m, d) && d.L >= 1 && d.de % 8 == 0 && !getenv("MPNHIP_NO_CHAIN_BF16_E16");
+    p.eb_hist = (p.b16 || eb_inf) ? reinterpret_cast<unsigned short*>(a.f(((size_t)p.hist_slots * E * d.de + 1) / 2)) : nullptr;
     size_t before = a.off;
     carve_step(a, m, d, N, E, true, save && m.agg == MPNHIP_AGG_MAX, &p.step0, p.b16);
     p.step_stride_bytes = 0;
