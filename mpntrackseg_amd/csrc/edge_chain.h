@@ -163,6 +163,9 @@ struct EdgeChainBf16Args {
     const unsigned short* xa16;   // [E, de] or nullptr (then xa / ldxa, fp32)
     const unsigned short* xb16;
     unsigned short* e16_out;      // [E, de] or nullptr
+#ifdef MPNHIP_CHAIN_TS
+    long long* ts;                // debug build: 48 cycle stamps per wave
+#endif
     int debug_skip;           // MPNHIP_CHAIN_BF16_DEBUG_SKIP, timing ablations: 1 no row saves, 2 no mask words (results wrong); 4: plain
                               // instead of non-temporal row stores (A-B)
 };
@@ -198,7 +201,8 @@ int chain_bf16_debug_mask(const unsigned* mask, int section, const int* header, 
 // One pair image: nsec sections [KA first-layer units | 2 x TO second-layer units] of 1 KiB (edge_chain_bf16.hip); element
 // strides make the transposed (backward) images the same kernel
 int pack_pair_bf16_general(const float* Wa, int64_t sa_n, int64_t sa_k, int a_col0, int seg_real, int seg_pad, int nseg, int H,
-                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s);
+                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s,
+                           int a_natural = 0);
 
 // ---- backward of the bf16-operand chain (edge_chain_bf16_bwd.hip) ----
 struct EdgeChainBf16BwdArgs {

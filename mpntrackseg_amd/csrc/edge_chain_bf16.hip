@@ -24,11 +24,24 @@
 // | second-layer units of the two k blocks the tile feeds (x all output tiles)], units of 1 KiB = one MFMA A operand
 // (64 lanes x 8 bf16; element i of lane (m, g) = W[n0 + m][k0 + (i & 3) + 8 (i >> 2) + 4 g], the accumulator layout's
 // order).  A chunk = the sections of two hidden tiles, contiguous in the image, double buffered, one barrier per chunk.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "edge_chain.h"
 #include "edge_chain_bf16_common.h"
 
 namespace mpnhip {
+
+// Debug build (make EXTRA=-DMPNHIP_CHAIN_TS): lane 0 of every wave stamps s_memtime at the phase boundaries and after every hidden
+// tile; with MPNHIP_CHAIN_TS=<file prefix> in the environment the 20th launch dumps its stamps (tools/chain_stamps.py bf16)
+#ifdef MPNHIP_CHAIN_TS
+#define TS16_INIT() long long* tsp = A.ts ? A.ts + ((int64_t)blockIdx.x * NW + wave) * 48 : nullptr
+#define TS16(i) do { if (tsp && lane == 0) tsp[i] = clock64(); } while (0)
+#else
+#define TS16_INIT() do {} while (0)
+#define TS16(i) do {} while (0)
+#endif
 
 // T1 = ceil(he/32), T2 = ceil(de/32), TF = ceil(hn/32), TD = ceil(dn/32), TC = ceil(hc/32); EF = 1: first-layer input e,
 // 2: [e0 | e] (each half padded to 32 T2 columns in the image).
@@ -39,7 +52,7 @@ namespace mpnhip {
 // -- the weight-gradient products -- rounds them to bf16 anyway: exact for this mode), and every ReLU decision (H1, e', HC, HF, M)
 // as one bit in a lane-private layout the backward chain kernel (edge_chain_bf16_bwd.hip) reads back with the same (block, wave,
 // lane) -> edge mapping: word w of wave tile wt at save_mask[(wt * NWORDS + w) * 64 + lane] (chain_bf16_mask_words()).
-template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2, bool SAVE = false>
+template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2, bool SAVE = false, int DEP = DEPTH>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kernel(EdgeChainBf16Args A) {
     constexpr int EPB = 32 * NW;           // edges per block
     constexpr int DE = 32 * T2, DN = 32 * TD, HC = 32 * TC;
@@ -82,6 +95,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     const char* const img1 = static_cast<const char*>(A.img_edge);
     const char* const imgf = static_cast<const char*>(grp == 1 ? A.img_flow[1] : A.img_flow[0]);
 
+    TS16_INIT();
+    TS16(0);
     chunk_fetch<bmin(CT, T1) * SEC1, NW>(img1, WBUF(0), wave, lane);
     {
         const float* bf2 = grp == 1 ? A.bf2_in : A.bf2_out;
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
         if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
         if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
     };
-    // ---- first-layer input: this lane's edge row(s), k = 16 kb + 4h + (0..3), 16 kb + 8 + 4h + (0..3) per k block ------
+    // ---- first-layer input: this lane's edge row(s), k = 16 kb + 8 h + (0..7) per k block (natural order: pack_chain_bf16) ------
     bf16x8 X[KB1];
 #pragma unroll
     for (int sg = 0; sg < EF; ++sg) {
@@ -138,19 +153,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             const unsigned short* xr = x16 + (size_t)edge * de;
 #pragma unroll
             for (int kb = 0; kb < KBE; ++kb) {
-                const int n0 = 16 * kb + 4 * lh, n1 = n0 + 8;
-                uint2 a = *reinterpret_cast<const uint2*>(xr + (EXACT || n0 < de ? n0 : 0));
-                uint2 b = *reinterpret_cast<const uint2*>(xr + (EXACT || n1 < de ? n1 : 0));
-                if (!EXACT && n0 >= de) a = make_uint2(0u, 0u);
-                if (!EXACT && n1 >= de) b = make_uint2(0u, 0u);
-                const u32x4 v = {a.x, a.y, b.x, b.y};
+                // k = 16 kb + 8 lh + (0..7): the first-layer units are packed in this (natural) order -- one 16-byte load
+                const int n0 = 16 * kb + 8 * lh;
+                uint4 a = *reinterpret_cast<const uint4*>(xr + (EXACT || n0 < de ? n0 : 0));
+                if (!EXACT && n0 >= de) a = make_uint4(0u, 0u, 0u, 0u);
+                const u32x4 v = {a.x, a.y, a.z, a.w};
                 X[sg * KBE + kb] = __builtin_bit_cast(bf16x8, v);
             }
         } else {
             const float* xr = sg == 0 ? A.xa + (int64_t)edge * A.ldxa : A.xb + (int64_t)edge * A.ldxb;
 #pragma unroll
             for (int kb = 0; kb < KBE; ++kb)
-                X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 4 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 + 4 * lh, de));
+                X[sg * KBE + kb] = pack8(ldrow<EXACT>(xr, 0u, 16 * kb + 8 * lh, de), ldrow<EXACT>(xr, 0u, 16 * kb + 8 * lh + 4, de));
         }
     }
     // gathered C-in of one H1 tile: Pr[row] and Pc[col], 4 row pieces each; fetched one tile ahead
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) en[o][r] = 0.f;
     __syncthreads();   // chunk 0 and the biases are in LDS
+    TS16(1);
 
     // ---- phases 1 + 2: per H1 tile  H1_t = relu(W1e_t X + Pr + Pc)  ->  e' += W2[:, tile t] H1_t -----------------
     int c = 0;
@@ -216,13 +231,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                     }
                 };
                 auto act = [](f32x16& v) { relu16(v); };
-                if (tt == 0) hidden_tile<0, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
-                else hidden_tile<SEC1 * 1024, KB1, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
+                if (tt == 0) hidden_tile<0, KB1, T2, DEP>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
+                else hidden_tile<SEC1 * 1024, KB1, T2, DEP>(lds_addr(WBUF(c)) + lane * 16, X, acc, en, act, fin);
             }
         }
         // (the chunk's last tile issued the 8 gathers of the tile after it -- except the very last one: 4 or none, drain)
         if (ch * CT + nt < T1) chunk_barrier<CIN_LOADS>(A.plain_barriers != 0);
         else __syncthreads();
+        TS16(2 + (ch < 20 ? ch : 19));
         ++c;
     }
     // ---- e' = relu(. + b2): out, and as the B operand of the classifier and the flow MLPs -------------------------------
@@ -255,6 +271,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if constexpr (SAVE) mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
         }
     }
+    TS16(22);
     // ---- phase 3: classifier (its image is in the current buffer) -------------------------------------------------------
     if (flow) chunk_fetch<bmin(CT, TF) * SECF, NW>(imgf, WBUF(c + 1), wave, lane);
     {
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             }
             const unsigned wa = lds_addr(WBUF(c)) + lane * 16;
             auto cls_tile = [&](auto Q) {
-                stream_units<Q.value * SECC * 1024, KBE>(wa, [&](auto U, const bf16x8& a) {
+                stream_units<Q.value * SECC * 1024, KBE, DEP>(wa, [&](auto U, const bf16x8& a) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, eb[U.value], acc, 0, 0, 0);
                 });
             };
@@ -298,6 +315,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     if (!flow) return;  // self loops take part in the edge update only (mpn.py:85,91)
     __syncthreads();
     ++c;
+    TS16(23);
 
     // ---- phases 4 + 5: per HF tile  HF_t = relu(Wfe_t e' + Pf[col])  ->  M += Wf2[:, tile t] HF_t ----------------------
     f32x16 mm[TD];
@@ -331,14 +349,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                     }
                 };
                 auto act = [](f32x16& v) { relu16(v); };
-                if (tt == 0) hidden_tile<0, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
-                else hidden_tile<SECF * 1024, KBE, TD>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
+                if (tt == 0) hidden_tile<0, KBE, TD, DEP>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
+                else hidden_tile<SECF * 1024, KBE, TD, DEP>(lds_addr(WBUF(c)) + lane * 16, eb, acc, mm, act, fin);
             }
         }
         if (ch + 1 < NCHF) {
             chunk_barrier<PF_LOADS>(A.plain_barriers != 0);   // (the Pf gathers of the next tile stay in flight)
             ++c;
         }
+        TS16(24 + (ch < 14 ? ch : 13));
     }
     if constexpr (SAVE) {
         // ReLU decisions of the messages (the backward of node_agg_fn needs nothing else of them for sum / mean)
@@ -383,6 +402,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
         constexpr int RT = AGG_RT, FR = 32 * RT, LP = 36, ROUNDS = TD / RT;
         static_assert(TD % RT == 0 && NW * FR * LP * 4 <= WB_BYTES, "aggregation slabs do not fit the chunk buffers");
         __syncthreads();   // every wave has consumed the last weight chunk
+        TS16(38);
         float* const wl = reinterpret_cast<float*>(smem) + wave * (FR * LP);
         const int wt = blockIdx.x * NW + wave;
         const int tile_first = tile0 + wave * 32;
@@ -431,6 +451,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 }
             }
         }
+        TS16(39);
         // the segment that begins in this tile and goes on (necessarily the tile's last): where k_agg_fixup starts
         if (lane == 0) {
             int r1 = -1;
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             A.start_row[wt] = r1;
         }
     }
+    TS16(40);
 #undef WBUF
 }
 
@@ -487,6 +509,8 @@ struct PairPack {
     const float* Wa; int64_t sa_n, sa_k; int a_col0, seg_real, seg_pad, nseg, H;   // first layer: Wa[n sa_n + (a_col0 + seg seg_real + k) sa_k], n < H
     const float* Wb; int64_t sb_o, sb_k; int O;                                    // second layer: Wb[o sb_o + k sb_k], o < O, k < H
     int KA, TO;
+    int a_natural;   // first-layer units: element i of lane half g = k 16 kb + 8 g + i (the B operand comes from MEMORY: one 16-byte
+                     // load per k block) instead of the accumulator layout's order (i & 3) + 8 (i >> 2) + 4 g
     __bf16* dst;
 };
 __global__ __launch_bounds__(64) void k_pack_pair_bf16(PairPack p) {
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(64) void k_pack_pair_bf16(PairPack p) {
         const int kk = (i & 3) + 8 * (i >> 2) + 4 * g;
         float x = 0.f;
         if (r < p.KA) {
-            const int kp = 16 * r + kk, sg = kp / p.seg_pad, k = kp % p.seg_pad, n = 32 * t + m;
+            const int kp = 16 * r + (p.a_natural ? 8 * g + i : kk), sg = kp / p.seg_pad, k = kp % p.seg_pad, n = 32 * t + m;
             if (n < p.H && sg < p.nseg && k < p.seg_real) x = p.Wa[(int64_t)n * p.sa_n + (int64_t)(p.a_col0 + sg * p.seg_real + k) * p.sa_k];
         } else {
             const int q = r - p.KA, cblk = q / p.TO, o = q % p.TO;
@@ -512,8 +536,10 @@ __global__ __launch_bounds__(64) void k_pack_pair_bf16(PairPack p) {
 }
 
 int pack_pair_bf16_general(const float* Wa, int64_t sa_n, int64_t sa_k, int a_col0, int seg_real, int seg_pad, int nseg, int H,
-                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s) {
+                           const float* Wb, int64_t sb_o, int64_t sb_k, int O, int KA, int TO, int nsec, void* dst, hipStream_t s,
+                           int a_natural) {
     PairPack p = {};
+    p.a_natural = a_natural;
     p.Wa = Wa; p.sa_n = sa_n; p.sa_k = sa_k; p.a_col0 = a_col0; p.seg_real = seg_real; p.seg_pad = seg_pad > 0 ? seg_pad : 32; p.nseg = nseg; p.H = H;
     p.Wb = Wb; p.sb_o = sb_o; p.sb_k = sb_k; p.O = O; p.KA = KA; p.TO = TO; p.dst = static_cast<__bf16*>(dst);
     if (nsec * (KA + 2 * TO) <= 0) return MPNHIP_OK;
@@ -553,7 +579,8 @@ int pack_chain_bf16(const float* w_edge0, int ld_edge0, int col0_edge, int ef, c
     size_t oc, of0, of1;
     chain_bf16_image_bytes(he, de, hn, dn, hc, ef, &oc, &of0, &of1);
     char* base = static_cast<char*>(image);
-    MPN_TRY(pack_pair_bf16_general(w_edge0, ld_edge0, 1, col0_edge, de, 32 * T2, ef, he, w_edge1, he, 1, de, 2 * T2 * ef, T2, T1, base, s));
+    // (the edge MLP's first layer takes its B operand from memory: natural k order, one 16-byte load per k block and lane)
+    MPN_TRY(pack_pair_bf16_general(w_edge0, ld_edge0, 1, col0_edge, de, 32 * T2, ef, he, w_edge1, he, 1, de, 2 * T2 * ef, T2, T1, base, s, 1));
     MPN_TRY(pack_pair_bf16_general(w_cls0, de, 1, 0, de, 32 * T2, 1, hc, nullptr, 0, 0, 0, 2 * T2, 0, TC, base + oc, s));
     for (int q = 0; q < 2; ++q)
         MPN_TRY(pack_pair_bf16_general(w_flow0[q], ld_flow0, 1, col0_flow, de, 32 * T2, 1, hn, w_flow1[q], hn, 1, dn, 2 * T2, TD, TF,
@@ -578,6 +605,18 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.E + epb - 1) / epb + 3);
     count_path(PC_CHAIN_FWD_BF16);
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0;
+#ifdef MPNHIP_CHAIN_TS
+    static long long* ts_buf = nullptr;
+    static size_t ts_cap = 0;
+    static int ts_launches = 0;
+    a.ts = nullptr;
+    if (getenv("MPNHIP_CHAIN_TS")) {
+        const size_t need = (size_t)blocks * 8 * 48 * sizeof(long long);
+        if (need > ts_cap) { if (ts_buf) (void)hipFree(ts_buf); ts_cap = hipMalloc(&ts_buf, need) == hipSuccess ? need : 0; }
+        if (ts_cap) { (void)hipMemsetAsync(ts_buf, 0, need, s); a.ts = ts_buf; }
+    }
+#endif
+    static const int dep_env = [] { const char* e = getenv("MPNHIP_CHAIN16_DEPTH"); return e ? atoi(e) : 0; }();   // A-B: LDS operand reads in flight
     const bool save = a.save_mask != nullptr;
     if (save && !(a.save_h1 && a.save_hc && a.save_hf && a.save_eb)) { set_error("edge_chain_bf16: incomplete save buffers"); return MPNHIP_ERR_ARG; }
     if (save) a.e16_out = a.save_eb;
@@ -587,7 +626,9 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
     switch (variant) {
         case 256:
             // (widths that are multiples of 32 only: the masked form of this variant does not fit the register budget)
-            if (four) MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 4, 1);
+            if (four && !save && dep_env == 8) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1, false, 8>), dim3(blocks), dim3(256), s, a);
+            else if (four && !save && dep_env == 6) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1, false, 6>), dim3(blocks), dim3(256), s, a);
+            else if (four) MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 4, 1);
             else MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 8, 2);
             break;
         case 128:
@@ -600,6 +641,21 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
     }
 #undef MPN_CB16
     MPN_LAUNCH_CHECK();
+#ifdef MPNHIP_CHAIN_TS
+    if (a.ts && ++ts_launches == 20) {
+        (void)hipStreamSynchronize(s);
+        const size_t n = (size_t)blocks * (four ? 4 : 8) * 48;
+        long long* h = (long long*)malloc(n * sizeof(long long));
+        (void)hipMemcpy(h, a.ts, n * sizeof(long long), hipMemcpyDeviceToHost);
+        char path[512];
+        snprintf(path, sizeof(path), "%s_bf16fwd.txt", getenv("MPNHIP_CHAIN_TS"));
+        if (FILE* f = fopen(path, "w")) {
+            for (size_t w = 0; w < n / 48; ++w) { for (int i = 0; i < 48; ++i) fprintf(f, "%lld ", h[w * 48 + i]); fprintf(f, "\n"); }
+            fclose(f);
+        }
+        free(h);
+    }
+#endif
     if (a.agg_out) {
         hipLaunchKernelGGL(k_agg_fixup, dim3(blocks * (four ? 4 : 8)), dim3(64), 0, s, a.header, a.seg_ptr, a.start_row, a.piece, a.agg_out,
                            a.N, a.dn, (a.dn + 31) / 32 * 32, a.agg, four ? 4 : 8);

@@ -98,22 +98,22 @@ __device__ __forceinline__ void chunk_barrier(bool plain) {
 }
 __device__ __forceinline__ void pin_order() { asm volatile("" ::: "memory"); }
 
-constexpr int DEPTH = 4;   // A operands in flight per wave
+constexpr int DEPTH = 4;   // A operands in flight per wave (default; the kernels' DEP template parameter)
 
-// NU units from LDS address wa + OFF0 (+ 1 KiB per unit), DEPTH reads in flight; use(u, a) consumes unit u's A operand
-template <int OFF0, int NU, class USE>
+// NU units from LDS address wa + OFF0 (+ 1 KiB per unit), DEP reads in flight; use(u, a) consumes unit u's A operand
+template <int OFF0, int NU, int DEP = DEPTH, class USE>
 __device__ __forceinline__ void stream_units(unsigned wa, USE&& use) {
-    bf16x8 a[DEPTH];
-    static_for<0, (DEPTH - 1 < NU ? DEPTH - 1 : NU)>([&](auto U) { lds_read<OFF0 + U.value * 1024>(wa, a[U.value]); });
+    bf16x8 a[DEP];
+    static_for<0, (DEP - 1 < NU ? DEP - 1 : NU)>([&](auto U) { lds_read<OFF0 + U.value * 1024>(wa, a[U.value]); });
     static_for<0, NU>([&](auto U) {
         constexpr int u = U.value;
-        if constexpr (u + DEPTH - 1 < NU) {
-            lds_read<OFF0 + (u + DEPTH - 1) * 1024>(wa, a[(u + DEPTH - 1) % DEPTH]);
-            lds_wait<DEPTH - 1>(a[u % DEPTH]);
+        if constexpr (u + DEP - 1 < NU) {
+            lds_read<OFF0 + (u + DEP - 1) * 1024>(wa, a[(u + DEP - 1) % DEP]);
+            lds_wait<DEP - 1>(a[u % DEP]);
         } else {
-            lds_wait<0>(a[u % DEPTH]);
+            lds_wait<0>(a[u % DEP]);
         }
-        use(U, a[u % DEPTH]);
+        use(U, a[u % DEP]);
     });
 }
 
@@ -122,10 +122,10 @@ __device__ __forceinline__ void stream_units(unsigned wa, USE&& use) {
 // bf16) into out[o].  wa = LDS address of the chunk buffer (+ lane * 16), OFF0 = the section's offset in it.
 // fin(hb0, hb1): called once with the finished tile as bf16 (registers 0-7 | 8-15), before the second-layer products (the
 // tile is saved from here).
-template <int OFF0, int KA, int TO, class ACT, class FIN>
+template <int OFF0, int KA, int TO, int DEP = DEPTH, class ACT, class FIN>
 __device__ __forceinline__ void hidden_tile(unsigned wa, const bf16x8* xin, f32x16& acc, f32x16* out, ACT&& act, FIN&& fin) {
     bf16x8 hb[2];
-    stream_units<OFF0, KA + 2 * TO>(wa, [&](auto U, const bf16x8& a) {
+    stream_units<OFF0, KA + 2 * TO, DEP>(wa, [&](auto U, const bf16x8& a) {
         constexpr int u = U.value;
         if constexpr (u < KA) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xin[u], acc, 0, 0, 0);

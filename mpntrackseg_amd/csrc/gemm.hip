@@ -769,13 +769,19 @@ __global__ __launch_bounds__(256) void k_splitk_sum_l2(const float* __restrict__
 }
 
 // true (and launched) when the shape calls for it and the scratch suffices; false: the caller takes the tiled kernel
+// few output tiles, long K: up to a few hundred 64 x 64 tiles (the node encoder's first layer: 2048 -> 128 over the reference's few
+// hundred nodes, and over cfg-B's 5,000 -- 158 tiles, each walking the whole K: 104 us; four K slices: ~35 us)
+constexpr int64_t SPLITK_MAX_ROWS = 8192, SPLITK_MAX_TILES = 320;
+static inline int64_t splitk_blocks(int64_t tiles) { return tiles < 96 ? 384 : 768; }
+
 bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n, int k, int relu,
                    float* scratch, size_t scratch_floats, hipStream_t stream, int* status, SplitkNext* next) {
     *status = MPNHIP_OK;
-    if (g_precision != 0 || getenv("MPNHIP_NO_SPLITK")) return false;
+    // (fp32 MFMAs: exact fp32 products -- also what the split precision may use; the bf16-operand mode must round its operands)
+    if (g_precision == 1 || getenv("MPNHIP_NO_SPLITK")) return false;
     const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
-    if (!scratch || m <= 0 || m > 4096 || k < 512 || k % 4 != 0 || ldx % 4 != 0 || tiles >= 96 || (((uintptr_t)x | (uintptr_t)w) & 15)) return false;
-    int S = (int)(384 / tiles);
+    if (!scratch || m <= 0 || m > SPLITK_MAX_ROWS || k < 512 || k % 4 != 0 || ldx % 4 != 0 || tiles >= SPLITK_MAX_TILES || (((uintptr_t)x | (uintptr_t)w) & 15)) return false;
+    int S = (int)(splitk_blocks(tiles) / tiles);
     if (S > k / 64) S = k / 64;
     if (S < 2) return false;
     int kc = ((k + S - 1) / S + 31) / 32 * 32;
@@ -798,8 +804,8 @@ bool linear_splitk(const float* x, int64_t ldx, const float* w, const float* b, 
 
 size_t linear_splitk_scratch_floats(int64_t m, int n, int k) {
     const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
-    if (m <= 0 || m > 4096 || k < 512 || tiles >= 96) return 0;
-    int S = (int)(384 / tiles);
+    if (m <= 0 || m > SPLITK_MAX_ROWS || k < 512 || tiles >= SPLITK_MAX_TILES) return 0;
+    int S = (int)(splitk_blocks(tiles) / tiles);
     if (S > k / 64) S = k / 64;
     return S >= 2 ? (size_t)(S + 1) * m * n : 0;
 }

@@ -616,11 +616,17 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bo
     if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
     if (wp_is_small(n_out, k_in)) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                   // wp_block_small
     if (src16) {
+        // cost = the columns every operand row is staged with, summed over the output tiles (a partial last tile stages only its
+        // live columns), + a term for the accumulator tiles that stay empty (MFMAs on zeros)
         long best = -1;
         for (int v = 0; v < 8; ++v) {
             const int bo = 64 * kVariants16[v].tm, bc = 64 * kVariants16[v].tn;
             const int to = (n_out + bo - 1) / bo, tc = (k_in + bc - 1) / bc;
-            const long cost = (long)to * tc * (bo + bc) * 64 + to * tc;
+            long staged = 0;
+            for (int i = 0; i < to; ++i)
+                for (int j = 0; j < tc; ++j) staged += (n_out - i * bo < bo ? n_out - i * bo : bo) + (k_in - j * bc < bc ? k_in - j * bc : bc);
+            const long waste = (long)to * tc * bo * bc - (long)n_out * k_in;
+            const long cost = staged * 4096 + waste / 16 + to * tc;
             if (best < 0 || cost < best) { best = cost; *variant = 8 + v; *tiles_o = to; *tiles_c = tc; }
         }
         return;
