@@ -31,6 +31,10 @@
 #include "edge_chain.h"
 #include "edge_chain_bf16_common.h"
 
+#ifndef MPNHIP_ROWSTORE_AB
+#define MPNHIP_ROWSTORE_AB 1   // 0: compile the A-B switches of the row stores out
+#endif
+
 namespace mpnhip {
 
 // Debug build (make EXTRA=-DMPNHIP_CHAIN_TS): lane 0 of every wave stamps s_memtime at the phase boundaries and after every hidden
@@ -69,6 +73,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     constexpr int AGG_RT = TD >= 2 ? 2 : 1, AGG_BYTES = NW * (32 * AGG_RT) * 36 * 4;
     constexpr int WB_BYTES = bmax(2 * CHU * 1024, (AGG_BYTES + 15) / 16 * 16);
     __shared__ __attribute__((aligned(16))) char smem[WB_BYTES + (DE + 2 * HC + DN) * 4];
+    // per-wave slabs of the full-line row stores (RowStage): a separate object, never the target of an LDS-DMA
+    __shared__ __attribute__((aligned(16))) char rowslab[NW * ROW_SLAB_BYTES];
     float* const sbias = reinterpret_cast<float*>(smem + WB_BYTES);
 #define WBUF(i) (smem + ((i) & 1) * (CHU * 1024))
 
@@ -124,24 +130,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
         mw = (t & 1) ? (mw | (bits << 8)) : bits;
         if (((t & 1) || t + 1 == T) && !(A.debug_skip & 2)) mask_wt[(size_t)(wbase + (t >> 1)) * 64] = mw;
     };
-    auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
-        // 32 contiguous bytes of the edge's bf16 row per lane: features 32 t + 16 lh .. + 15 (tile_rows16)
-        // (the lane exchange needs every lane: predicate the stores only)
+    RowStage rs;
+    rs.init(rowslab + wave * ROW_SLAB_BYTES, lane, tile0 + wave * 32, end);
+    // a finished bf16 tile t of T to its rows [E, width]: tiles go out in pairs, 128 bytes per row = whole lines (RowStage); a lone
+    // last tile straight from the registers (32 contiguous bytes per lane: tile_rows16).  NT: non-temporal -- rows that are read
+    // again only in the backward pass, a whole forward later (984 -> 935 us per launch at cfg-E; MPNHIP_CHAIN_BF16_DEBUG_SKIP=4: plain)
+    auto save_tile = [&](unsigned short* base, int width, int t, int T, const bf16x8& h0, const bf16x8& h1, bool nt_ok) {
         if (A.debug_skip & 1) return;
         uint4 lo, hi;
         tile_rows16(h0, h1, lo, hi);
-        const int f = 32 * t + 16 * lh;
-        unsigned short* q = base + (size_t)edge * width + f;
-        // non-temporal: these rows are read again only in the backward pass, a whole forward later -- keeping them out of L2 takes
-        // the training forward's launch from 984 to 935 us at cfg-E (MPNHIP_CHAIN_BF16_DEBUG_SKIP=4: plain stores, A-B)
-        if (!(A.debug_skip & 4)) {
-            const u32x4 l4 = {lo.x, lo.y, lo.z, lo.w}, h4 = {hi.x, hi.y, hi.z, hi.w};
-            if (edge_ok && (EXACT || f < width)) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(q));
-            if (edge_ok && (EXACT || f + 8 < width)) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(q + 8));
+        const bool nt = nt_ok && !(A.debug_skip & 4);
+        if ((!(t & 1) && t + 1 == T) || (MPNHIP_ROWSTORE_AB && (A.debug_skip & 8))) {   // (8: A-B, every tile straight from the registers)
+            const int f = 32 * t + 16 * lh;
+            unsigned short* q = base + (size_t)edge * width + f;
+            if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
+            if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
             return;
         }
-        if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
-        if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
+        rs.put16(t & 1, lo, hi);
+        if (t & 1) {
+            if (nt) rs.flush<true>(reinterpret_cast<char*>(base), (size_t)width * 2, 64 * (t - 1), (width - 32 * (t - 1)) * 2);
+            else rs.flush<false>(reinterpret_cast<char*>(base), (size_t)width * 2, 64 * (t - 1), (width - 32 * (t - 1)) * 2);
+        }
     };
     // ---- first-layer input: this lane's edge row(s), k = 16 kb + 8 h + (0..7) per k block (natural order: pack_chain_bf16) ------
     bf16x8 X[KB1];
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 else if (flow) pf_issue(0);
                 auto fin = [&](const bf16x8& h0, const bf16x8& h1) {
                     if constexpr (SAVE) {
-                        save_tile(A.save_h1, he, t, h0, h1);
+                        save_tile(A.save_h1, he, t, T1, h0, h1, true);
                         mask_put(0, t, T1, tile_mask_bits(h0, h1, ones));
                     }
                 };
@@ -244,7 +254,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     // ---- e' = relu(. + b2): out, and as the B operand of the classifier and the flow MLPs -------------------------------
     bf16x8 eb[KBE];
     {
-        const unsigned eo = (unsigned)edge * (unsigned)de;
 #pragma unroll
         for (int o = 0; o < T2; ++o) {
 #pragma unroll
@@ -253,21 +262,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 en[o][4 * g + 0] += b.x; en[o][4 * g + 1] += b.y; en[o][4 * g + 2] += b.z; en[o][4 * g + 3] += b.w;
             }
             relu16(en[o]);
-            if (A.e_new) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) strow<EXACT>(A.e_new, eo, 32 * o + 8 * g + 4 * lh, de, get4(en[o], g), edge_ok);
+            if (A.e_new) {   // (an fp32 tile is 128 bytes per row: whole lines through the slab)
+                rs.put32(en[o]);
+                rs.flush<false>(reinterpret_cast<char*>(A.e_new), (size_t)de * 4, 128 * o, (de - 32 * o) * 4);
             }
             eb[2 * o] = pack_regs(en[o], 0);
             eb[2 * o + 1] = pack_regs(en[o], 1);
-            if (A.e16_out) {
-                // (plain stores: the next step's launch reads these rows)
-                uint4 lo, hi;
-                tile_rows16(eb[2 * o], eb[2 * o + 1], lo, hi);
-                const int f = 32 * o + 16 * lh;
-                unsigned short* q = A.e16_out + (size_t)edge * de + f;
-                if (edge_ok && (EXACT || f < de)) *reinterpret_cast<uint4*>(q) = lo;
-                if (edge_ok && (EXACT || f + 8 < de)) *reinterpret_cast<uint4*>(q + 8) = hi;
-            }
+        }
+        // (a second loop: a bf16 tile waits in the slab for its partner, and an fp32 tile in between would overwrite it)
+#pragma unroll
+        for (int o = 0; o < T2; ++o) {
+            if (A.e16_out) save_tile(A.e16_out, de, o, T2, eb[2 * o], eb[2 * o + 1], false);   // (plain stores: the next step reads these rows)
             if constexpr (SAVE) mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
         }
     }
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if constexpr (SAVE) {
                 relu16(acc);
                 const bf16x8 h0 = pack_regs(acc, 0), h1 = pack_regs(acc, 1);
-                save_tile(A.save_hc, hc, q, h0, h1);
+                save_tile(A.save_hc, hc, q, TC, h0, h1, true);
                 mask_put(WB_C, q, TC, tile_mask_bits(h0, h1, ones));
             }
             // layer 1 (out dim 1): the same operand rounding, fp32 accumulation over this lane's 16 features
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 if (t + 1 < TF) pf_issue(t + 1);
                 auto fin = [&](const bf16x8& h0, const bf16x8& h1) {
                     if constexpr (SAVE) {
-                        save_tile(A.save_hf, hn, t, h0, h1);
+                        save_tile(A.save_hf, hn, t, TF, h0, h1, true);
                         mask_put(WB_F, t, TF, tile_mask_bits(h0, h1, ones));
                     }
                 };

@@ -20,21 +20,11 @@
 #include "edge_chain.h"
 #include "edge_chain_bf16_common.h"
 
+#ifndef MPNHIP_ROWSTORE_AB
+#define MPNHIP_ROWSTORE_AB 1   // 0: compile the A-B switches of the row stores out
+#endif
+
 namespace mpnhip {
-
-namespace {
-
-// (ok: the wave holds at least one real edge -- its lanes issue the tile's stores; an all-padding wave issues none, and the
-// counted wait below must not count on them)
-template <int N>
-__device__ __forceinline__ void bwd_chunk_end(bool counted, bool wave_live) {
-    // the next chunk's LDS-DMA was issued before this chunk's tiles; behind it only the tiles' N row stores (two per tile) (exec-masked, but
-    // issued whenever the wave has a live lane).  vmcnt(N) therefore covers the DMA and leaves the stores in flight.
-    if (counted && wave_live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-    else __syncthreads();
-}
-
-}  // namespace
 
 // T1 = he / 32 ... as in edge_chain_bf16_kernel; NW waves per block, CT hidden tiles per weight chunk -- the SAME NW as the
 // forward launch of these widths (chain_bf16_geometry): the mask words are addressed by (block, wave, lane).
@@ -51,6 +41,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
     constexpr int WB_E = (T1 + 1) / 2, WB_C = WB_E + (T2 + 1) / 2, WB_F = WB_C + (TC + 1) / 2, WB_M = WB_F + (TF + 1) / 2;
     constexpr int NWORDS = WB_M + (TD + 1) / 2;
     __shared__ __attribute__((aligned(16))) char smem[2 * CHU * 1024 + HC * 4];
+    __shared__ __attribute__((aligned(16))) char rowslab[NW * ROW_SLAB_BYTES];   // full-line row stores (RowStage)
     float* const swc2 = reinterpret_cast<float*>(smem + 2 * CHU * 1024);
 #define WBUF(i) (smem + ((i) & 1) * (CHU * 1024))
 
@@ -72,8 +63,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
     const int edge_raw = tile0 + wave * 32 + lj;
     const bool edge_ok = edge_raw < end;
     const int edge = edge_ok ? edge_raw : end - 1;
-    const bool wave_live = __builtin_amdgcn_readfirstlane(tile0 + wave * 32) < end;
-    const bool counted = EXACT && !A.plain_barriers;
     const bool flow = grp < 2;
     const char* const imgf = static_cast<const char*>(grp == 1 ? A.img_flow[1] : A.img_flow[0]);
     const char* const img1 = static_cast<const char*>(A.img_edge);
@@ -83,24 +72,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
     for (int i = tid; i < HC; i += 64 * NW) swc2[i] = i < hc ? A.wc2[i] : 0.f;
 
     const unsigned* const mask_wt = A.mask + ((size_t)(blockIdx.x * NW + wave) * NWORDS) * 64 + lane;
-    // a finished dZ tile as 32 contiguous bytes of the edge's bf16 row per lane (features 32 t + 16 lh .. + 15; tile_rows16)
-    auto save_tile = [&](unsigned short* base, int width, int t, const bf16x8& h0, const bf16x8& h1) {
-        // (the lane exchange needs every lane: predicate the stores only)
+    RowStage rs;
+    rs.init(rowslab + wave * ROW_SLAB_BYTES, lane, tile0 + wave * 32, end);
+    // a finished dZ tile t of T to its bf16 rows [E, width]: in pairs, 128 bytes per row = whole lines (RowStage); a lone last tile
+    // straight from the registers.  Plain stores: the scatter-adds and the weight-gradient products read these rows right away
+    // (non-temporal: 611 -> 756 us per launch at cfg-E; MPNHIP_CHAIN_BF16_DEBUG_SKIP=4 selects them, A-B)
+    auto save_tile = [&](unsigned short* base, int width, int t, int T, const bf16x8& h0, const bf16x8& h1) {
         if (A.debug_skip & 1) return;
         uint4 lo, hi;
         tile_rows16(h0, h1, lo, hi);
-        const int f = 32 * t + 16 * lh;
-        unsigned short* q = base + (size_t)edge * width + f;
-        // (plain stores: the scatter-adds and the weight-gradient products read these rows right away -- non-temporal stores took
-        // the launch from 611 to 756 us at cfg-E; MPNHIP_CHAIN_BF16_DEBUG_SKIP=4 selects them, A-B)
-        if (A.debug_skip & 4) {
-            const u32x4 l4 = {lo.x, lo.y, lo.z, lo.w}, h4 = {hi.x, hi.y, hi.z, hi.w};
-            if (edge_ok && (EXACT || f < width)) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(q));
-            if (edge_ok && (EXACT || f + 8 < width)) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(q + 8));
+        if ((!(t & 1) && t + 1 == T) || (MPNHIP_ROWSTORE_AB && (A.debug_skip & 8))) {   // (8: A-B, every tile straight from the registers)
+            const int f = 32 * t + 16 * lh;
+            unsigned short* q = base + (size_t)edge * width + f;
+            if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
+            if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
             return;
         }
-        if (edge_ok && (EXACT || f < width)) *reinterpret_cast<uint4*>(q) = lo;
-        if (edge_ok && (EXACT || f + 8 < width)) *reinterpret_cast<uint4*>(q + 8) = hi;
+        rs.put16(t & 1, lo, hi);
+        if (t & 1) {
+            if (A.debug_skip & 4) rs.flush<true>(reinterpret_cast<char*>(base), (size_t)width * 2, 64 * (t - 1), (width - 32 * (t - 1)) * 2);
+            else rs.flush<false>(reinterpret_cast<char*>(base), (size_t)width * 2, 64 * (t - 1), (width - 32 * (t - 1)) * 2);
+        }
     };
     const float dl = A.dlog[A.perm[edge]];
 
@@ -145,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
                 if (t & 1) apply_mask16<1>(v, mw); else apply_mask16<0>(v, mw);
                 X[2 * t] = pack_regs(v, 0);
                 X[2 * t + 1] = pack_regs(v, 1);
-                save_tile(A.dZM, dn, t, X[2 * t], X[2 * t + 1]);
+                save_tile(A.dZM, dn, t, TD, X[2 * t], X[2 * t + 1]);
             }
         }
         __syncthreads();   // chunk 0 and wc2 are in LDS (every load above has landed)
@@ -170,13 +162,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const unsigned mw = mwf[t >> 1];
                     auto act = [&](f32x16& v) { if (t & 1) apply_mask16<1>(v, mw); else apply_mask16<0>(v, mw); };
-                    auto fin = [&](const bf16x8& h0, const bf16x8& h1) { save_tile(A.dZF, hn, t, h0, h1); };
+                    auto fin = [&](const bf16x8& h0, const bf16x8& h1) { save_tile(A.dZF, hn, t, TF, h0, h1); };
                     if (tt == 0) hidden_tile<0, KBM, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, dEa, act, fin);
                     else hidden_tile<SECF * 1024, KBM, T2>(lds_addr(WBUF(c)) + lane * 16, X, acc, dEa, act, fin);
                 }
             }
-            if (nt == CT) bwd_chunk_end<2 * CT>(counted, wave_live);
-            else bwd_chunk_end<2>(counted, wave_live);
+            __syncthreads();   // (counted waits that leave the row stores in flight measured the same: 42.0 vs 42.4 ms per cfg-E step)
             ++c;
         }
     } else {
@@ -213,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
             }
             if (q & 1) apply_mask16<1>(v, mwc); else apply_mask16<0>(v, mwc);
             bf16x8 hb[2] = {pack_regs(v, 0), pack_regs(v, 1)};
-            save_tile(A.dZc, hc, q, hb[0], hb[1]);
+            save_tile(A.dZc, hc, q, TC, hb[0], hb[1]);
             const unsigned wa = lds_addr(WBUF(c)) + lane * 16;
             auto cls_tile = [&](auto Q) {
                 stream_units<Q.value * SECC * 1024, 2 * T2>(wa, [&](auto U, const bf16x8& a) {
@@ -239,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
             if (o & 1) apply_mask16<1>(dEa[o], mwe); else apply_mask16<0>(dEa[o], mwe);
             X2[2 * o] = pack_regs(dEa[o], 0);
             X2[2 * o + 1] = pack_regs(dEa[o], 1);
-            save_tile(A.dZ2, de, o, X2[2 * o], X2[2 * o + 1]);
+            save_tile(A.dZ2, de, o, T2, X2[2 * o], X2[2 * o + 1]);
         }
     }
     // dE_prev accumulators; at the first step e_{s-1} IS the re-attached e0: add into its running gradient (read here, used as C-in)
@@ -277,23 +268,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_bwd_
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 const unsigned mw = mw1[t >> 1];
                 auto act = [&](f32x16& v) { if (t & 1) apply_mask16<1>(v, mw); else apply_mask16<0>(v, mw); };
-                auto fin = [&](const bf16x8& h0, const bf16x8& h1) { save_tile(A.dZ1, he, t, h0, h1); };
+                auto fin = [&](const bf16x8& h0, const bf16x8& h1) { save_tile(A.dZ1, he, t, T1, h0, h1); };
                 if (tt == 0) hidden_tile<0, KBE, T2>(lds_addr(WBUF(c)) + lane * 16, X2, acc, dp, act, fin);
                 else hidden_tile<SEC1 * 1024, KBE, T2>(lds_addr(WBUF(c)) + lane * 16, X2, acc, dp, act, fin);
             }
         }
         if (ch + 1 < NCH1) {
-            if (nt == CT) bwd_chunk_end<2 * CT>(counted, wave_live);
-            else bwd_chunk_end<2>(counted, wave_live);
+            __syncthreads();
             ++c;
         }
     }
-    {
-        const unsigned eo = (unsigned)edge * (unsigned)de;
 #pragma unroll
-        for (int o = 0; o < T2; ++o)
+    for (int o = 0; o < T2; ++o) {   // (fp32 tiles: 128 bytes per row, whole lines through the slab)
+        if (MPNHIP_ROWSTORE_AB && (A.debug_skip & 16)) {
+            const unsigned eo = (unsigned)edge * (unsigned)de;
 #pragma unroll
             for (int g = 0; g < 4; ++g) strow<EXACT>(dst, eo, 32 * o + 8 * g + 4 * lh, de, get4(dp[o], g), edge_ok);
+            continue;
+        }
+        rs.put32(dp[o]);
+        rs.flush<false>(reinterpret_cast<char*>(dst), (size_t)de * 4, 128 * o, (de - 32 * o) * 4);
     }
 #undef WBUF
 }
