@@ -21,7 +21,7 @@ $(TORCH_LIB): $(CSRC)/torch_ops.cpp include/mpnhip.h $(LIB)
 	    -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
 	    $< -o $@ -L$(CSRC) -lmpnhip -L$(TORCH_DIR)/lib -lc10 -lc10_hip -ltorch_cpu -ltorch_hip -ltorch -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h $(CSRC)/edge_chain_bf16_common.h include/mpnhip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/plan.h $(CSRC)/edge_chain.h $(CSRC)/edge_chain_bf16_common.h $(CSRC)/row_stage.h include/mpnhip.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

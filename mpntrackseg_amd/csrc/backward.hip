@@ -242,6 +242,7 @@ struct BwdPlan {
     // zero-padded copies of the per-edge weights for the fused backward chain (native [n][k] orientation)
     float* wf2p[2]; float* wfep[2]; float* wc1p; float* w2p; float* w1ep;
     float* gWnode;                      // [pw, kx] gradient of the packed node-projection weights
+    unsigned short* ncb_img;            // unit images of the fused node-side backward kernel (node_chain.hip) or nullptr
     float* wt_scratch;                  // MPNHIP_PREC_BF16: transposed weight blocks of the activation-gradient products
     size_t wt_scratch_floats;
     // bf16-operand training on the fused kernels (FwdPlan::b16): the dZ blocks above are bf16 rows (half the floats), the gradient
@@ -322,6 +323,9 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
         p.w1ep = a.f(HE * 2 * DE * 3 / 2);
     }
     p.gWnode = a.f((size_t)d.pw * d.kx);
+    p.ncb_img = nullptr;
+    if (node_chain_bwd_supported(d.dn, d.pw, d.kx) && m.node.n_layers == 1 && m.precision == MPNHIP_PREC_FP32_SPLIT)
+        p.ncb_img = reinterpret_cast<unsigned short*>(a.f((node_chain_bwd_image_shorts(d.dn, d.pw, nullptr) + 1) / 2));
     {   // MPNHIP_PREC_BF16: transposition scratch of the activation-gradient products (two direction groups of the largest weight)
         size_t mx = (size_t)d.pw * d.kx;
         const mpnhip_mlp* all[] = {&m.enc_node, &m.enc_edge, &m.edge, &m.flow_in, &m.flow_out, &m.node, &m.classifier};
@@ -990,6 +994,13 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     bool dx_split = false;   // the gradient w.r.t. x_s arrived as two K halves (p.dX[cx] + p.dXh)
     bool node_a_done = false;   // dZn / dAGG of the coming step were already produced by node_step32_bwd
     // (k_node_step32_bwd stages the weights in LDS: 128 pw + 8 KB + ... <= 64 KB, 16-byte aligned rows)
+    // wider models in the split precision: the same three launches as one MFMA kernel (node_chain.hip, node_chain_bwd_kernel)
+    const bool fuse_node_chain_bwd = p.ncb_img && !g_bwd_bf16 && N > 0 && L > 1 && d.nf == 2;
+    size_t ncb_off_wu = 0;
+    if (fuse_node_chain_bwd) {
+        node_chain_bwd_image_shorts(dn, pw, &ncb_off_wu);
+        MPN_TRY(pack_node_chain_bwd(m.node.weight[0], f.Wnode, dn, pw, kx, p.ncb_img, s));
+    }
     const bool fuse_node_bwd = !g_bwd_bf16 && dn == 32 && N <= 4096 && pw <= 384 && kx % 4 == 0 &&
                                ((((uintptr_t)f.Wnode) | ((uintptr_t)m.node.weight[0])) & 15) == 0 && !getenv("MPNHIP_NO_NODE_FUSION");
 
@@ -1121,6 +1132,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 // in one launch (segment.hip, node_step32_bwd); the next iteration starts at the chain kernel
                 MPN_TRY(node_step32_bwd(dP, (int)N, pw, f.Wnode + dn, kx, f.x_hist + xs * (step - 1), m.node.weight[0],
                                         p.dZn + (size_t)(b_ - 1) * xs, p.dAGG, s));
+                node_a_done = true;
+            } else if (hoist_x && step > 1 && fuse_node_chain_bwd) {
+                NodeChainBwdArgs a = {(int)N, dn, pw, dP, p.ncb_img, f.x_hist + xs * (step - 1), p.ncb_img + ncb_off_wu,
+                                      p.dZn + (size_t)(b_ - 1) * xs, p.dAGG};
+                MPN_TRY(launch_node_chain_bwd(a, s));
                 node_a_done = true;
             } else if (hoist_x && step > 1 && pw % 8 == 0 && N * 2 < 2000000000 && !g_bwd_bf16) {
                 // [N, pw] x [pw, dn] is 157 tiles of 64 x 64 at cfg-B -- not enough blocks for 256 CUs and 34 K steps each: the two K

@@ -250,6 +250,23 @@ bool node_chain_supported(int dn, int pw, int kx);
 size_t node_chain_image_shorts(int dn, int pw, size_t* off_wx);
 int pack_node_chain(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s);
 int launch_node_chain(const NodeChainArgs& a, hipStream_t s);
+// ... and its backward mirror: dX = dP Wx, dZn = dX (.) [x_prev > 0], dAGG = dZn Wu in one launch
+struct NodeChainBwdArgs {
+    int N, dn, pw;
+    const float* dP;                 // [N, pw] gradient of this step's projections
+    const unsigned short* wxT_img;   // packed units (pack_node_chain_bwd)
+    const float* x_prev;             // [N, dn] output of the previous step's node update (its ReLU mask)
+    const unsigned short* wuT_img;
+    float* dZn;                      // [N, dn] out: gradient at the previous step's node-update pre-activation
+    float* dAGG;                     // [N, 2 dn] out
+#ifdef MPNHIP_NODE_BWD_DEBUG
+    int debug;                       // ablation build (make EXTRA=-DMPNHIP_NODE_BWD_DEBUG): 1 no phase-1 MFMAs, 2 no phase 3, 4 no phase 1
+#endif
+};
+bool node_chain_bwd_supported(int dn, int pw, int kx);
+size_t node_chain_bwd_image_shorts(int dn, int pw, size_t* off_wu);
+int pack_node_chain_bwd(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s);
+int launch_node_chain_bwd(const NodeChainBwdArgs& a, hipStream_t s);
 // the whole step loop of an inference forward at the reference's widths in one launch (persist32.hip)
 struct Persist32Args {
     int N, L, agg, pw, he, hn, hc, nodes_per_block;
@@ -329,7 +346,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_NODE_CHAIN_BWD, PC_COUNT
 };
 void count_path(int id);
 

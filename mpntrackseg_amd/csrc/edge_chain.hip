@@ -21,8 +21,11 @@
 // pieces beyond the real width are masked on load / store), so one template serves the BASELINE.json 128-d
 // configuration (he 320, de 64, hn 224, dn 128, hc 32 -> tiles 10/2/7/4), the reference's shipped 32-d dims
 // (80/16/56/32/8 -> 3/1/2/1) and 64-d (5/1/4/2); anything else uses the unfused GEMM path.
+#include <type_traits>
+
 #include "common.h"
 #include "edge_chain.h"
+#include "row_stage.h"
 #ifdef MPNHIP_CHAIN_TS
 #include <cstdio>
 #include <string>
@@ -192,9 +195,7 @@ __device__ __forceinline__ Split8 split_regs(const f32x16& s, int r0) {
     return r0 == 0 ? split8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]) : split8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
 }
 
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
+// (lds_addr: row_stage.h)
 // The three pieces of one unit.  Inline assembly on purpose: a compiler-visible ds_read_b128 of the object the LDS-DMA
 // writes into is preceded by s_waitcnt vmcnt(0) (the next chunk's DMA would be drained in front of every operand
 // fetch); the waits for these reads are placed by hand (lds_wait: LDS operations of a wave complete in order).
@@ -372,6 +373,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_kernel(EdgeCh
     const int K1 = A.k1a + A.k1b;                 // columns of [e0 | e] (multiples of 16)
     const int nch1 = K1 / KC1;
     const bool flow = grp < 2;
+    // (Row stores of the FORWARD kernel stay as they are -- 16-byte pieces straight from the accumulator layout.  Measured with the
+    // backward kernel's slab scheme (row_stage.h; slabs in place of the phase-1 staging buffers + 2 KB): all saves through slabs 83.3 ->
+    // 88.7 us per training launch (30 registers spilled at the phase-2 peak), HC / HF / M only 83.0 us: the forward is not bound
+    // by its stores.)
     // (wave-uniform base + lane: no address registers; rows of P / Q0 / save_h1 are addressed as base + 32-bit offset)
     unsigned* const mkb = A.save_mask ? A.save_mask + (int64_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave) * NW * 64 : nullptr;
 #define MKP(w) mkb[(w) * 64 + lane]
@@ -768,6 +773,29 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     // registers -- inputs are negated as they are loaded, outputs as they are stored -- and the bias enters neighbouring edges
     // with opposite signs: zero mean over any sum.
     const unsigned sx = SP && (lj & 1) ? 0x80000000u : 0u;
+    // dZ rows leave through a per-wave LDS slab as whole 128-byte lines (row_stage.h; tools/micro/store_pattern.hip: the 16-byte
+    // pieces of 32 different rows a wave instruction writes straight from the accumulator layout run at 1.65 TB/s, 8 whole lines
+    // per instruction at 5.4).  The 128-d template only: 18 KB more LDS per block would cost the narrower ones their third wave.
+#ifdef MPNHIP_CHAIN_DIRECT_ROWS
+    constexpr bool SLAB = false;     // (A-B build: make EXTRA=-DMPNHIP_CHAIN_DIRECT_ROWS)
+#else
+    constexpr bool SLAB = T1 >= 10;
+#endif
+    __shared__ __attribute__((aligned(16))) char rowslab[SLAB ? 4 * ROW_SLAB_BYTES : 16];   // (touched by inline assembly only)
+    RowStage rs;
+    rs.init(rowslab + (SLAB ? wave * ROW_SLAB_BYTES : 0), lane, tile0 + wave * 32, end);
+    // tile t (32 columns) of this wave's rows of a row-major [*, width] matrix; v in the sign the memory image has
+    auto store_tile = [&](float* mat, int width, int t, const f32x16& v) {
+        if constexpr (SLAB) {
+            rs.put32v(v);   // (every tile stored here went through a ReLU / mask / sign flip: VALU results)
+            rs.template flush<false>(reinterpret_cast<char*>(mat), (size_t)width * 4, 128 * t, (width - 32 * t) * 4);
+        } else {
+            float* o2 = mat + (int64_t)edge * width;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, width, get4(v, g), edge_ok);
+        }
+    };
+    auto flipped = [&](const f32x16& a) { f32x16 v = a; flip16(v, sx); return v; };
     const int KEp = A.cat_two ? 2 * DE : DE;  // padded columns of [e0 | e_{s-1}] (each half padded to DE)
     const int npass6 = KEp / 64 > 0 ? KEp / 64 : 1;
     const int ncol6 = KEp < 64 ? KEp : 64;    // columns per B6 pass
@@ -842,12 +870,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     if (flow) {
         // ---- B1: dZM = gathered gradient (.) [M > 0] -----------------------------------------------------------
         {
-            float* o2 = A.dZM + (int64_t)edge * dn;
 #pragma unroll
             for (int t = 0; t < TD; ++t) {
                 apply_mask(dzm[t], mk[W_M + (t >> 1)], 16 * (t & 1));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, dn, get4(dzm[t], g), edge_ok);
+                store_tile(A.dZM, dn, t, dzm[t]);
                 if (SP) flip16(dzm[t], sx);
             }
         }
@@ -873,12 +899,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
         }
         TS(3);
         {
-            float* o2 = A.dZF + (int64_t)edge * hn;
 #pragma unroll
             for (int t = 0; t < TF; ++t) {
                 apply_mask(dzf[t], mk[W_HF + (t >> 1)], 16 * (t & 1));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, hn, flip4(get4(dzf[t], g), sx), edge_ok);
+                store_tile(A.dZF, hn, t, flipped(dzf[t]));
             }
         }
         TS(4);
@@ -922,11 +946,7 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
             set4(dzc, g, make_float4(dls * w.x, dls * w.y, dls * w.z, dls * w.w));
         }
         apply_mask(dzc, mk[W_HC], 0);
-        {
-            float* o2 = A.dZc + (int64_t)edge * hc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 8 * g + 4 * lh, hc, flip4(get4(dzc, g), sx), edge_ok);
-        }
+        store_tile(A.dZc, hc, 0, flipped(dzc));
         chunk_fetch<chunk_q(N4_5), SP>(A.w2, N4_5, tid, wbuf_at(c + 1));
         if constexpr (SP) chain_units<T2, 2>(dzc, 0, dE, lds_addr(wbuf_at(c)) + lane * 16, T2, 0, 0);
         else chain_tile<T2>(dzc, dE, wbuf_at(c), DE, 0, 0, 4 * lh * DE + lj);
@@ -935,12 +955,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     }
     // dZ2 = dE' (.) [e_s > 0]  (written over the incoming gradient)
     {
-        float* o2 = A.dE_io + (int64_t)edge * de;
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
             apply_mask(dE[t], mk[W_E + (t >> 1)], 16 * (t & 1));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, de, flip4(get4(dE[t], g), sx), edge_ok);
+            store_tile(A.dE_io, de, t, flipped(dE[t]));
         }
     }
 
@@ -973,12 +991,10 @@ __global__ __launch_bounds__(256, chain_waves(T1)) void edge_chain_bwd_kernel(Ed
     }
     TS(7);
     {
-        float* o2 = A.dZ1 + (int64_t)edge * he;
 #pragma unroll
         for (int t = 0; t < T1; ++t) {
             apply_mask(dz1[t], mk[W_H1 + (t >> 1)], 16 * (t & 1));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) strow<EXACT>(o2, 32 * t + 8 * g + 4 * lh, he, flip4(get4(dz1[t], g), sx), edge_ok);
+            store_tile(A.dZ1, he, t, flipped(dz1[t]));
         }
     }
 

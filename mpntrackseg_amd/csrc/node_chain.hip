@@ -208,9 +208,175 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
     }
 }
 
-// units [tile t][k block kb][piece]: lane (m = lane & 31, g = lane >> 5), element i = piece(W[32 t + m][col0 + 16 kb + 8 g + i])
+
+// The node side of one step of the BACKWARD pass in one launch (the mirror of the kernel above; autograd of mpn.py:97-99 and of the
+// per-node projections): for the 32 nodes of a block
+//   dX    = dP Wx                       [32 x pw] x [pw x dn]   gradient w.r.t. x_{s-1} through step s's projections
+//   dZn   = dX (.) [x_{s-1} > 0]        ReLU of step s-1's node update
+//   dAGG  = dZn Wu                      [32 x dn] x [dn x 2 dn]
+// Before: a grouped GEMM of 2 x 158 blocks and 34 K steps each (28 us at cfg-B), k_relu_mask (5 us) and a GEMM (10 us) on the
+// caller's stream between two chain kernels.  Split operands as everywhere in MPNHIP_PREC_FP32_SPLIT: three bf16 pieces, six MFMAs.
+//   1. the pw / 16 contraction blocks of the first product are dealt to the block's NWV waves round-robin; a wave splits ITS blocks of
+//      the dP rows once (32 bytes per lane and block, straight from global memory) and multiplies them into all dn / 32 output
+//      tiles; weight units from L2 as in the forward kernel, NB blocks ahead;
+//   2. the partial tiles meet in LDS; wave t sums tile t, applies the mask, stores dZn rows and leaves the tile in LDS;
+//   3. every wave takes every NWV-th 32-column tile of dAGG (dn / 16 blocks each).
+// Measured at cfg-B (N = 5000: 157 blocks, K = 1088; ablation build make EXTRA=-DMPNHIP_NODE_BWD_DEBUG, rocprofv3 minimum of 275
+// launches): 22.1 us whole, 20.7 without the phase-1 MFMAs, 19.1 without phase 3, 8.4 without phase 1, 4.7 without both -- the 12 us
+// of phase 1 are its loads: every block pulls the same 835 KB of weight units (+ 139 KB of dP rows) through its CU's L1 at
+// ~37 bytes per clock.  The three launches it replaces took 28 + 5 + 10 us.
+template <int DT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void node_chain_bwd_kernel(NodeChainBwdArgs A) {
+    constexpr int DN = 32 * DT, KB1 = DN / 16, XP = DN + 4;
+    constexpr int NB = NWV > 4 ? 2 : 4;          // contraction blocks of weight units / dP pieces in flight per wave (phase 1)
+    __shared__ __attribute__((aligned(16))) float part_s[NWV * DT * 4 * 64 * 4];   // [wave][tile][g][lane][4]
+    __shared__ __attribute__((aligned(16))) float z_s[32 * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int N = A.N;
+    const int node = n0 + lj < N ? n0 + lj : N - 1;
+    const bool ok = n0 + lj < N;
+    const int KBP = A.pw / 16;
+    // v_mfma_f32_32x32x16_bf16 adds its products with a small bias toward -infinity (tools/micro/mfma_bias.hip); every sum the
+    // backward takes over nodes / edges would add it up coherently.  As in the split backward chain kernel (edge_chain.hip) the
+    // gradients of every other node are kept NEGATED in the registers and LDS (flipped as they are loaded and as they are stored)
+    const unsigned sx = (lj & 1) ? 0x80000000u : 0u;
+    auto fx = [&](float v) { return __uint_as_float(__float_as_uint(v) ^ sx); };
+    auto fx4 = [&](float4 v) { return make_float4(fx(v.x), fx(v.y), fx(v.z), fx(v.w)); };
+
+    // ---- 1. partial dX^T tiles over this wave's contraction blocks wave, wave + 4, ... -------------------------------------
+    {
+        f32x16 acc[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const int cnt = (KBP - wave + NWV - 1) / NWV;    // >= NB is not required: out-of-range blocks are clamped to the last one and unused
+        const float* dpr = A.dP + (int64_t)node * A.pw + 8 * lh;
+        const int start = cnt > 0 ? (int)((blockIdx.x * 5u) % (unsigned)cnt) : 0;
+        bf16x8 ring[NB][DT][3];
+        float4 xr[NB][2];
+        auto fetch = [&](int it, int slot) {
+            // (every block walks its blocks from a different start: all N / 32 blocks stream the same image -- started together on
+            // the same units they queue on the same L2 channels, as in the forward kernel)
+            int ii = (it < cnt ? it : cnt - 1) + start;
+            ii = ii >= cnt ? ii - cnt : ii;
+            const int kb = wave + NWV * ii;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) ld_units(A.wxT_img, (t * KBP + kb) * 3, lane, ring[slot][t]);
+            xr[slot][0] = *reinterpret_cast<const float4*>(dpr + 16 * kb);
+            xr[slot][1] = *reinterpret_cast<const float4*>(dpr + 16 * kb + 4);
+        };
+#ifdef MPNHIP_NODE_BWD_DEBUG
+        if (cnt > 0 && !(A.debug & 4)) {
+#else
+        if (cnt > 0) {
+#endif
+#pragma unroll
+            for (int q = 0; q < NB; ++q) fetch(q, q);
+            // whole rounds of NB blocks WITHOUT a branch inside (a conditional stage makes hipcc's wait-count pass merge two load
+            // orders at every join: it then drains vmcnt(0) before each stage -- no loads in flight under the MFMAs, 24 us instead
+            // of ~12 at cfg-B), then the remaining < NB stages
+            const int full = cnt / NB;
+            for (int r = 0; r < full; ++r) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const NSplit8 b = nsplit8(fx4(xr[q][0]), fx4(xr[q][1]));
+#ifdef MPNHIP_NODE_BWD_DEBUG
+                    if (A.debug & 1) {
+#pragma unroll
+                        for (int t = 0; t < DT; ++t)
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) asm volatile("" ::"v"(ring[q][t][u]), "v"(b.p[u]));
+                    } else
+#endif
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) nmfma6(acc[t], ring[q][t], b);
+                    fetch((r + 1) * NB + q, q);
+                    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would hoist every stage's split to the top of the round: a full drain)
+                }
+            }
+            const int rem = cnt - full * NB;
+#pragma unroll
+            for (int q = 0; q < NB - 1; ++q) {
+                if (q < rem) {               // (wave-uniform)
+                    const NSplit8 b = nsplit8(fx4(xr[q][0]), fx4(xr[q][1]));
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) nmfma6(acc[t], ring[q][t], b);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&part_s[(((wave * DT + t) * 4 + g) * 64 + lane) * 4]) =
+                    make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+    __syncthreads();
+
+    // ---- 2. dZn tile `wave` = (sum of the partials) (.) [x_prev > 0] -----------------------------------------------------
+    if (wave < DT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = *reinterpret_cast<const float4*>(&part_s[(((0 * DT + wave) * 4 + g) * 64 + lane) * 4]);
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) {
+                const float4 u = *reinterpret_cast<const float4*>(&part_s[(((w * DT + wave) * 4 + g) * 64 + lane) * 4]);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const int n = 32 * wave + 8 * g + 4 * lh;
+            const float4 x = *reinterpret_cast<const float4*>(A.x_prev + (int64_t)node * DN + n);
+            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+            *reinterpret_cast<float4*>(&z_s[lj * XP + n]) = v;
+            if (ok) *reinterpret_cast<float4*>(A.dZn + (int64_t)(n0 + lj) * DN + n) = fx4(v);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. dAGG = dZn Wu: tiles wave, wave + 4, ... of the 2 dn columns ---------------------------------------------------------
+    {
+        NSplit8 bz[KB1];
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            const float* zr = &z_s[lj * XP + 16 * kb + 8 * lh];
+            bz[kb] = nsplit8(*reinterpret_cast<const float4*>(zr), *reinterpret_cast<const float4*>(zr + 4));
+        }
+        constexpr int NT = 2 * DT;
+        float* out = A.dAGG + (int64_t)node * (2 * DN) + 4 * lh;
+        bf16x8 ring[KB1][3];
+        if (wave < NT) {
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) ld_units(A.wuT_img, (wave * KB1 + kb) * 3, lane, ring[kb]);
+        }
+#ifdef MPNHIP_NODE_BWD_DEBUG
+        if (A.debug & 2) return;
+#endif
+        for (int t = wave; t < NT; t += NWV) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int tn = t + NWV < NT ? t + NWV : t;
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) {
+                nmfma6(acc, ring[kb], bz[kb]);
+                ld_units(A.wuT_img, (tn * KB1 + kb) * 3, lane, ring[kb]);
+            }
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(out + 32 * t + 8 * g) = fx4(make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+            }
+        }
+    }
+}
+
+// units [tile t][k block kb][piece]: lane (m = lane & 31, g = lane >> 5), element i = piece(A[32 t + m][16 kb + 8 g + i]) of the
+// logical [n_out x K] operand A[n][k] = W[n * ldw + (col0 + k) * sk]  (sk = 1: rows of W; the backward's transposed operands
+// read W column-wise: ldw = 1, sk = W's row pitch)
 __global__ __launch_bounds__(64) void k_pack_node_units(const float* __restrict__ W, int64_t ldw, int col0, int n_out, int K,
-                                                         unsigned short* __restrict__ dst) {
+                                                         unsigned short* __restrict__ dst, int64_t sk = 1) {
     const int lane = threadIdx.x, m = lane & 31, g = lane >> 5;
     const int kbs = (K + 15) / 16;
     const int t = blockIdx.x / kbs, kb = blockIdx.x - t * kbs;
@@ -218,7 +384,7 @@ __global__ __launch_bounds__(64) void k_pack_node_units(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n = 32 * t + m, k = 16 * kb + 8 * g + i;
-        x[i] = (n < n_out && k < K) ? W[(int64_t)n * ldw + col0 + k] : 0.f;
+        x[i] = (n < n_out && k < K) ? W[(int64_t)n * ldw + (int64_t)(col0 + k) * sk] : 0.f;
     }
     const NSplit8 s = nsplit8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
     uint4* out = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * 3 * 512) + lane;
@@ -253,6 +419,46 @@ int launch_node_chain(const NodeChainArgs& a, hipStream_t s) {
     if (a.dn == 128) hipLaunchKernelGGL(node_chain_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
     else if (a.dn == 64) hipLaunchKernelGGL(node_chain_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
     else { set_error("node_chain: unsupported width %d", a.dn); return MPNHIP_ERR_UNSUPPORTED; }
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+bool node_chain_bwd_supported(int dn, int pw, int kx) {
+    return (dn == 64 || dn == 128) && pw % 16 == 0 && pw >= 64 && kx == 2 * dn && !getenv("MPNHIP_NO_NODE_CHAIN_BWD");
+}
+size_t node_chain_bwd_image_shorts(int dn, int pw, size_t* off_wu) {
+    const size_t wx = (size_t)(dn / 32) * (pw / 16) * 3 * 512;
+    if (off_wu) *off_wu = wx;
+    return wx + (size_t)(2 * dn / 32) * (dn / 16) * 3 * 512;
+}
+// the transposed operands: A1[k][p] = Wnode[p][dn + k] (dn x pw), A2[c][k] = Wu[k][c] (2 dn x dn)
+int pack_node_chain_bwd(const float* Wu, const float* Wnode, int dn, int pw, int kx, unsigned short* img, hipStream_t s) {
+    size_t off = 0;
+    node_chain_bwd_image_shorts(dn, pw, &off);
+    hipLaunchKernelGGL(k_pack_node_units, dim3((dn / 32) * (pw / 16)), dim3(64), 0, s, Wnode + dn, (int64_t)1, 0, dn, pw, img, (int64_t)kx);
+    hipLaunchKernelGGL(k_pack_node_units, dim3((2 * dn / 32) * (dn / 16)), dim3(64), 0, s, Wu, (int64_t)1, 0, 2 * dn, dn, img + off, (int64_t)2 * dn);
+    MPN_LAUNCH_CHECK();
+    return MPNHIP_OK;
+}
+
+int launch_node_chain_bwd(const NodeChainBwdArgs& a_in, hipStream_t s) {
+    if (a_in.N <= 0) return MPNHIP_OK;
+    count_path(PC_NODE_CHAIN_BWD);
+#ifdef MPNHIP_NODE_BWD_DEBUG
+    NodeChainBwdArgs a = a_in;
+    a.debug = getenv("MPNHIP_NODE_BWD_DEBUG") ? atoi(getenv("MPNHIP_NODE_BWD_DEBUG")) : 0;
+#else
+    const NodeChainBwdArgs& a = a_in;
+#endif
+    const unsigned blocks = (unsigned)((a.N + 31) / 32);
+    // (4 or 8 waves per block -- one or two per SIMD -- measure the same, 21.3 / 21.0 us at cfg-B: the launch is bound by the weight
+    // units every block streams from L2, see below; 4 is the default for its smaller LDS footprint beside the side stream's blocks)
+    static const int nwv = getenv("MPNHIP_NODE_BWD_WAVES") ? atoi(getenv("MPNHIP_NODE_BWD_WAVES")) : 4;
+    if (a.dn == 128 && nwv == 4) hipLaunchKernelGGL((node_chain_bwd_kernel<4, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.dn == 128) hipLaunchKernelGGL((node_chain_bwd_kernel<4, 8>), dim3(blocks), dim3(512), 0, s, a);
+    else if (a.dn == 64 && nwv == 4) hipLaunchKernelGGL((node_chain_bwd_kernel<2, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.dn == 64) hipLaunchKernelGGL((node_chain_bwd_kernel<2, 8>), dim3(blocks), dim3(512), 0, s, a);
+    else { set_error("node_chain_bwd: unsupported width %d", a.dn); return MPNHIP_ERR_UNSUPPORTED; }
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -201,3 +201,33 @@ def test_split_backward_is_unbiased_against_the_fp32_backward():
     for k in ga:
         d = float(np.linalg.norm(gb[k] - ga[k]) / max(np.linalg.norm(ga[k]), 1e-30))
         assert d < 3e-6, (k, d)                         # (3e-5 ... 5e-5 before the fix)
+
+
+@pytest.mark.parametrize("d,agg", [(128, "sum"), (64, "mean"), (128, "max")])
+def test_split_node_side_backward_kernel_is_the_path_taken_and_equals_the_separate_products(d, agg, monkeypatch):
+    """node_chain.hip, node_chain_bwd_kernel: dX = dP Wx -> ReLU mask of the previous step's node update -> dAGG = dZn Wu in one
+    launch per step (autograd of reference models/mpn.py:97-99 and of the projections gathered at mpn.py:69,87,93).  It must be the
+    path taken (L - 1 launches), and agree with the three separate launches (MPNHIP_NO_NODE_CHAIN_BWD=1: grouped GEMM, k_relu_mask,
+    GEMM -- same split operands, another summation order) far below the oracle tolerance; the oracle comparison itself is
+    test_split_gradients_match_oracle's, which now runs through this kernel.  More nodes than one 32-node block, a ragged last
+    block."""
+    L = 4
+    gs = [synth.make_graph(n, e, T=6, seed=240 + i, node_in_dim=48) for i, (n, e) in enumerate([(70, 500), (45, 302), (38, 150)])]
+    g = synth.batch_graphs(gs)
+    params = synth.model_params(d, L, agg, node_in_dim=48)
+    W = synth.make_weights(params, seed=17)
+    r = synth.normal(5, (L, g["edge_index"].shape[1]))
+    model = make_train_model(params, W)
+    model.gemm_precision = "fp32_split"
+    capi.path_counters(reset=True)
+    lo, gx, gea, pg = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r)
+    counts = capi.path_counters(reset=True)
+    assert counts["node_chain_bwd"] == L - 1, counts
+    monkeypatch.setenv("MPNHIP_NO_NODE_CHAIN_BWD", "1")
+    lo2, gx2, gea2, pg2 = native_grads(model, g["x"], g["edge_index"], g["edge_attr"], r)
+    counts = capi.path_counters(reset=True)
+    assert counts["node_chain_bwd"] == 0, counts
+    assert np.array_equal(lo, lo2)
+    worst = max([nerr(gx, gx2), nerr(gea, gea2)] + [nerr(pg[k], pg2[k]) for k in pg])
+    print("fused vs separate node-side backward: worst relative difference %.2e" % worst)
+    assert worst < 2e-5
