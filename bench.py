@@ -532,21 +532,25 @@ TRAFFIC_SOURCE = ("committed builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
                   "tools/pmc_summary.py), not this run")
 
 
-def pmc_traffic(kernel_key, cfg_name, precision="fp32"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json, made by
-    tools/pmc_summary.py with the MI355X guide's corrections), or None.  The passes were taken on cfg-B."""
+def pmc_traffic(kernel_key, cfg_name, precision="fp32", mode="fwd"):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/pmc_summary*.json, made by
+    tools/pmc_summary.py with the MI355X guide's corrections; newest round first), or None.  cfg-B passes: the default training
+    command; cfg-E (bf16): the forward command, and from round 4 the training command (pmc_summary_cfgE_train.json)."""
+    rounds = ("r04", "r03", "r02", "r01")
     if cfg_name == "E" and precision == "bf16":
-        try:
-            for rnd in ("r03", "r02"):
-                pth = os.path.join(REPO, "profiles", rnd, "pmc_summary_cfgE.json")
-                if os.path.exists(pth):
-                    return json.load(open(pth)).get(kernel_key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        name = "pmc_summary_cfgE_train.json" if mode == "train" else "pmc_summary_cfgE.json"
+        for rnd in rounds:
+            pth = os.path.join(REPO, "profiles", rnd, name)
+            try:
+                v = json.load(open(pth)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                v = None
+            if v is not None:
+                return v
         return None
     if cfg_name != "B" or precision == "bf16":
         return None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in rounds:
         path = os.path.join(REPO, "profiles", rnd, "pmc_summary.json" if precision in ("fp32", "fp32_wgsplit") else "pmc_summary_split.json")
         try:
             v = json.load(open(path)).get(kernel_key, {}).get("hbm_bytes_per_launch")
@@ -594,7 +598,7 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
             # mask word: 64 lanes x 4 bytes per 32-edge wave tile) -- every one of them is read again by the backward
             alg_bytes += E * ((he + hn + hc + de) * 2 + mask_words * 8)
         ach = alg_bytes / (gemm_us * 1e-6) / 1e9
-        traffic = pmc_traffic("edge_chain_bf16", args.config, args.precision)
+        traffic = pmc_traffic("edge_chain_bf16_save" if mode == "train" else "edge_chain_bf16", args.config, args.precision, mode)
         res["roofline"] = {"bound": "hbm",
                            "kernel": "edge_chain_bf16_kernel<20,4,14,8,2> (two 4-wave blocks per CU" + (", SAVE variant" if mode == "train" else "") + "): fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
                                      "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers, node_agg_fn in the kernel; bound by the per-edge "
@@ -680,7 +684,8 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
             res["roofline_bwd_chain"] = {"bound": "hbm", "kernel": "edge_chain_bf16_bwd_kernel: fused activation-gradient chain of one MP step, bf16 operands, "
                                                                    "bf16 dZ rows out; %d edges x %d MACs" % (E, macs_b),
                                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": bu, "launches": bn,
-                                         "traffic": None, "algorithmic_bytes": bytes_b, "algorithmic_flops": fl,
+                                         "traffic": pmc_traffic("edge_chain_bf16_bwd", args.config, args.precision, "train"),
+                                         "algorithmic_bytes": bytes_b, "algorithmic_flops": fl,
                                          "mfma_frac_of_bf16_peak": fl / (bu * 1e-6) / 1e12 / 2516.6, "ms_per_step": bu * c["L"] / 1e3}
             cand["roofline_bwd_chain"] = res["roofline_bwd_chain"]["ms_per_step"]
         elif bn and chain:
@@ -708,7 +713,7 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                                                                      % ("bf16 source rows as stored by the chain kernels, one product per k block" if chain == 2 else
                                                                         "three-piece bf16 operands split in the loader"),
                                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": tu, "launches": tn_,
-                                           "traffic": pmc_traffic("wgrad_panel", args.config, args.precision),
+                                           "traffic": pmc_traffic("wgrad_panel", args.config, args.precision, "train"),
                                            "algorithmic_bytes": tw, "launches_per_step": launches, "ms_per_step": tu * launches / 1e3}
             if res["roofline_weight_grad"]["traffic"]:
                 res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / tw

@@ -30,7 +30,10 @@ extern "C" {
 /* Operand precision of every Linear layer's product.  FP32 (default): fp32 operands and accumulation, the reference's
  * arithmetic.  BF16: activations and weights are rounded to bf16 (round to nearest even) as they enter the product,
  * accumulation, biases, gather-adds and aggregation stay fp32 -- BASELINE.json's "bf16 MLP GEMMs on MFMA"
- * configuration (SURVEY.md section 8d cfg-E).  mpnhip_backward rounds the operands of its products the same way (round 3). */
+ * configuration (SURVEY.md section 8d cfg-E).  mpnhip_backward rounds the operands of its products the same way (round 3).
+ * Round 4: at the fused chain's widths (edge dim 16 ... 128) mpnhip_forward_saved keeps the hidden activations of the per-edge
+ * modules as bf16 rows -- the values the backward's products would round them to anyway -- and the ReLU decisions as bits, and
+ * mpnhip_backward runs one fused chain kernel per step over them; the workspaces of the two calls belong together as before. */
 #define MPNHIP_PREC_FP32 0
 #define MPNHIP_PREC_BF16 1
 /* FP32_SPLIT: fp32 results from bf16 matrix instructions.  In the fused per-edge chain kernels (forward and backward) every

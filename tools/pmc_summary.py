@@ -17,6 +17,14 @@ KEYS = {  # json key -> substring of the kernel name (+ optional grid filter)
     "gemm_edge_l1": "gemm_kernel<4, 1, 5, 0>",
     "edge_chain": "edge_chain_kernel",
     "edge_chain_bf16": "edge_chain_bf16_kernel",
+    # the 256-d variant's SAVE (training) and inference instantiations: <..., NW=4, CTI=1, SAVE, DEPTH>
+    "edge_chain_bf16_save": "1, true, 4>(mpnhip::EdgeChainBf16Args",
+    "edge_chain_bf16_infer": "1, false, 4>(mpnhip::EdgeChainBf16Args",
+    "edge_chain_bf16_bwd": "edge_chain_bf16_bwd_kernel",
+    "segment_reduce3_b16": "k_segment_reduce3_b16",
+    "sum_blocks_bf16": "k_sum_blocks_bf16",
+    "node_chain": "node_chain_kernel",
+    "node_chain_bwd": "node_chain_bwd_kernel",
     "edge_chain_bwd": "edge_chain_bwd_kernel",
     "k_aggregate": "k_aggregate",
     "gemm_tn": "gemm_tn_kernel",

@@ -2,7 +2,7 @@
 # Round measurement set (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats of the default bench
 # command, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, kernel-trace only), tracking-driver numbers.
 # Outputs land in gpurun_out/$RND/; copy what should be judged into profiles/$RND/.
-RND=${RND:-r03}
+RND=${RND:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -26,7 +26,11 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- 
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fwd -- python $R/bench.py --mode fwd --no-cpu-baseline --no-split-line > $O/stats_fwd.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_cfgE.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgC -- python $R/bench.py --config C --no-cpu-baseline --no-split-line > $O/stats_cfgC.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgE_train -- python $R/bench.py --config E --precision bf16 --mode train --steps 10 --warmup 4 --no-cpu-baseline --no-split-line --no-extras > $O/stats_cfgE_train.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfgD -- python $R/bench.py --config D --no-cpu-baseline --no-split-line --no-extras > $O/stats_cfgD.log 2>&1
 # HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_Et -- python $R/bench.py --config E --precision bf16 --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch_Et.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_Et -- python $R/bench.py --config E --precision bf16 --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write_Et.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch32.log 2>&1
@@ -42,6 +46,11 @@ F=$(ls $O/pmc_fetch32/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write3
 python tools/pmc_summary.py $F $W $O/pmc_summary.json > /dev/null
 F=$(ls $O/pmc_fetch_E/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write_E/*/*counter_collection.csv | head -1)
 python tools/pmc_summary.py $F $W $O/pmc_summary_cfgE.json > /dev/null
+F=$(ls $O/pmc_fetch_Et/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write_Et/*/*counter_collection.csv | head -1)
+python tools/pmc_summary.py $F $W $O/pmc_summary_cfgE_train.json > /dev/null
+cp $(ls $O/stats_cfgE_train/*/*kernel_stats.csv | head -1) $O/bench_train_cfgE_bf16_kernel_stats.csv
+cp $(ls $O/stats_cfgD/*/*kernel_stats.csv | head -1) $O/bench_train_cfgD_kernel_stats.csv
+[ -x build/micro/store_pattern ] && { ./build/micro/store_pattern 400000 20; ./build/micro/store_pattern 50000 50; } > $O/store_pattern.txt 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/bench_train_cfgB_kernel_stats.csv
 cp $(ls $O/stats_fwd/*/*kernel_stats.csv | head -1) $O/bench_fwd_cfgB_kernel_stats.csv
 cp $(ls $O/stats_cfgE/*/*kernel_stats.csv | head -1) $O/bench_fwd_cfgE_bf16_kernel_stats.csv
