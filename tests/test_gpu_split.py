@@ -231,3 +231,28 @@ def test_split_node_side_backward_kernel_is_the_path_taken_and_equals_the_separa
     worst = max([nerr(gx, gx2), nerr(gea, gea2)] + [nerr(pg[k], pg2[k]) for k in pg])
     print("fused vs separate node-side backward: worst relative difference %.2e" % worst)
     assert worst < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
+@pytest.mark.parametrize("agg", ["sum", "max"])
+def test_chain_kernels_with_partial_last_tiles_at_the_128d_template(precision, agg):
+    """Widths that need the 128-d chain template (tiles 10 / 2 / 7 / 4) but are NOT multiples of 32 -- he 304, de 48, hn 208, dn 112,
+    hc 24: every module's last 32-column tile is partial, loads are masked and stores cut (in the backward kernel the dZ rows leave
+    through the per-wave LDS slabs, row_stage.h: a partial tile stores only its live 16-byte pieces, rows are no longer 128-byte
+    aligned).  Forward + every gradient against the oracle; the chain kernels must be the path taken."""
+    params = synth.model_params(128, 3, agg, node_in_dim=48)
+    params["encoder_feats_dict"].update(edge_out_dim=48, node_out_dim=112)
+    params["edge_model_feats_dict"]["dims"] = [304, 48]
+    params["node_model_feats_dict"]["dims"] = [208, 112]
+    params["classifier_feats_dict"].update(edge_in_dim=48, edge_dims=[24])
+    g = small_batch(180)
+    W = synth.make_weights(params, seed=23)
+    model = make_train_model(params, W)
+    model.gemm_precision = precision
+    keep = []
+    assert capi.load().mpnhip_edge_chain_active(model.c_model(keep)) == 1
+    capi.path_counters(reset=True)
+    check_against_oracle(params, W, g, robust=(agg == "max"), precision=precision)
+    counts = capi.path_counters(reset=True)
+    key = "edge_chain_bwd_split" if precision == "fp32_split" else "edge_chain_bwd"
+    assert counts[key] >= 3, {k: v for k, v in counts.items() if v}
