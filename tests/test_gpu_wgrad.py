@@ -11,7 +11,7 @@ from mpntrackseg_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(320, 64), (64, 320), (224, 64), (32, 64), (128, 224), (128, 256), (1088, 128), (80, 32), (16, 80), (56, 16), (8, 16),
-          (18, 18), (1, 32), (1, 8), (640, 128), (448, 128)]
+          (18, 18), (1, 32), (1, 8), (640, 128), (448, 128), (72, 6), (144, 6), (160, 7)]
 ROWS = [3, 16, 17, 44, 300, 1000]
 
 
