@@ -38,15 +38,41 @@ def bf16_forward(params, W, g):
     assert np.isfinite(got).all() and err < 2e-2, ("bf16 forward", err)
 
 
+def bf16_training(params, W, g, seed, tiny):
+    """one training step with bf16 operands (round 4: the fused SAVE forward / backward chain kernels + bf16-row consumers where the
+    widths have them) against the bf16 oracle's autograd on the branch the HIP forward took -- tests/test_gpu_parity.py::
+    test_bf16_mode_trains_gradients_match_the_bf16_oracle on random configurations"""
+    import torch
+    from mpntrackseg_amd.mpn import MOTMPNet
+    from oracle import mpn_oracle as O
+    from pinned import hip_run, oracle_run, rel_l2
+    dev = torch.device("cuda:0")
+    model = MOTMPNet(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    model = model.to(dev).train()
+    model.gemm_precision = "bf16"
+    L, E = max(params["num_enc_steps"], 1), g["edge_index"].shape[1]
+    r = synth.normal(seed, (L, E))
+    lg, grads, given, counts = hip_run(model, g, r, dev)
+    with O.precision("bf16"):
+        l32, ref, _ = oracle_run(params, W, g, r, given, "impose", dtype=torch.float32)
+    tol = 1e-1 if tiny else 2e-2
+    err = float(np.linalg.norm(lg.astype(np.float64) - l32) / max(np.linalg.norm(l32), 1e-30))
+    worst = max([rel_l2(grads[k], ref[k]) for k in ref if np.linalg.norm(ref[k]) > 0] + [0.0])
+    assert np.isfinite(lg).all() and err < tol and worst < tol, ("bf16 training", err, worst)
+    return counts.get("edge_chain_bwd_bf16", 0), worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--bf16-train", action="store_true", help="only the bf16-operand training step (adds d = 256)")
     a = ap.parse_args()
     rng = np.random.RandomState(a.seed)
     fails = 0
     for i in range(a.cases):
-        d = int(rng.choice([32, 64, 128]))
+        d = int(rng.choice([32, 64, 128, 256] if a.bf16_train else [32, 64, 128]))
         L = int(rng.randint(1, 4))
         agg = str(rng.choice(["sum", "mean", "max"]))
         N = int(rng.choice([3, 9, 40, 130, 300]))
@@ -86,6 +112,11 @@ def main():
             saved = dict(tp.TOLS)
             if tiny:
                 tp.TOLS = {k: (10 * v[0], 10 * v[1]) for k, v in saved.items()}
+            if a.bf16_train:
+                nb, worst = bf16_training(params, W, g, seed, tiny)
+                print("case %2d ok: d=%d L=%d %s N=%d E=%d nid=%d %s  fused backward launches %d, worst gradient rel l2 %.1e" %
+                      (i, d, L, agg, g["x"].shape[0], g["edge_index"].shape[1], nid, kind, nb, worst), flush=True)
+                continue
             try:
                 for prec in ("fp32", "fp32_split", "fp32_wgsplit"):
                     tp.run_case(params, W, g, prec, seed=seed)
