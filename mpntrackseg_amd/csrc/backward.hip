@@ -245,6 +245,8 @@ struct BwdPlan {
     unsigned short* ncb_img;            // unit images of the fused node-side backward kernel (node_chain.hip) or nullptr
     float* wt_scratch;                  // MPNHIP_PREC_BF16: transposed weight blocks of the activation-gradient products
     size_t wt_scratch_floats;
+    float* wt_keep[2];                  // ... the node update's (0) and the projections' (1) blocks, transposed once per backward
+    size_t wt_keep_floats[2];
     // bf16-operand training on the fused kernels (FwdPlan::b16): the dZ blocks above are bf16 rows (half the floats), the gradient
     // w.r.t. e_s travels between the steps in two fp32 buffers, and the backward chain kernel has its own pair images
     bool b16;
@@ -336,6 +338,9 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
             }
         p.wt_scratch_floats = m.precision == MPNHIP_PREC_BF16 ? 2 * mx : 0;
         p.wt_scratch = a.f(p.wt_scratch_floats);
+        p.wt_keep_floats[0] = m.precision == MPNHIP_PREC_BF16 && m.node.n_layers >= 1 ? (size_t)d.dn * m.node.in_dim : 0;
+        p.wt_keep_floats[1] = m.precision == MPNHIP_PREC_BF16 ? (size_t)d.pw * d.dn : 0;
+        for (int i = 0; i < 2; ++i) p.wt_keep[i] = a.f(p.wt_keep_floats[i]);
     }
     size_t sl = 0;
     auto upd = [&](size_t f) { sl = f > sl ? f : sl; };
@@ -416,6 +421,10 @@ static thread_local bool g_wg_src16 = false;
 struct Src16Scope { bool old; explicit Src16Scope(bool v) : old(g_wg_src16) { g_wg_src16 = v; } ~Src16Scope() { g_wg_src16 = old; } };
 static thread_local float* g_wt_scratch = nullptr;
 static thread_local size_t g_wt_scratch_floats = 0;
+// ... and two blocks that are KEPT for the whole backward: the node update's and the per-node projections' weights are the operands of
+// an activation-gradient product in every step (22 transpositions of the same two blocks per cfg-E step before round 4, 25 - 30 us each)
+struct WtKeep { float* wt; size_t floats; bool valid; };
+static thread_local WtKeep g_wt_keep[2] = {{nullptr, 0, false}, {nullptr, 0, false}};
 
 // dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
@@ -489,7 +498,7 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
 // C = mask( A B (+ C) ) with B given as weight rows: B[k][n] = W[k * ldw + n]  (dH = dZ W)
 static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, const float* const W[2], int64_t ldw, int K,
                     int N, float* C, int64_t ldc, const int* c_idx, const float* mask, int64_t ldmask, int accumulate,
-                    const RowRange rr[2], int64_t rows, hipStream_t s) {
+                    const RowRange rr[2], int64_t rows, hipStream_t s, int keep = -1) {
     GemmArgs a = {};
     a.ngroups = ngroups;
     a.N = N;
@@ -511,7 +520,10 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
         if (bf16) {
             // WT[n][k] = W[k][n]: the block as an nn.Linear weight of the product C = A WT^T (bf16 operands, K-contiguous)
             float* wt = g_wt_scratch + (size_t)q * K * N;
-            MPN_TRY(transpose_padded(W[q], ldw, 0, K, N, wt, K, N, s));
+            WtKeep* kp = (keep >= 0 && ngroups == 1 && g_wt_keep[keep].wt && (size_t)K * N <= g_wt_keep[keep].floats) ? &g_wt_keep[keep] : nullptr;
+            if (kp) wt = kp->wt;
+            if (!kp || !kp->valid) MPN_TRY(transpose_padded(W[q], ldw, 0, K, N, wt, K, N, s));
+            if (kp) kp->valid = true;   // (one stream: the later steps' products are ordered behind this transposition)
             g.B = wt;
             g.ldb = K;
         }
@@ -696,6 +708,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     }
     g_wt_scratch = p.wt_scratch;
     g_wt_scratch_floats = p.wt_scratch_floats;
+    struct KeepScope {   // (valid only inside this call: the blocks live in this call's workspace)
+        KeepScope(const BwdPlan& q) { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {q.wt_keep_floats[i] ? q.wt_keep[i] : nullptr, q.wt_keep_floats[i], false}; }
+        ~KeepScope() { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {nullptr, 0, false}; }
+    } keep_scope(p);
+    if (getenv("MPNHIP_NO_WT_KEEP")) for (int i = 0; i < 2; ++i) g_wt_keep[i].wt = nullptr;
     GraphView g;
     graph_layout(n_nodes, n_edges, &g, const_cast<void*>(graph_buf));
     const int he = d.he, hn = d.hn, dn = d.dn, de = d.de, kx = d.kx, ke = d.ke, pw = d.pw, L = d.L;
@@ -1024,7 +1041,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         if (!node_a_done) {
             MPN_TRY(relu_mask(dXc, x_s, dZn, (int64_t)xs, s, dx_split ? p.dXh : nullptr));
             const float* Wq[2] = {m.node.weight[0], nullptr};
-            MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s));
+            MPN_TRY(act_grad(1, dZn, dn, nullptr, Wq, 2 * dn, dn, 2 * dn, p.dAGG, 2 * dn, nullptr, nullptr, 0, 0, nullptr, N, s, 0));
         }
         dx_split = false;
         node_a_done = false;
@@ -1158,7 +1175,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 // dP after the loop: one product instead of L
                 const float* Wa[2] = {f.Wnode + dn, nullptr};
                 MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, dn, step == 1 ? p.dX0 : dXp, dn, nullptr, nullptr, 0, step == 1 ? 1 : 0,
-                                 nullptr, N, s));
+                                 nullptr, N, s, 1));
             } else {
                 const float* Wa[2] = {f.Wnode, nullptr};
                 MPN_TRY(act_grad(1, dP, pw, nullptr, Wa, kx, pw, kx, p.dCat, kx, nullptr, nullptr, 0, 0, nullptr, N, s));
