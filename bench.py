@@ -243,7 +243,7 @@ def extras(dev, budget_s=60.0):
             ("cfgC_train", ("C", "train", "auto", 30, 8), None),
             ("cfgC_fwd", ("C", "fwd", "auto", 60, 10), None),
             ("cfgE_bf16_fwd", ("E", "fwd", "bf16", 5, 2), None),
-            ("cfgE_bf16_train", ("E", "train", "bf16", 3, 1), None),
+            ("cfgE_bf16_train", ("E", "train", "bf16", 5, 1), None),   # (5 steps = 15 weight-gradient launches: every 5th samples each of the three sizes once)
             ("cfgE_bf16_fwd_unfused_aggregation", ("E", "fwd", "bf16", 3, 1), {"MPNHIP_NO_AGG_FUSION": "1"})]
     res, t_start, cache = {}, time.time(), {}
     for name, (cfg, mode, prec, steps, warm), env in plan:
@@ -372,8 +372,11 @@ def main():
         step()
     profiled = rank == 0 and not args.no_roofline
     if profiled:
-        lib.mpnhip_profile_enable(7)  # HIP events attached to every 7th launch of each profiled kernel kind (7: coprime with the 12 chain
-        # launches and the 3 differently-sized weight-gradient launches of a step, so every position of a step is sampled)
+        # HIP events attached to every 7th launch of each profiled kernel kind (7: coprime with the 12 chain launches and the 3
+        # differently-sized weight-gradient launches of a step, so every position of a step is sampled); large graphs (cfg-E: ~10
+        # steps, 30 weight-gradient launches) every 5th -- six samples, two of each launch size (with 7: five samples, unbalanced:
+        # avg_us 5.9 - 6.7 ms in the line against 4.8 ms in the rocprofv3 trace)
+        lib.mpnhip_profile_enable(5 if E >= 200000 else 7)
     capi.path_counters(reset=True)
     barrier()
     torch.cuda.synchronize()
