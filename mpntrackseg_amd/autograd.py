@@ -17,12 +17,13 @@ def avg_pool_native(x):
     return y
 
 
-def native_forward_saved(model, g, x, ea, logits):
-    """mpnhip_forward(save_for_backward=1) into a private workspace; returns that workspace."""
+def native_forward_saved(model, g, x, ea, logits, cmodel=None):
+    """mpnhip_forward(save_for_backward=1) into a private workspace; returns that workspace.  ``cmodel``: a native model description
+    the caller built with ``model.c_model`` and keeps alive (train.TrainStep caches it: building one costs ~50 us of host time)."""
     lib = capi.load()
     keep = []
     N, E = x.shape[0], ea.shape[0]
-    m = model.c_model(keep, n_edges=E)
+    m = cmodel if cmodel is not None else model.c_model(keep, n_edges=E)
     with torch.cuda.device(x.device):
         ws = torch.empty(max(lib.mpnhip_forward_workspace_bytes(m, N, E, 1), 256), dtype=torch.uint8, device=x.device)
         capi.check(lib.mpnhip_forward(m, capi.ptr(g.buf), N, E, capi.ptr(x), capi.ptr(ea), capi.ptr(logits), None, None,
@@ -30,13 +31,14 @@ def native_forward_saved(model, g, x, ea, logits):
     return ws
 
 
-def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, need_gea=False, defer_side_join=False):
+def native_backward(model, g, x, ea, grad_logits, fwd_ws, grads, need_gx=False, need_gea=False, defer_side_join=False, cmodel=None):
     """mpnhip_backward; ``grads``: id(param) -> buffer the parameter gradient is ACCUMULATED into.
-    ``defer_side_join``: MPNHIP_BWD_DEFER_SIDE_JOIN (include/mpnhip.h) -- the caller joins the side stream itself."""
+    ``defer_side_join``: MPNHIP_BWD_DEFER_SIDE_JOIN (include/mpnhip.h) -- the caller joins the side stream itself.
+    ``cmodel``: a description built with ``model.c_model(keep, grads=grads, n_edges=E)`` that the caller keeps alive."""
     lib = capi.load()
     keep = []
     N, E = x.shape[0], ea.shape[0]
-    m = model.c_model(keep, grads=grads, n_edges=E)
+    m = cmodel if cmodel is not None else model.c_model(keep, grads=grads, n_edges=E)
     gx = torch.empty_like(x) if need_gx else None
     gea = torch.empty_like(ea) if need_gea else None
     gl = capi.f32c(grad_logits)

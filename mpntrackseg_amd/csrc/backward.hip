@@ -83,6 +83,21 @@ __global__ void k_add_block(const float* __restrict__ src, int64_t lds, float* _
     dst[(int64_t)r * ldd + c0 + c] += src[(int64_t)r * lds + c];
 }
 
+// the same for four row blocks of one source in one launch (the packed node-projection gradient back into its layers' gradients)
+struct AddParts { float* dst[4]; int64_t ldd[4]; int c0[4]; int r0[4]; int rows[4]; };
+__global__ void k_add_block4(const float* __restrict__ src, int64_t lds, int cols, AddParts P) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t n = (int64_t)P.rows[k] * cols;
+        if (q == k && i >= n) { i -= n; q = k + 1; }
+    }
+    if (i >= (int64_t)P.rows[q] * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    P.dst[q][(int64_t)r * P.ldd[q] + P.c0[q] + c] += src[(int64_t)(P.r0[q] + r) * lds + c];
+}
+
 // src [rows, 2d] (or [rows, d] when !two): acc[r][c] += src[r][c]; other[r][c] (=|+=) src[r][d + c]
 __global__ void k_split_cat(const float* __restrict__ src, int64_t rows, int d, int two, float* __restrict__ acc,
                             float* __restrict__ other, int other_accumulate) {
@@ -1268,10 +1283,14 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             {m.edge.grad_weight[0], m.edge.in_dim, kx, he, he},
             {m.flow_out.grad_weight[0], m.flow_out.in_dim, 0, 2 * he, hn},
             {m.flow_in.grad_weight[0], m.flow_in.in_dim, 0, 2 * he + hn, hn}};
-        for (auto& q : parts) {
-            int64_t tot = (int64_t)q.rows * kx;
-            hipLaunchKernelGGL(k_add_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, us, p.gWnode + (size_t)q.r0 * kx,
-                               kx, q.dst, q.ld, q.c0, q.rows, kx);
+        AddParts P;
+        int64_t tot = 0;
+        for (int i = 0; i < 4; ++i) {
+            P.dst[i] = parts[i].dst; P.ldd[i] = parts[i].ld; P.c0[i] = parts[i].c0; P.r0[i] = parts[i].r0; P.rows[i] = parts[i].rows;
+            tot += (int64_t)parts[i].rows * kx;
+        }
+        if (tot > 0) {   // (one launch for the four blocks: they are disjoint destinations)
+            hipLaunchKernelGGL(k_add_block4, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, us, p.gWnode, (int64_t)kx, kx, P);
             MPN_LAUNCH_CHECK();
         }
         return MPNHIP_OK;

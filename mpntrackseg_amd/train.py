@@ -135,6 +135,25 @@ class TrainStep:
         self._side = None
         self.opt = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay)
         self.first_class_step = max(int(model.num_enc_steps) - int(model.num_class_steps), 0)
+        self._cmodels = {}
+
+    def native_models(self, n_edges):
+        """The native model descriptions (``mpnhip_model``: every weight's and gradient's device address) of the forward and of the
+        backward, built once per resolved operand precision and reused: the parameters are views of the bucket's flat buffer and
+        the gradients views of its gradient buffer, so the addresses do not change from step to step.  Building one costs 50 - 70 us
+        of Python, a step needs several, and at the reference's graph sizes the step is bound by the host (KITTIMOTS-like graph:
+        453 us to enqueue a 390 us step, tools/diag/host_cost.py).  The cache is checked against the parameters' addresses."""
+        model = self.model
+        prec = model.operand_precision(n_edges)
+        ptrs = tuple(p.data_ptr() for p in self.bucket.params)
+        hit = self._cmodels.get(prec)
+        if hit is None or hit[0] != ptrs:
+            keep_f, keep_b = [], []
+            mf = model.c_model(keep_f, n_edges=n_edges)
+            mb = model.c_model(keep_b, grads=self.bucket.views, n_edges=n_edges)
+            hit = (ptrs, mf, mb, keep_f, keep_b)
+            self._cmodels[prec] = hit
+        return hit[1], hit[2]
 
     def allreduce_buckets(self, side_pending):
         """all-reduce(sum) / W of the flat gradient buffer.  ``side_pending``: the backward left its side stream un-joined
@@ -172,11 +191,12 @@ class TrainStep:
         g = _prepared(edge_index, x.shape[0], holder)
         x = capi.f32c(x)
         ea = capi.f32c(edge_attr)
-        check_hot_path_inputs(model.c_model([]), g, x, ea)
         E = ea.shape[0]
+        m_fwd, m_bwd = self.native_models(E)
+        check_hot_path_inputs(m_fwd, g, x, ea)
         L = max(int(model.num_enc_steps), 1)
         logits = torch.empty((L, E), dtype=torch.float32, device=x.device)
-        ws = native_forward_saved(model, g, x, ea, logits)
+        ws = native_forward_saved(model, g, x, ea, logits, cmodel=m_fwd)
         if labels is None:
             if getattr(self, "_default_labels", None) is None or self._default_labels.numel() != E:
                 self._default_labels = (torch.arange(E, device=x.device) % 7 == 0).float()
@@ -186,8 +206,8 @@ class TrainStep:
         self.last_loss, glog = tracking_loss_and_grad(logits, labels, self.first_class_step, 1.0, edge_graph=edge_graph, n_graphs=n_graphs)
         self.bucket.zero_()
         lib = capi.load()
-        defer = self.collectives and bool(lib.mpnhip_backward_uses_side_stream(model.c_model([])))
-        native_backward(model, g, x, ea, glog, ws, self.bucket.views, defer_side_join=defer)
+        defer = self.collectives and bool(lib.mpnhip_backward_uses_side_stream(m_fwd))
+        native_backward(model, g, x, ea, glog, ws, self.bucket.views, defer_side_join=defer, cmodel=m_bwd)
         # IndexError like the reference's x[row] gather for an edge_index outside [0, N) (graph prep clamps such entries and sets a
         # flag): read once per graph, BEFORE anything is done with the gradients of the clamped graph -- the prep finished long
         # before the backward was enqueued, so the read waits for nothing
