@@ -603,7 +603,9 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         ach = alg_bytes / (gemm_us * 1e-6) / 1e9
         traffic = pmc_traffic("edge_chain_bf16_save" if mode == "train" else "edge_chain_bf16", args.config, args.precision, mode)
         res["roofline"] = {"bound": "hbm",
-                           "kernel": "edge_chain_bf16_kernel<20,4,14,8,2> (two 4-wave blocks per CU" + (", SAVE variant" if mode == "train" else "") + "): fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
+                           "kernel": "edge_chain_bf16_kernel<%d,%d,%d,%d,%d> (%s" % ((he + 31) // 32, (de + 31) // 32, (hn + 31) // 32, (dn + 31) // 32, (hc + 31) // 32,
+                                                                                   "two 4-wave blocks per CU" if d >= 256 else "one 8-wave block per CU")
+                                     + (", SAVE variant" if mode == "train" else "") + "): fused edge MLP + classifier + flow MLPs of one MP step, bf16 operands / "
                                      "fp32 accumulate (v_mfma_f32_32x32x16_bf16), hidden layers N-tiled in registers, node_agg_fn in the kernel; bound by the per-edge "
                                      "gathers of the projection table (%d B per edge from a %d MB table, uniformly random columns)"
                                      % ((2 * he + hn) * 4, N * (2 * he + 2 * hn) * 4 // 1000000),
