@@ -282,7 +282,13 @@ def main():
     if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            # a launcher (torch.distributed.run) always sets it; a lone --force-collectives run picks a free port, so that two
+            # bench / pytest processes on one host do not collide on a fixed one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
@@ -407,7 +413,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * E / ms_per_step
+    # whole-job units = the SUM of the ranks' edge counts: the kNN configurations (cfg-C / cfg-D) build a different graph per rank
+    # (seed = 1 + rank), so rank 0's count times the world size would be off by the spread of E
+    edges_total, edges_per_rank = E, [E]
+    if world > 1:
+        te = torch.zeros(world, device=dev, dtype=torch.float64)
+        te[rank] = float(E)
+        dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        edges_per_rank = [int(round(v)) for v in te.tolist()]
+        edges_total = sum(edges_per_rank)
+    value = edges_total / ms_per_step
 
     out = {
         "metric": "edges/ms (MPN %s) on %s tracking graph" % ("forward+backward" if mode == "train" else "forward",
@@ -425,7 +440,7 @@ def main():
                                "%s, one graph per GPU" % (args.config, N, E, c["d"], c["L"], args.agg,
                                                           "training step (fwd+bwd%s)" % ("+RCCL grad all-reduce" if world > 1 else "")
                                                           if mode == "train" else "inference forward"),
-                   "nodes": N, "edges": E, "feat_dim": c["d"], "mp_steps": c["L"], "agg": args.agg, "mode": mode,
+                   "nodes": N, "edges": E, "edges_all_ranks": edges_total, "edges_per_rank": edges_per_rank, "feat_dim": c["d"], "mp_steps": c["L"], "agg": args.agg, "mode": mode,
                    "parallelism": ("1-rank %s process group, collectives issued (functional run of the data-parallel code path)"
                                    % ("RCCL (nccl)" if args.backend == "nccl" else args.backend)) if force_pg else
                                   "graphs sharded 1 per GPU (dp%d)" % world if args.backend == "nccl" or world == 1 else
@@ -526,7 +541,7 @@ def main():
             out["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         print(json.dumps(ordered_line(out)))
-    if world > 1:
+    if world > 1 or force_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
 

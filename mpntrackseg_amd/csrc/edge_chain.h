@@ -205,6 +205,15 @@ int pack_pair_bf16_general(const float* Wa, int64_t sa_n, int64_t sa_k, int a_co
                            int a_natural = 0);
 
 // ---- backward of the bf16-operand chain (edge_chain_bf16_bwd.hip) ----
+// the tile counts / exactness launch_edge_chain_bf16_bwd has an instantiation for (its dispatch table, stated once: the forward's
+// plan asks this before it saves in the bf16-row form, so that a width the backward cannot take trains on the unfused path)
+static inline bool edge_chain_bf16_bwd_supported(int he, int de, int hn, int dn, int hc) {
+    const bool exact = he % 32 == 0 && de % 32 == 0 && hn % 32 == 0 && dn % 32 == 0 && hc % 32 == 0;
+    const int t1 = (he + 31) / 32, t2 = (de + 31) / 32, tf = (hn + 31) / 32, td = (dn + 31) / 32, tc = (hc + 31) / 32;
+    if (t1 == 20 && t2 == 4 && tf == 14 && td == 8 && tc == 2) return exact;
+    return (t1 == 10 && t2 == 2 && tf == 7 && td == 4 && tc == 1) || (t1 == 5 && t2 == 1 && tf == 4 && td == 2 && tc == 1) ||
+           (t1 == 3 && t2 == 1 && tf == 2 && td == 1 && tc == 1);
+}
 struct EdgeChainBf16BwdArgs {
     int E, N, agg, first_step;
     int he, de, hn, dn, hc;   // real widths

@@ -336,6 +336,10 @@ int launch_edge_chain_bf16_bwd(const EdgeChainBf16BwdArgs& a_in, hipStream_t s) 
     const unsigned blocks = (unsigned)((a.E + epb - 1) / epb + 3);
     const bool exact = a.he % 32 == 0 && a.de % 32 == 0 && a.hn % 32 == 0 && a.dn % 32 == 0 && a.hc % 32 == 0;
     const int t1 = (a.he + 31) / 32, t2 = (a.de + 31) / 32, tf = (a.hn + 31) / 32, td = (a.dn + 31) / 32, tc = (a.hc + 31) / 32;
+    if (!edge_chain_bf16_bwd_supported(a.he, a.de, a.hn, a.dn, a.hc)) {
+        set_error("edge_chain_bf16_bwd: unsupported widths");
+        return MPNHIP_ERR_UNSUPPORTED;
+    }
     count_path(PC_CHAIN_BWD_BF16);
 #define MPN_CBB(...) MPN_LAUNCH_PROFILED((edge_chain_bf16_bwd_kernel<__VA_ARGS__>), dim3(blocks), dim3(64 * nw), s, a)
     if (t1 == 20 && t2 == 4 && tf == 14 && td == 8 && tc == 2 && exact) {

@@ -814,7 +814,8 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.last = step + 1 == d.L ? 1 : 0;
         io.P_next = io.last ? nullptr : step_at(p, step + 1).P;
         // (bf16-operand chain: the edge features travel between the steps as bf16 rows; the fp32 ones only where they are returned)
-        const bool e16_on = p.eb_hist && p.cb.ok && (!save || p.b16);
+        // (a graph with nodes and no edges launches no chain kernel: nothing mirrors, run_step takes its E == 0 path)
+        const bool e16_on = p.eb_hist && p.cb.ok && (!save || p.b16) && E > 0;
         const StepE16 e16 = {p.eb_hist, p.eb_hist ? p.eb_hist + es * prev : nullptr, p.eb_hist ? p.eb_hist + es * cur : nullptr,
                              step + 1 == d.L || getenv("MPNHIP_CHAIN_BF16_KEEP_E32") != nullptr};
         MPN_TRY(run_step(m, d, g, p.Wnode, p.bnode, io, b, save && m.agg == MPNHIP_AGG_MAX, s, &p.cw, save != 0, &p.cb, e16_on ? &e16 : nullptr));

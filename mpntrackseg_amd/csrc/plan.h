@@ -94,7 +94,8 @@ static inline bool chain_bf16_ok(const mpnhip_model& m, const Dims& d) {
 // round 3's unfused training path, A-B switch).
 static inline bool chain_bf16_train_ok(const mpnhip_model& m, const Dims& d) {
     return chain_bf16_ok(m, d) && d.L >= 1 && d.he % 8 == 0 && d.de % 8 == 0 && d.hn % 8 == 0 && d.dn % 8 == 0 &&
-           m.classifier.out_dims[0] % 8 == 0 && !getenv("MPNHIP_NO_CHAIN_BF16_TRAIN");
+           m.classifier.out_dims[0] % 8 == 0 && edge_chain_bf16_bwd_supported(d.he, d.de, d.hn, d.dn, m.classifier.out_dims[0]) &&
+           !getenv("MPNHIP_NO_CHAIN_BF16_TRAIN");
 }
 
 // ------------------------------------------------------------------------------------ workspace

@@ -253,12 +253,31 @@ def node_model_forward(nm, x, edge_index, edge_attr):
     return _BnReluDropout.apply(z, None, None, None, True, 0.0, 0)
 
 
+def _int64_index(edge_index, holder):
+    """``edge_index`` as int64 WITHOUT defeating the holder's graph-prep cache (``mpn._prepared`` keys on tensor identity): an int64
+    input is returned as is; any other dtype is converted once per (tensor, version) and the copy kept on the holder, so the
+    second call presents the same object again instead of a fresh one that would redo the sort and the CSR build."""
+    if edge_index.dtype == torch.int64:
+        return edge_index
+    if holder is not None:
+        c = getattr(holder, "_mpnhip_ei64", None)
+        if c is not None and c[0] is edge_index and c[1] == edge_index._version:
+            return c[2]
+    ei = edge_index.to(torch.int64)
+    if holder is not None:
+        try:
+            object.__setattr__(holder, "_mpnhip_ei64", (edge_index, edge_index._version, ei))
+        except Exception:
+            pass
+    return ei
+
+
 def hot_path(model, x, edge_index, edge_attr, holder=None, return_state=False):
     """Encoder -> L x (reattach, MetaLayer, classifier): logits [max(L, 1), E] (mpn.py:349-392, the tracking branch);
     ``return_state``: (logits, final node features, final edge features) like ``MOTMPNet.hot_path``."""
     capi.require_device(x, edge_index, edge_attr)
     x, ea = capi.f32c(x), capi.f32c(edge_attr)
-    ei = edge_index.to(torch.int64)
+    ei = _int64_index(edge_index, holder)
     N = x.shape[0]
     # the reference's x[row] gather raises IndexError (mpn.py:69): validated once per prepared graph through graph prep's flag
     # (cached on the holder like the fused path's), not by a min / max host read per call

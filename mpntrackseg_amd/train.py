@@ -142,10 +142,15 @@ class TrainStep:
         backward, built once per resolved operand precision and reused: the parameters are views of the bucket's flat buffer and
         the gradients views of its gradient buffer, so the addresses do not change from step to step.  Building one costs 50 - 70 us
         of Python, a step needs several, and at the reference's graph sizes the step is bound by the host (KITTIMOTS-like graph:
-        453 us to enqueue a 390 us step, tools/diag/host_cost.py).  The cache is checked against the parameters' addresses."""
+        453 us to enqueue a 390 us step, tools/diag/host_cost.py).  The cache is keyed on the parameters' addresses and shapes,
+        ``num_enc_steps``, the reattach flags and the aggregation mode."""
         model = self.model
         prec = model.operand_precision(n_edges)
-        ptrs = tuple(p.data_ptr() for p in self.bucket.params)
+        # everything c_model() bakes into the description besides the precision: the parameters' addresses and shapes (layer
+        # dims), the step count, the reattach flags and the aggregation -- a model edited between two steps gets a new description
+        agg = getattr(model.MPNet.node_model, "node_agg_fn", None)
+        ptrs = (tuple((p.data_ptr(), tuple(p.shape)) for p in self.bucket.params), int(model.num_enc_steps),
+                bool(model.reattach_initial_nodes), bool(model.reattach_initial_edges), getattr(agg, "code", id(agg)))
         hit = self._cmodels.get(prec)
         if hit is None or hit[0] != ptrs:
             keep_f, keep_b = [], []

@@ -85,3 +85,19 @@ def test_bench_two_ranks_on_one_gpu(cfg):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["mode"] == "train"
     # SURVEY.md section 8e "Reporting": the all-reduce alone and the bus bandwidth it corresponds to
     assert d["allreduce_ms"] > 0 and d["allreduce_bytes"] > 0 and d["bus_gbs"] > 0, d
+
+
+def test_bench_eight_ranks_on_one_gpu_reports_the_sum_of_the_ranks_edges():
+    """the exact layout of BASELINE.json configs[3] -- eight ranks, one KITTIMOTS-like graph each (cfg-D: every
+    rank builds its OWN kNN graph, seed 1 + rank, so the edge counts differ) -- on the one leased GPU over gloo (functional only).
+    `value` must be the sum of the ranks' edge counts over the step time, not rank 0's count times eight."""
+    r = run_ranks(["bench.py", "--gpus", "8", "--backend", "gloo", "--config", "D", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                   "--no-split-line", "--no-extras"], nproc=8, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    per_rank = d["config"]["edges_per_rank"]
+    assert d["n_gpus"] == 8 and len(per_rank) == 8 and all(e > 0 for e in per_rank), d["config"]
+    assert len(set(per_rank)) > 1, per_rank                       # the ranks' graphs really differ
+    assert d["config"]["edges_all_ranks"] == sum(per_rank)
+    assert abs(d["value"] - sum(per_rank) / d["ms_per_step"]) <= 1e-6 * d["value"], (d["value"], per_rank, d["ms_per_step"])
+    assert d["scaling"] == "weak" and d["allreduce_ms"] > 0

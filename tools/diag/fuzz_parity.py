@@ -63,6 +63,49 @@ def bf16_training(params, W, g, seed, tiny):
     return counts.get("edge_chain_bwd_bf16", 0), worst
 
 
+def gen_case(rng, bf16_train=False):
+    """One random configuration drawn from `rng` (np.random.RandomState): dict(d, L, agg, N, E, nid, kind, seed, params, W, g,
+    tiny), or None when the graph generator cannot place that many distinct cross-frame pairs on so few nodes.  Shared by main()
+    below and by tests/test_gpu_bf16_train.py (ten seeded cases of the bf16 training step inside the driver-run suite)."""
+    d = int(rng.choice([32, 64, 128, 256] if bf16_train else [32, 64, 128]))
+    L = int(rng.randint(1, 4))
+    agg = str(rng.choice(["sum", "mean", "max"]))
+    N = int(rng.choice([3, 9, 40, 130, 300]))
+    maxpairs = N * (N - 1) // 4
+    E = 2 * int(min(maxpairs, rng.choice([2, 17, 63, 64, 65, 129, 500, 1300])))
+    E = max(E, 2)
+    nid = int(rng.choice([16, 48, 64]))
+    kind = str(rng.choice(["plain", "batch", "oneway", "noreattach"]))
+    seed = int(rng.randint(1, 1000))
+    c = dict(d=d, L=L, agg=agg, N=N, E=E, nid=nid, kind=kind, seed=seed)
+    try:
+        if kind == "batch":
+            n2 = max(N // 2, 4)
+            e2 = max(min(E // 4 * 2, (n2 * (n2 - 1) // 6) * 2), 2)
+            gs = [synth.make_graph(n2, e2, T=5, seed=seed + k, node_in_dim=nid) for k in range(2)]
+            g = synth.batch_graphs(gs)
+            ei = g["edge_index"].copy()
+            ei[:, 0] = [1, 1]          # a self loop
+            g["edge_index"] = ei
+        else:
+            g = synth.make_graph(N, E, T=max(2, min(6, N)), seed=seed, node_in_dim=nid)
+    except ValueError:      # (the generator cannot place that many distinct cross-frame pairs on so few nodes)
+        return None
+    if kind == "oneway":            # only the (row < col) halves: no flow_in edge at all
+        h = g["edge_index"].shape[1] // 2
+        g["edge_index"] = g["edge_index"][:, :h].copy()
+        g["edge_attr"] = g["edge_attr"][:h].copy()
+    params = synth.model_params(d, L, agg, node_in_dim=nid)
+    if kind == "noreattach":
+        params["reattach_initial_nodes"] = bool(rng.randint(2))
+        params["reattach_initial_edges"] = bool(rng.randint(2))
+    W = synth.make_weights(params, seed=seed, gain=0.8)
+    # (a handful of edges: a parameter gradient is a sum of a few terms that may cancel -- its RELATIVE error is then a
+    # matter of conditioning, not of the kernels; seen: 1.8e-5 on an 8-element tensor of a 4-edge graph, in fp32 mode)
+    c.update(params=params, W=W, g=g, tiny=g["edge_index"].shape[1] < 64)
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=24)
@@ -72,43 +115,13 @@ def main():
     rng = np.random.RandomState(a.seed)
     fails = 0
     for i in range(a.cases):
-        d = int(rng.choice([32, 64, 128, 256] if a.bf16_train else [32, 64, 128]))
-        L = int(rng.randint(1, 4))
-        agg = str(rng.choice(["sum", "mean", "max"]))
-        N = int(rng.choice([3, 9, 40, 130, 300]))
-        maxpairs = N * (N - 1) // 4
-        E = 2 * int(min(maxpairs, rng.choice([2, 17, 63, 64, 65, 129, 500, 1300])))
-        E = max(E, 2)
-        nid = int(rng.choice([16, 48, 64]))
-        kind = str(rng.choice(["plain", "batch", "oneway", "noreattach"]))
-        seed = int(rng.randint(1, 1000))
-        try:
-            if kind == "batch":
-                n2 = max(N // 2, 4)
-                e2 = max(min(E // 4 * 2, (n2 * (n2 - 1) // 6) * 2), 2)
-                gs = [synth.make_graph(n2, e2, T=5, seed=seed + k, node_in_dim=nid) for k in range(2)]
-                g = synth.batch_graphs(gs)
-                ei = g["edge_index"].copy()
-                ei[:, 0] = [1, 1]          # a self loop
-                g["edge_index"] = ei
-            else:
-                g = synth.make_graph(N, E, T=max(2, min(6, N)), seed=seed, node_in_dim=nid)
-        except ValueError:      # (the generator cannot place that many distinct cross-frame pairs on so few nodes)
+        c = gen_case(rng, a.bf16_train)
+        if c is None:
             print("case %2d skipped (generator)" % i, flush=True)
             continue
+        d, L, agg, N, E, nid, kind, seed = (c[k] for k in ("d", "L", "agg", "N", "E", "nid", "kind", "seed"))
+        params, W, g, tiny = c["params"], c["W"], c["g"], c["tiny"]
         try:
-            if kind == "oneway":            # only the (row < col) halves: no flow_in edge at all
-                h = g["edge_index"].shape[1] // 2
-                g["edge_index"] = g["edge_index"][:, :h].copy()
-                g["edge_attr"] = g["edge_attr"][:h].copy()
-            params = synth.model_params(d, L, agg, node_in_dim=nid)
-            if kind == "noreattach":
-                params["reattach_initial_nodes"] = bool(rng.randint(2))
-                params["reattach_initial_edges"] = bool(rng.randint(2))
-            W = synth.make_weights(params, seed=seed, gain=0.8)
-            # (a handful of edges: a parameter gradient is a sum of a few terms that may cancel -- its RELATIVE error is then a
-            # matter of conditioning, not of the kernels; seen: 1.8e-5 on an 8-element tensor of a 4-edge graph, in fp32 mode)
-            tiny = g["edge_index"].shape[1] < 64
             saved = dict(tp.TOLS)
             if tiny:
                 tp.TOLS = {k: (10 * v[0], 10 * v[1]) for k, v in saved.items()}
