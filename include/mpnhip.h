@@ -238,6 +238,31 @@ int mpnhip_segment_reduce(const float* src, const int64_t* row, int64_t m, int d
 int mpnhip_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t m, int n,
                   int k, int relu, void* stream);
 
+/* One nn.Linear (+ ReLU) of models/mlp.py:27 in BASELINE.json's configs[4] arithmetic -- what mpnhip_forward / mpnhip_backward run
+ * for the node-side products of models/mpn.py:69,87,93,97-99 when mpnhip_model.precision == MPNHIP_PREC_BF16 (round 5: the 128 x 128
+ * tiled kernel, csrc/gemm_bf16.hip):
+ *     y[m][n] = mask( act( sum_k bf16(xcat[m][k]) * bf16(w[n][k]) + b[n] + c_in[m][n] ) (+ y[m][n]) ),  fp32 accumulation,
+ * xcat = [x | x2] (torch.cat of the re-attached initial and the current features, mpn.py:369-373, never materialised).
+ * Operands are fp32 rows rounded to bf16 (RNE) as they are staged, or ALREADY bf16 rows in memory (x_bf16 / w_bf16 != 0: the
+ * pointers are bfloat16 bit patterns, leading dims count elements; K, ksplit and the leading dims multiples of 8, 16-byte bases).
+ * b, c_in, mask (value kept where mask > 0), x2 and y16 (a bf16 mirror of the result) may be NULL.  n % 4 == 0, k % 4 == 0. */
+typedef struct mpnhip_linear_bf16_args {
+    const void* x;  int64_t ldx;        /* [m, ksplit] */
+    const void* x2; int64_t ldx2;       /* [m, k - ksplit] or NULL (then ksplit == k) */
+    const void* w;  int64_t ldw;        /* [n, k] */
+    const float* b;                     /* [n] */
+    const float* c_in; int64_t ldc_in;  /* [m, n] added before the activation */
+    const float* mask; int64_t ldmask;  /* [m, n] */
+    float* y; int64_t ldy;              /* [m, n] */
+    uint16_t* y16; int64_t ldy16;       /* [m, n] bf16 mirror of y */
+    int64_t m;
+    int n, k, ksplit;
+    int x_bf16, w_bf16, relu, accumulate;
+} mpnhip_linear_bf16_args;
+int mpnhip_linear_bf16(const mpnhip_linear_bf16_args* args, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even; NaN stays NaN): the packed weight images / feature mirrors of that mode. n % 4 == 0. */
+int mpnhip_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
 /* The weight / bias gradient autograd derives for one nn.Linear of models/mlp.py, batched over the
  * message-passing steps that share the weight:  grad_w[o][c] += sum_b sum_m dZ[b][m][o] * H[b][m][c],  grad_b[o] += sum dZ[b][m][o].
  * dZ [nbatch][rows][n_out] (gradient at the layer's pre-activation), H [nbatch][rows][k_in] (the layer's input), both dense
@@ -463,6 +488,9 @@ int mpnhip_time_weight_grad_prec(const float* dZ, const float* H, int64_t rows, 
 /* Average duration (us) of `iters` launches of y = relu(x W^T + b). */
 int mpnhip_time_linear(const float* x, const float* w, const float* b, float* y, int64_t m, int n, int k, int iters,
                        float* avg_us, void* stream);
+
+/* Average duration (us) of `iters` launches of mpnhip_linear_bf16. */
+int mpnhip_time_linear_bf16(const mpnhip_linear_bf16_args* args, int iters, float* avg_us, void* stream);
 
 #ifdef __cplusplus
 }

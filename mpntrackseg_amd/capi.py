@@ -47,6 +47,17 @@ class Model(C.Structure):
     ]
 
 
+class LinearBf16Args(C.Structure):
+    """``mpnhip_linear_bf16_args`` (include/mpnhip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64), ("x2", C.c_void_p), ("ldx2", C.c_int64), ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("b", C.c_void_p), ("c_in", C.c_void_p), ("ldc_in", C.c_int64), ("mask", C.c_void_p), ("ldmask", C.c_int64),
+        ("y", C.c_void_p), ("ldy", C.c_int64), ("y16", C.c_void_p), ("ldy16", C.c_int64), ("m", C.c_int64),
+        ("n", C.c_int), ("k", C.c_int), ("ksplit", C.c_int), ("x_bf16", C.c_int), ("w_bf16", C.c_int), ("relu", C.c_int),
+        ("accumulate", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/mpnhip.h one to one (tests/test_capi_symbols.py
 # checks that every function the header declares is listed here and exported by the library)
 _P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
@@ -80,6 +91,9 @@ SIGNATURES = {
                                             _P, _Z, _P]),
     "mpnhip_bn_relu_dropout_backward": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, C.c_float, C.c_uint64, _P, _P, _P, _P, _Z, _P]),
     "mpnhip_linear": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _P]),
+    "mpnhip_linear_bf16": (_I, [_P, _P]),
+    "mpnhip_to_bf16": (_I, [_P, _P, _L, _P]),
+    "mpnhip_time_linear_bf16": (_I, [_P, _I, C.POINTER(C.c_float), _P]),
     "mpnhip_weight_grad_workspace_bytes": (_Z, [_I, _I, _L, _I]),
     "mpnhip_weight_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "mpnhip_time_weight_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _Z, _I, C.POINTER(C.c_float), _P]),

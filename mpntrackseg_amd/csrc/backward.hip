@@ -263,6 +263,7 @@ struct BwdPlan {
     size_t wt_scratch_floats;
     float* wt_keep[2];                  // ... the node update's (0) and the projections' (1) blocks, transposed once per backward
     size_t wt_keep_floats[2];
+    unsigned short* wt_keep16[2];       // ... and their bf16 images: the B operand of the tiled bf16 GEMM as bf16 rows (gemm_bf16.hip)
     // bf16-operand training on the fused kernels (FwdPlan::b16): the dZ blocks above are bf16 rows (half the floats), the gradient
     // w.r.t. e_s travels between the steps in two fp32 buffers, and the backward chain kernel has its own pair images
     bool b16;
@@ -361,6 +362,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
         p.wt_keep_floats[0] = m.precision == MPNHIP_PREC_BF16 && m.node.n_layers >= 1 ? (size_t)d.dn * m.node.in_dim : 0;
         p.wt_keep_floats[1] = m.precision == MPNHIP_PREC_BF16 ? (size_t)d.pw * d.dn : 0;
         for (int i = 0; i < 2; ++i) p.wt_keep[i] = a.f(p.wt_keep_floats[i]);
+        for (int i = 0; i < 2; ++i) p.wt_keep16[i] = reinterpret_cast<unsigned short*>(a.f((p.wt_keep_floats[i] + 1) / 2));
     }
     size_t sl = 0;
     auto upd = [&](size_t f) { sl = f > sl ? f : sl; };
@@ -443,8 +445,8 @@ static thread_local float* g_wt_scratch = nullptr;
 static thread_local size_t g_wt_scratch_floats = 0;
 // ... and two blocks that are KEPT for the whole backward: the node update's and the per-node projections' weights are the operands of
 // an activation-gradient product in every step (22 transpositions of the same two blocks per cfg-E step before round 4, 25 - 30 us each)
-struct WtKeep { float* wt; size_t floats; bool valid; };
-static thread_local WtKeep g_wt_keep[2] = {{nullptr, 0, false}, {nullptr, 0, false}};
+struct WtKeep { float* wt; size_t floats; bool valid; unsigned short* wt16; };
+static thread_local WtKeep g_wt_keep[2] = {{nullptr, 0, false, nullptr}, {nullptr, 0, false, nullptr}};
 
 // dW += dZ^T [H | H2] (+ bias) for one or two groups, over nbatch row blocks
 static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand dZ, const int* dz_idx, Operand H, Operand H2, int csplit,
@@ -543,8 +545,12 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
             WtKeep* kp = (keep >= 0 && ngroups == 1 && g_wt_keep[keep].wt && (size_t)K * N <= g_wt_keep[keep].floats) ? &g_wt_keep[keep] : nullptr;
             if (kp) wt = kp->wt;
             if (!kp || !kp->valid) MPN_TRY(transpose_padded(W[q], ldw, 0, K, N, wt, K, N, s));
+            // the kept blocks also as bf16 rows (rounded once per backward instead of in every block of every step's product)
+            const bool img16 = kp && kp->wt16 && K % 8 == 0 && ((size_t)K * N) % 4 == 0 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
+            if (img16 && !kp->valid) MPN_TRY(to_bf16_rows(wt, kp->wt16, (int64_t)K * N, s));
             if (kp) kp->valid = true;   // (one stream: the later steps' products are ordered behind this transposition)
-            g.B = wt;
+            g.B = img16 ? reinterpret_cast<const float*>(kp->wt16) : wt;
+            g.b16 = img16 ? 1 : 0;
             g.ldb = K;
         }
         g.C = C;
@@ -729,8 +735,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     g_wt_scratch = p.wt_scratch;
     g_wt_scratch_floats = p.wt_scratch_floats;
     struct KeepScope {   // (valid only inside this call: the blocks live in this call's workspace)
-        KeepScope(const BwdPlan& q) { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {q.wt_keep_floats[i] ? q.wt_keep[i] : nullptr, q.wt_keep_floats[i], false}; }
-        ~KeepScope() { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {nullptr, 0, false}; }
+        KeepScope(const BwdPlan& q) { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {q.wt_keep_floats[i] ? q.wt_keep[i] : nullptr, q.wt_keep_floats[i], false, q.wt_keep_floats[i] ? q.wt_keep16[i] : nullptr}; }
+        ~KeepScope() { for (int i = 0; i < 2; ++i) g_wt_keep[i] = {nullptr, 0, false, nullptr}; }
     } keep_scope(p);
     if (getenv("MPNHIP_NO_WT_KEEP")) for (int i = 0; i < 2; ++i) g_wt_keep[i].wt = nullptr;
     GraphView g;

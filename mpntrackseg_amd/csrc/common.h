@@ -73,6 +73,11 @@ struct GemmGroup {
     const int* row_end;    // device int: one past the last row (nullptr -> m_static)
     int64_t lda, lda2, ldb, ldg1, ldg2, ldmask, ldc;
     int64_t m_static;      // row count when row_end == nullptr
+    // bf16-operand mode, tiled kernel (gemm_bf16.hip) only: the operand is bf16 ROWS in memory -- A / A2 (a16) or B (b16) point at
+    // unsigned shorts, their leading dims count them; C16: a bf16 mirror of the result, [rows][ldc16] (row m, no scatter)
+    int a16, b16;
+    unsigned short* C16;
+    int64_t ldc16;
 };
 
 struct GemmArgs {
@@ -87,6 +92,8 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& args, int a_layout, int b_layout, hipStream_t stream);
+// MPNHIP_PREC_BF16 at large row counts / with bf16 rows in memory (gemm_bf16.hip); false: not a shape of that kernel
+bool launch_gemm_bf16_tiled(const GemmArgs& args, hipStream_t stream, int* status);
 // operand precision of the calling thread's GEMMs (mpnhip_model.precision): 0 fp32, 1 bf16 operands / fp32 accumulate
 void set_gemm_precision(int p);
 int gemm_precision();
@@ -152,7 +159,7 @@ struct WpJob {             // one product (one direction group of it), as the ke
     int red_block0;        // ... in the slab-sum launch
 };
 constexpr int WP_MAX_JOBS = 16;
-struct WpTable { WpJob job[WP_MAX_JOBS]; int njobs; };
+struct WpTable { WpJob job[WP_MAX_JOBS]; int njobs; int debug; };   // debug: timing ablations (MPNHIP_WP_DEBUG; results wrong)
 struct WpProduct {         // host-side description of one product
     const float* dZ; int64_t ldz, z_bstride;
     const float* H; int64_t ldh, h_bstride;
@@ -346,7 +353,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_NODE_CHAIN_BWD, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_NODE_CHAIN_BWD, PC_GEMM_BF16_TILED, PC_GEMM_BF16_RING, PC_COUNT
 };
 void count_path(int id);
 

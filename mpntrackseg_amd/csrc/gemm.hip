@@ -551,6 +551,11 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
                   (!g.mask || (al16(g.mask) && g.ldmask % 4 == 0));
     }
     a.epi_vec = epi_vec ? 1 : 0;
+    for (int i = 0; i < a.ngroups; ++i)
+        if ((a.g[i].a16 || a.g[i].b16 || a.g[i].C16) && (!fast || !epi_vec || bl != B_KCONTIG)) {
+            set_error("gemm: bf16 operand rows need the tiled bf16 kernel's alignment (K, leading dims, N multiples of 4 / 8; 16-byte bases)");
+            return MPNHIP_ERR_UNSUPPORTED;
+        }
     if (!fast) {
         const GemmGroup& G0 = a.g[0];
         if (a.ngroups == 1 && a.K >= 1 && a.K <= 8 && a.ksplit == a.K && bl == B_KCONTIG && !G0.A2 && !G0.G1 && !G0.G2 && !G0.mask &&
@@ -574,6 +579,22 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
     const int N = a.N;
     const int64_t M = a.m_upper;
     const int nt = (N + 31) / 32;  // 32-wide column tiles needed
+    {
+        // bf16-operand mode: the 128 x 128 tiled kernel (gemm_bf16.hip) from a few thousand rows, and whenever an operand is bf16
+        // rows in memory (only that kernel reads them)
+        bool rows16 = false;
+        for (int i = 0; i < a.ngroups; ++i) rows16 = rows16 || a.g[i].a16 || a.g[i].b16 || a.g[i].C16;
+        int prec = g_precision;
+        if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);
+        if (bl == B_KCONTIG && (rows16 || (prec == 1 && M >= 4096 && !a.small_tiles))) {
+            int st = MPNHIP_OK;
+            if (launch_gemm_bf16_tiled(a, s, &st)) {
+                if (st == MPNHIP_OK) count_path(PC_GEMM_BF16);
+                return st;
+            }
+        }
+        if (rows16) { set_error("gemm: bf16 operand rows [%lld x %d x %d] are not a shape of the tiled bf16 kernel", (long long)M, N, a.K); return MPNHIP_ERR_UNSUPPORTED; }
+    }
     if (M >= 8192 && !a.small_tiles) {
         // waves stacked along M (block 128 x 32 TN): pick the strip width that wastes the fewest tiles,
         // widest first (A is then re-read from L2 the fewest times)

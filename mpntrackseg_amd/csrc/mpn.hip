@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback", "edge_chain_bwd_bf16", "node_chain_bwd"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback", "edge_chain_bwd_bf16", "node_chain_bwd", "gemm_bf16_tiled", "gemm_bf16_ring"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }
@@ -348,6 +348,10 @@ struct StepIO {
     int last;                             //    (node_step32: the reference's node width)
     float* P_next;                        //    where the next step's projections go (its step buffers; inference: the shared ones)
     const unsigned short* nc_img;         //    non-null: node_chain.hip's kernel (dn = 64 / 128, split precision) instead of node_step32
+    // MPNHIP_PREC_BF16 with bf16 rows (gemm_bf16.hip): images of the packed projection / node-update weights, mirrors of xa / xb,
+    // and where the mirror of x_new goes
+    const unsigned short* Wnode16; const unsigned short* Wu16; const unsigned short* xa16; const unsigned short* xb16;
+    unsigned short* x_new16;
 };
 
 // One MetaLayer.forward (mpn.py:33-54) (+ classifier, mpn.py:114) on prepared weights.
@@ -367,7 +371,13 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         a.ngroups = 1; a.N = d.pw; a.relu = 0; a.m_upper = N;
         GemmGroup& G = a.g[0];
         init_group(G);
-        if (io.P0 && io.xb) {
+        if (io.Wnode16 && io.xa16) {
+            // bf16 rows in memory, the whole K (both segments), biases in the epilogue: the LDS-DMA ring kernel
+            a.K = d.kx; a.ksplit = io.xb16 ? io.kxa : d.kx;
+            G.A = reinterpret_cast<const float*>(io.xa16); G.lda = io.ldxa; G.a16 = 1;
+            G.A2 = reinterpret_cast<const float*>(io.xb16); G.lda2 = io.ldxb;
+            G.B = reinterpret_cast<const float*>(io.Wnode16); G.ldb = d.kx; G.b16 = 1; G.bias = bnode;
+        } else if (io.P0 && io.xb) {
             // xa (the re-attached initial features) does not change from step to step: its product is P0
             a.K = d.kx - io.kxa; a.ksplit = a.K;
             G.A = io.xb; G.lda = io.ldxb;
@@ -518,6 +528,16 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         prof_begin(PROF_AGG, s);
         MPN_TRY(aggregate(g, b.M, d.dn, m.agg, b.AGG, save_arg ? b.ARG : nullptr, s));
         prof_end(PROF_AGG, s);
+    }
+    if (io.Wu16 && N > 0) {
+        // bf16 weight image; the bf16 mirror of the new node features (the next step's projections read it) leaves with the result
+        GemmArgs a = {};
+        a.ngroups = 1; a.N = d.dn; a.K = 2 * d.dn; a.ksplit = a.K; a.relu = 1; a.m_upper = N;
+        GemmGroup& G = a.g[0];
+        init_group(G);
+        G.A = b.AGG; G.lda = 2 * d.dn; G.B = reinterpret_cast<const float*>(io.Wu16); G.ldb = 2 * d.dn; G.b16 = 1;
+        G.bias = m.node.bias[0]; G.C = io.x_new; G.ldc = d.dn; G.C16 = io.x_new16; G.ldc16 = d.dn; G.m_static = N;
+        return launch_gemm(a, A_KCONTIG, B_KCONTIG, s);
     }
     MPN_TRY(linear(b.AGG, 2 * d.dn, m.node.weight[0], m.node.bias[0], io.x_new, d.dn, N, d.dn, 2 * d.dn, 1, s));
     return MPNHIP_OK;
@@ -707,7 +727,14 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         // (after the flush: the unit images of the fused node-side kernel read the packed projection weights)
         if (p.nc_img && m.precision == MPNHIP_PREC_FP32_SPLIT)
             MPN_TRY(pack_node_chain(m.node.weight[0], p.Wnode, d.dn, d.pw, d.kx, p.nc_img, s));
+        // ... and so do the bf16 images of the node-side weights (gemm_bf16.hip reads bf16 rows)
+        if (p.Wnode16 && ((size_t)d.pw * d.kx) % 4 == 0 && ((size_t)d.dn * 2 * d.dn) % 4 == 0 && (((uintptr_t)m.node.weight[0]) & 15) == 0) {
+            MPN_TRY(to_bf16_rows(p.Wnode, p.Wnode16, (int64_t)d.pw * d.kx, s));
+            MPN_TRY(to_bf16_rows(m.node.weight[0], p.Wu16, (int64_t)d.dn * 2 * d.dn, s));
+        }
     }
+    // bf16 rows for the node-side products of this call (weights at the head of the workspace: kept with the other images)
+    const bool rows16 = p.Wnode16 && p.xb_hist && ((size_t)d.pw * d.kx) % 4 == 0 && (((uintptr_t)m.node.weight[0]) & 15) == 0;
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
     float* hid[MPNHIP_MAX_LAYERS];
@@ -726,7 +753,10 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
 
     const size_t xs = (size_t)N * d.dn, es = (size_t)E * d.de;
     if (p.eb_hist && p.cb.ok && (!save || p.b16) && es && d.L > 0) MPN_TRY(to_bf16_rows(e0, p.eb_hist, (int64_t)es, s));   // the encoder output as slot 0 of the bf16 mirror
-    const bool hoist = d.nf == 2 && d.L > 1;
+    if (rows16 && xs && d.L > 0) MPN_TRY(to_bf16_rows(x0, p.xb_hist, (int64_t)xs, s));   // the encoder output as slot 0 of the node mirror
+    // (bf16 rows: the projections multiply [x0 | x] whole -- twice the MFMAs, which this product has to spare, instead of streaming
+    // the [N, pw] fp32 table P0 back in every step)
+    const bool hoist = d.nf == 2 && d.L > 1 && !rows16;
     // few nodes at the reference's width: P0 and the first step's projections by one small kernel (decided with fuse_node below)
     const bool proj_small = hoist && d.dn == 32 && N > 0 && N <= 4096 && d.kx == 2 * d.dn && m.precision != MPNHIP_PREC_BF16 &&
                             ((((uintptr_t)p.Wnode) | ((uintptr_t)p.P0) | ((uintptr_t)x0)) & 15) == 0 && !getenv("MPNHIP_NO_NODE_FUSION");
@@ -807,6 +837,12 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         io.x_new = p.x_hist + xs * cur;
         io.logits = logits + (size_t)step * E;
         io.P0 = hoist ? p.P0 : nullptr;
+        if (rows16) {
+            io.Wnode16 = p.Wnode16; io.Wu16 = p.Wu16;
+            io.xa16 = d.nf == 2 ? p.xb_hist : p.xb_hist + xs * prev;
+            io.xb16 = d.nf == 2 ? p.xb_hist + xs * prev : nullptr;
+            io.x_new16 = p.xb_hist + xs * cur;
+        }
         io.Q0 = hoist_e ? p.Q0 : nullptr;
         io.fuse_node = fuse_node ? 1 : 0;
         io.nc_img = fuse_node_chain ? p.nc_img : nullptr;

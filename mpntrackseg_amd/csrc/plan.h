@@ -151,6 +151,12 @@ struct FwdPlan {
     ChainWeights cw;
     ChainBf16 cb;
     unsigned short* nc_img;   // unit images of the fused node-side kernel (node_chain.hip) or nullptr
+    // MPNHIP_PREC_BF16, round 5 (gemm_bf16.hip): bf16 images of the packed projection weights [pw][kx] and of the node update's
+    // weight [dn][2 dn] (weight images: at the head of the plan), and bf16 mirrors of the node features, one per history slot
+    // [hist_slots][N, dn] -- the A operand of the projections is bf16 rows in memory, [x0 | x] as two K segments
+    unsigned short* Wnode16;
+    unsigned short* Wu16;
+    unsigned short* xb_hist;
     float* P_alt;  // [N, pw] (inference, dn = 32) or nullptr
     int* barrier;  // 4 words: grid barrier of the one-launch step loop
     float* P0;     // [N, pw] step-invariant half of the per-node projections: x0 Wnode[:, :dn]^T + bnode
@@ -234,6 +240,10 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.nc_img = nullptr;
     if (node_chain_supported(d.dn, d.pw, d.kx) && m.node.n_layers == 1)
         p.nc_img = reinterpret_cast<unsigned short*>(a.f((node_chain_image_shorts(d.dn, d.pw, nullptr) + 1) / 2));
+    // (bf16 rows for the tiled / ring GEMM kernels: 16-byte pieces of 8 elements)
+    const bool rows16 = m.precision == MPNHIP_PREC_BF16 && d.kx % 8 == 0 && d.dn % 8 == 0 && m.node.n_layers == 1 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
+    p.Wnode16 = rows16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)d.pw * d.kx + 1) / 2)) : nullptr;
+    p.Wu16 = rows16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)d.dn * 2 * d.dn + 1) / 2)) : nullptr;
     p.P0 = a.f((size_t)N * d.pw);
     p.P_alt = (!save && d.dn == 32) ? a.f((size_t)N * d.pw) : nullptr;   // second projection buffer of the one-launch step loop (persist32.hip)
     p.barrier = a.i(4);
@@ -253,6 +263,7 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     p.hist_slots = save ? d.L + 1 : 3;
     p.x_hist = a.f((size_t)p.hist_slots * N * d.dn);
     p.e_hist = a.f((size_t)p.hist_slots * E * d.de);
+    p.xb_hist = rows16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)p.hist_slots * N * d.dn + 1) / 2)) : nullptr;
     p.b16 = save && cb_shapes && chain_bf16_train_ok(m, d);
     // (inference in the bf16-operand mode keeps the same mirror over its three history slots: the chain kernel reads its first-layer
     // input as bf16 rows -- the values it rounds to anyway -- and writes the new features as bf16 for the next step)

@@ -98,7 +98,7 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const b
 // B16: both operands are bf16 rows in memory (the dZ blocks and saved activations of the bf16-operand chain kernels,
 // edge_chain_bf16*.hip): a stage is loaded as 8-byte pieces (4 columns) and stored to LDS as it is -- one piece, no split.
 template <int TM, int TN, bool B16 = false>
-__device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const int by, char* lds) {
+__device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const int by, char* lds, const int dbg = 0) {
     constexpr int BO = 64 * TM, BC = 64 * TN;
     constexpr int ES = B16 ? 2 : 4;   // bytes per source element
     using StageT = std::conditional_t<B16, uint2, f32x4>;
@@ -303,11 +303,25 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
             // steady state (every stage of the round has a successor D stages on: straight-line code, the loads' waits are counted)
             for (; st + 2 * D <= nfull; st += D) {
                 wp_static_for<0, D>([&](auto d) {
+#ifndef MPNHIP_WP_ABLATE
                     store(d, WP_KB);
                     __syncthreads();
                     WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
                     products();
                     __syncthreads();
+#else
+                    {   // ablation build (make EXTRA=-DMPNHIP_WP_ABLATE, MPNHIP_WP_DEBUG=bits): 1 no products, 2 no split / LDS stores, 4 no loads, 8 no barriers
+                        if (!(dbg & 2)) store(d, WP_KB);
+                        else {
+                            _Pragma("unroll") for (int j = 0; j < PZ; ++j) asm volatile("" :: "v"(zreg[d.value][j]));
+                            _Pragma("unroll") for (int j = 0; j < PH; ++j) asm volatile("" :: "v"(hreg[d.value][j]));
+                        }
+                        if (!(dbg & 8)) __syncthreads();
+                        if (!(dbg & 4)) WP_LOAD(zreg[d.value], hreg[d.value], r0 + (st + d.value + D) * WP_KB);
+                        if (!(dbg & 1)) products();
+                        if (!(dbg & 8)) __syncthreads();
+                    }
+#endif
                 });
             }
             for (; st < nfull; st += D) {
@@ -520,22 +534,22 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
     const int ntiles = J.tiles_o * J.tiles_c;
     const int by = local / ntiles, tile = local - by * ntiles;
     switch (J.variant) {
-        case 0: wp_block<5, 1>(J, tile, by, wp_lds); break;
-        case 1: wp_block<1, 5>(J, tile, by, wp_lds); break;
-        case 2: wp_block<4, 1>(J, tile, by, wp_lds); break;
-        case 3: wp_block<1, 1>(J, tile, by, wp_lds); break;
+        case 0: wp_block<5, 1>(J, tile, by, wp_lds, tab.debug); break;
+        case 1: wp_block<1, 5>(J, tile, by, wp_lds, tab.debug); break;
+        case 2: wp_block<4, 1>(J, tile, by, wp_lds, tab.debug); break;
+        case 3: wp_block<1, 1>(J, tile, by, wp_lds, tab.debug); break;
         case 6: wp_block_vec(J, by, wp_lds); break;
         case 7: wp_block_small(J, by, wp_lds); break;
         // bf16 source rows (one piece: ten accumulator tiles per wave fit): the shapes of the 256-d / 128-d / narrower models
-        case 8: wp_block<5, 2, true>(J, tile, by, wp_lds); break;
-        case 9: wp_block<2, 5, true>(J, tile, by, wp_lds); break;
-        case 10: wp_block<4, 2, true>(J, tile, by, wp_lds); break;
-        case 11: wp_block<2, 4, true>(J, tile, by, wp_lds); break;
-        case 12: wp_block<1, 2, true>(J, tile, by, wp_lds); break;
-        case 13: wp_block<2, 1, true>(J, tile, by, wp_lds); break;
-        case 14: wp_block<1, 1, true>(J, tile, by, wp_lds); break;
-        case 15: wp_block<2, 2, true>(J, tile, by, wp_lds); break;
-        default: wp_block<2, 2>(J, tile, by, wp_lds); break;
+        case 8: wp_block<5, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 9: wp_block<2, 5, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 10: wp_block<4, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 11: wp_block<2, 4, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 12: wp_block<1, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 13: wp_block<2, 1, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 14: wp_block<1, 1, true>(J, tile, by, wp_lds, tab.debug); break;
+        case 15: wp_block<2, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+        default: wp_block<2, 2>(J, tile, by, wp_lds, tab.debug); break;
     }
 }
 
@@ -786,6 +800,7 @@ int wp_batch_flush(hipStream_t s) {
     }();
     (void)attr_set;
     count_path(PC_TN_PANEL_LAUNCH);
+    if (const char* e = getenv("MPNHIP_WP_DEBUG")) b->tab.debug = atoi(e); else b->tab.debug = 0;
     prof_begin(PROF_TN, s, b->bytes);   // (HBM-bound by design: the hook's work figure is the launch's operand bytes)
     {
         hipEvent_t e0, e1;

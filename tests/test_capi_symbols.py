@@ -53,6 +53,12 @@ def test_struct_layout_matches_c():
     assert capi.Model.weights_prepacked.offset == capi.Model.precision.offset + 4
 
 
+def test_linear_bf16_args_layout_matches_c():
+    # 15 pointers / int64 fields, int64 m, 7 ints, padded to 8
+    assert ctypes.sizeof(capi.LinearBf16Args) == 15 * 8 + 8 + 7 * 4 + 4
+    assert capi.LinearBf16Args.m.offset == 120 and capi.LinearBf16Args.n.offset == 128 and capi.LinearBf16Args.accumulate.offset == 152
+
+
 def test_precision_codes_match_header():
     src = open(os.path.join(REPO, "include", "mpnhip.h")).read()
     codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define MPNHIP_PREC_([A-Z0-9_]+) (\d+)", src)}
