@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := mpntrackseg_amd/csrc
-SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_bf16.hip $(CSRC)/gemm_tn.hip $(CSRC)/wgrad_panel.hip $(CSRC)/edge_chain.hip $(CSRC)/edge_chain_bf16.hip $(CSRC)/edge_chain_bf16_bwd.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/node_chain.hip $(CSRC)/persist32.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/bn_dropout.hip $(CSRC)/attention.hip $(CSRC)/graph_build.hip $(CSRC)/tracker.hip
+SRCS := $(CSRC)/gemm.hip $(CSRC)/gemm_bf16.hip $(CSRC)/gemm_tn.hip $(CSRC)/wgrad_panel.hip $(CSRC)/wgrad_rows16.hip $(CSRC)/edge_chain.hip $(CSRC)/edge_chain_bf16.hip $(CSRC)/edge_chain_bf16_bwd.hip $(CSRC)/graph_prep.hip $(CSRC)/segment.hip $(CSRC)/node_chain.hip $(CSRC)/persist32.hip $(CSRC)/mpn.hip $(CSRC)/backward.hip $(CSRC)/loss.hip $(CSRC)/bn_dropout.hip $(CSRC)/attention.hip $(CSRC)/graph_build.hip $(CSRC)/tracker.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := $(CSRC)/libmpnhip.so
 # EXTRA=-DMPNHIP_CHAIN_TS builds the fused chain kernels with per-phase cycle stamps (tools/chain_stamps.py)

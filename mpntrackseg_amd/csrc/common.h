@@ -173,9 +173,13 @@ struct WpProduct {         // host-side description of one product
     int pieces;            // 3 (fp32 from three bf16 pieces) or 1 (bf16-rounded operands); 0 = 3
     int src16;             // bf16 source rows (WpJob::src16); needs pieces == 1
 };
-struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes; int nblocks, nred; bool batched;
+// (nblocks2 / bytes2: the jobs of wgrad_rows16.hip's kernel -- variant >= 16, their block0 counts inside that launch)
+struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flops, bytes, bytes2; int nblocks, nblocks2, nred; bool batched;
                  hipStream_t stream; bool has_stream; };   // has_stream: the stream every flush of this batch goes to is known (wp_batch_roll)
 bool wp_eligible(const WpProduct& p);
+// wgrad_rows16.hip: the one-pass LDS-DMA kernel for bf16 rows at the 256-d widths
+int r16_variant(int n_out, int k_in, int* tiles_c);
+int launch_wgrad_rows16(const WpTable& tab, int nblocks, hipStream_t s);
 // (batched: the job shares its launch with the other products of a group of steps -- fewer row chunks per job)
 size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched, bool src16 = false);
 void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched);   // opens b for the calling thread
@@ -353,7 +357,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 enum PathCounter {
     PC_CHAIN_FWD = 0, PC_CHAIN_FWD_SPLIT, PC_CHAIN_BWD, PC_CHAIN_BWD_SPLIT, PC_AGGREGATE, PC_AGGREGATE_BLOCK, PC_NODE_STEP32,
     PC_NODE_STEP32_BWD, PC_SEG_SHORT, PC_SEG_BLOCK, PC_SEG_BLOCK3, PC_EDGE_ENCODER, PC_EDGE_ENCODER_BWD, PC_TN_MFMA, PC_TN_SMALL,
-    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_NODE_CHAIN_BWD, PC_GEMM_BF16_TILED, PC_GEMM_BF16_RING, PC_COUNT
+    PC_TN_GENERIC, PC_GEMM_FP32, PC_GEMM_SPLIT, PC_GEMM_BF16, PC_WEIGHT_PACK, PC_SEG_SHORT3, PC_GEMM_SPLITK, PC_CHAIN_FWD_BF16, PC_TN_PANEL, PC_TN_PANEL_LAUNCH, PC_NODE_CHAIN, PC_PERSIST32, PC_TN_PANEL_FALLBACK, PC_CHAIN_BWD_BF16, PC_NODE_CHAIN_BWD, PC_GEMM_BF16_TILED, PC_GEMM_BF16_RING, PC_TN_ROWS16, PC_COUNT
 };
 void count_path(int id);
 

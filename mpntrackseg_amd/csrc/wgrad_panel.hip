@@ -527,8 +527,10 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
 __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
     extern __shared__ __attribute__((aligned(16))) char wp_lds[];
     const int b = blockIdx.x;
-    int j = 0;
-    for (int i = 1; i < tab.njobs; ++i) j = b >= tab.job[i].block0 ? i : j;
+    int j = -1;
+    for (int i = 0; i < tab.njobs; ++i)
+        if (tab.job[i].variant < 16 && b >= tab.job[i].block0) j = i;   // (variants >= 16: wgrad_rows16.hip's launch)
+    if (j < 0) return;
     const WpJob& J = tab.job[j];
     const int local = b - J.block0;
     const int ntiles = J.tiles_o * J.tiles_c;
@@ -626,9 +628,15 @@ bool wp_is_small(int n_out, int k_in) {   // wp_block_small's shapes
 }
 const WpVariant kVariants16[8] = {{5, 2}, {2, 5}, {4, 2}, {2, 4}, {1, 2}, {2, 1}, {1, 1}, {2, 2}};   // kernel cases 8 .. 15
 
-void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bool src16 = false) {
+// rows16: the product's operands meet the LDS-DMA kernel's alignment (16-byte rows): its variants 16 .. 19 where the shape has one
+void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bool src16 = false, bool rows16 = false) {
     if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
     if (wp_is_small(n_out, k_in)) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                   // wp_block_small
+    if (src16 && rows16) {
+        int tc = 1;
+        const int v = r16_variant(n_out, k_in, &tc);
+        if (v >= 0) { *variant = v; *tiles_o = 1; *tiles_c = tc; return; }
+    }
     if (src16) {
         // cost = the columns every operand row is staged with, summed over the output tiles (a partial last tile stages only its
         // live columns), + a term for the accumulator tiles that stay empty (MFMAs on zeros)
@@ -713,9 +721,16 @@ bool wp_eligible(const WpProduct& p) {
 
 size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched, bool src16) {
     int v, to, tc, chunk, nsplit;
-    wp_choose(n_out, k_in, &v, &to, &tc, src16);
-    wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit);
-    return ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
+    size_t need = 0;
+    // (bf16 rows: which of the two kernels takes the product depends on the operands' alignment, known only when it is added --
+    // reserve for the one that cuts more row chunks)
+    for (int pass = 0; pass < (src16 ? 2 : 1); ++pass) {
+        wp_choose(n_out, k_in, &v, &to, &tc, src16, pass == 1);
+        wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit);
+        const size_t f = ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
+        need = f > need ? f : need;
+    }
+    return need;
 }
 
 void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched) {
@@ -727,6 +742,8 @@ void wp_batch_begin(WpBatch* b, float* slab, size_t slab_floats, bool batched) {
     b->flops = 0.0;
     b->bytes = 0.0;
     b->nblocks = 0;
+    b->nblocks2 = 0;
+    b->bytes2 = 0.0;
     b->nred = 0;
     b->stream = nullptr;
     b->has_stream = false;
@@ -751,6 +768,8 @@ bool wp_batch_roll(int* status) {
 bool wp_batch_open() { return g_wp != nullptr; }
 void wp_batch_abort() { g_wp = nullptr; }
 
+static bool ranged_gather(const WpProduct& p) { return p.dz_idx || p.h_idx || p.H2; }
+
 // records the n (1 or 2: the direction groups of one product) jobs, or none of them
 bool wp_batch_add(const WpProduct* ps, int n) {
     WpBatch* b = g_wp;
@@ -766,7 +785,10 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         const bool ranged = p.row_begin || p.row_end;
         WpJob& J = b->tab.job[b->tab.njobs];
         J = WpJob{};
-        wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c, p.src16 != 0);
+        auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+        const bool rows16 = p.src16 && !ranged_gather(p) && al16(p.dZ) && al16(p.H) && p.ldz % 8 == 0 && p.ldh % 8 == 0 && p.z_bstride % 8 == 0 &&
+                            p.h_bstride % 8 == 0 && p.ldz < ((int64_t)1 << 28) && p.ldh < ((int64_t)1 << 28);
+        wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c, p.src16 != 0, rows16);
         J.src16 = p.src16 ? 1 : 0;
         wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
@@ -776,9 +798,16 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         J.slab = b->slab + b->used;
         J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
         J.n_out = p.n_out; J.k_in = p.k_in; J.nbatch = p.nbatch;
-        J.block0 = b->nblocks;
+        if (J.variant >= 16) {   // wgrad_rows16.hip's launch
+            J.block0 = b->nblocks2;
+            b->nblocks2 += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
+            b->bytes2 += 2.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * (p.n_out + p.k_in);
+            count_path(PC_TN_ROWS16);
+        } else {
+            J.block0 = b->nblocks;
+            b->nblocks += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
+        }
         J.red_block0 = b->nred;
-        b->nblocks += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
         b->nred += (int)(((int64_t)p.n_out * tn_kpad(p.k_in) / 4 + 31) / 32);
         b->used += wp_slab_floats(p.n_out, p.k_in, p.rows, p.nbatch, ranged, b->batched, p.src16 != 0);
         b->flops += 2.0 * (ranged ? p.rows / 2.0 : (double)p.rows) * p.nbatch * p.n_out * p.k_in;
@@ -801,16 +830,26 @@ int wp_batch_flush(hipStream_t s) {
     (void)attr_set;
     count_path(PC_TN_PANEL_LAUNCH);
     if (const char* e = getenv("MPNHIP_WP_DEBUG")) b->tab.debug = atoi(e); else b->tab.debug = 0;
-    prof_begin(PROF_TN, s, b->bytes);   // (HBM-bound by design: the hook's work figure is the launch's operand bytes)
-    {
-        hipEvent_t e0, e1;
-        if (prof_launch_events(&e0, &e1))
-            hipExtLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, e0, e1, 0, b->tab);
-        else
-            hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+    if (b->nblocks2 > 0) {
+        // the bf16-row jobs of the LDS-DMA kernel (wgrad_rows16.hip): the profiled launch of a batch that has them (their bytes)
+        prof_begin(PROF_TN, s, b->bytes2);
+        const int r2 = launch_wgrad_rows16(b->tab, b->nblocks2, s);
+        prof_end(PROF_TN, s);
+        MPN_TRY(r2);
+        if (b->nblocks > 0) hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+        MPN_LAUNCH_CHECK();
+    } else if (b->nblocks > 0) {
+        prof_begin(PROF_TN, s, b->bytes);   // (HBM-bound by design: the hook's work figure is the launch's operand bytes)
+        {
+            hipEvent_t e0, e1;
+            if (prof_launch_events(&e0, &e1))
+                hipExtLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, e0, e1, 0, b->tab);
+            else
+                hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+        }
+        prof_end(PROF_TN, s);
+        MPN_LAUNCH_CHECK();
     }
-    prof_end(PROF_TN, s);
-    MPN_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b->nred), dim3(256), 0, s, b->tab);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
