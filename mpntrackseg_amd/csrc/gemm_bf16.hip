@@ -340,18 +340,18 @@ __device__ __forceinline__ void rg_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8&
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
-constexpr int RG_THREADS = 768;     // waves 0-7 multiply and store, waves 8-11 load
-
-template <int WM, int WN, int TM, int TN, int NST>
-__global__ __launch_bounds__(RG_THREADS, 3) void gemm_bf16_ring_kernel(RingArgs a) {
+// waves 0-7 multiply and store, waves 8 .. 8 + NLW - 1 load; BPC blocks per CU (launch bounds: 64 (8 + NLW) BPC / 256 waves per SIMD)
+template <int WM, int WN, int TM, int TN, int NST, int NLW, int BPC>
+__global__ __launch_bounds__(64 * (8 + NLW), (8 + NLW) * BPC / 4) void gemm_bf16_ring_kernel(RingArgs a) {
     static_assert(WM * WN == 8 && TM == 2 && (TN == 1 || TN == 2), "wave arrangement");
+    constexpr int RG_THREADS = 64 * (8 + NLW);
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int PA = BM / 32, PB = BN / 32;                 // 1 KiB pieces (8 rows) per LOADER wave and stage
+    constexpr int PA = BM / 8 / NLW, PB = BN / 8 / NLW;       // 1 KiB pieces (8 rows) per LOADER wave and stage
     constexpr int NP = PA + PB;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int BIAS_OFF = NST * STAGE;
     constexpr int LDS = BIAS_OFF + RG_BIAS_MAX * 4;
-    static_assert(LDS <= 163840, "LDS");
+    static_assert(LDS * BPC <= 163840, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     float* const sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -527,8 +527,8 @@ int launch_ring(const GemmArgs& a, hipStream_t s) {
     int grid = total >= 256 ? 256 : (int)((total + 7) / 8 * 8);
     if (const char* e = getenv("MPNHIP_GEMM_RING_DEBUG")) r.debug = atoi(e);
     if (const char* e = getenv("MPNHIP_GEMM_RING_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 1024) grid = v / 8 * 8; }
-    if (big) MPN_LAUNCH_PROFILED((gemm_bf16_ring_kernel<4, 2, 2, 2, 3>), dim3((unsigned)grid), dim3(RG_THREADS), s, r);
-    else MPN_LAUNCH_PROFILED((gemm_bf16_ring_kernel<2, 4, 2, 1, 4>), dim3((unsigned)grid), dim3(RG_THREADS), s, r);
+    if (big) MPN_LAUNCH_PROFILED((gemm_bf16_ring_kernel<4, 2, 2, 2, 3, 4, 1>), dim3((unsigned)grid), dim3(768), s, r);
+    else MPN_LAUNCH_PROFILED((gemm_bf16_ring_kernel<2, 4, 2, 1, 4, 4, 1>), dim3((unsigned)grid), dim3(768), s, r);
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;
 }

@@ -228,6 +228,69 @@ __global__ __launch_bounds__(256) void gemm_tn_generic_kernel(TnArgs args) {
     if (live && l == 0) TN_G(slab)[((size_t)blockIdx.y * args.n_out + o) * tn_kpad(args.k_in) + c] = tot;
 }
 
+// Few input columns, many outputs (k_in <= 8, 32 < n_out <= 256: the edge encoder's first layer at the wider models' widths -- [144 x 6]
+// at 256-d -- whose H rows are edge_attr read through the sort permutation): the any-shape kernel above gives every output element
+// its own 8 lanes, so 32 blocks per row chunk each walk all of the chunk's dZ rows with 4-byte strided loads (0.83 ms of a cfg-E
+// training step).  Here a block owns a row chunk and ALL outputs: thread o keeps the k_in + 1 sums of output row o, reads dZ[row][o]
+// (consecutive threads: whole lines) and takes the row's k_in H values as LDS broadcasts from a 64-row stage.  Same chunking and
+// slab format; plain fp32 FMAs in a fixed order.
+constexpr int NK_ROWS = 64;
+__global__ __launch_bounds__(256) void gemm_tn_narrowk_kernel(TnArgs args) {
+    __shared__ __attribute__((aligned(16))) float hs[NK_ROWS][8];
+    __shared__ int zr[NK_ROWS];
+    const int n_out = args.n_out, k_in = args.k_in;
+    const int* rbp = TN_G(row_begin);
+    const int* rep = TN_G(row_end);
+    const int rb = rbp ? *rbp : 0;
+    const int re = rep ? *rep : (int)TN_G(m_static);
+    const int batch = blockIdx.y / args.nsplit;
+    const int r0 = rb + (blockIdx.y % args.nsplit) * args.chunk;
+    int r1 = r0 + args.chunk;
+    r1 = r1 < re ? r1 : re;
+    if (r0 >= r1) return;
+    const int tid = threadIdx.x;
+    const bool live = tid < n_out;
+    const float* dZ = TN_G(dZ) + (int64_t)batch * TN_G(z_bstride) + (live ? tid : 0);
+    const float* H = TN_G(H) + (int64_t)batch * TN_G(h_bstride);
+    const int* zi = TN_G(dz_idx);
+    const int* hi = TN_G(h_idx);
+    const int64_t ldz = TN_G(ldz), ldh = TN_G(ldh);
+    float acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+    for (int m0 = r0; m0 < r1; m0 += NK_ROWS) {
+        const int nr = r1 - m0 < NK_ROWS ? r1 - m0 : NK_ROWS;
+        for (int i = tid; i < NK_ROWS * 8; i += 256) {
+            const int r = i >> 3, c = i & 7;
+            float v = 0.f;
+            if (r < nr && c < k_in) v = H[(int64_t)(hi ? hi[m0 + r] : m0 + r) * ldh + c];
+            hs[r][c] = v;
+        }
+        if (tid < NK_ROWS) zr[tid] = tid < nr ? (zi ? zi[m0 + tid] : m0 + tid) : (zi ? zi[m0] : m0);
+        __syncthreads();
+        if (live) {
+#pragma unroll 8
+            for (int r = 0; r < NK_ROWS; ++r) {
+                const float z = r < nr ? dZ[(int64_t)zr[r] * ldz] : 0.f;
+                const float4 h0 = *reinterpret_cast<const float4*>(&hs[r][0]);
+                const float4 h1 = *reinterpret_cast<const float4*>(&hs[r][4]);
+                acc[0] = fmaf(z, h0.x, acc[0]); acc[1] = fmaf(z, h0.y, acc[1]); acc[2] = fmaf(z, h0.z, acc[2]); acc[3] = fmaf(z, h0.w, acc[3]);
+                acc[4] = fmaf(z, h1.x, acc[4]); acc[5] = fmaf(z, h1.y, acc[5]); acc[6] = fmaf(z, h1.z, acc[6]); acc[7] = fmaf(z, h1.w, acc[7]);
+                acc[8] += z;
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        float* sl = TN_G(slab) + ((size_t)blockIdx.y * n_out + tid) * tn_kpad(k_in);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < k_in) sl[c] = acc[c];
+        sl[k_in] = acc[8];
+    }
+}
+static inline bool tn_narrowk(int n_out, int k_in) { return k_in <= 8 && n_out > 32 && n_out <= 256 && !getenv("MPNHIP_TN_NO_NARROWK"); }
+
 // Narrow outputs (n_out <= 32, k_in <= 32: the reference's 18-wide edge encoder, the [1 x hc] classifier output layer): the
 // any-shape kernel above is latency-bound there (one dependent gather chain per row and lane).  Here a block stages 64 rows of
 // dZ and H (through the row indices, if any) in LDS and every thread owns up to five output elements (o, c) -- c == k_in is
@@ -423,7 +486,8 @@ void tn_plan(TnArgs& a) {
     // A block's rounds are serial and each is two dependent global-load latencies long (row index -> row), so 128 blocks x 10
     // rounds took 45-52 us per product at cfg-C's 77.8k edges; the slabs stay small (n_out (k_in + 4) floats each)
     const bool narrow = a.n_out <= 32 && a.k_in <= 32;
-    const int cap = narrow ? 2048 : 128;
+    // (few input columns, one block per chunk for all outputs -- gemm_tn_narrowk_kernel: two blocks per CU, slabs of n_out x 8 floats)
+    const int cap = narrow ? 2048 : (tn_narrowk(a.n_out, a.k_in) ? 512 : 128);
     if (target > cap) target = cap;
     int64_t chunk = (a.m_upper + target - 1) / target;
     chunk = (chunk + TBK - 1) / TBK * TBK;
@@ -466,6 +530,8 @@ int launch_gemm_tn(const TnArgs& a_in, hipStream_t s) {
         else
             MPN_LAUNCH_PROFILED(gemm_tn_kernel<128>, dim3(nblocks), dim3(TNT), s, a);
         prof_end(PROF_TN, s);
+    } else if (tn_narrowk(a.n_out, a.k_in) && a.csplit == a.k_in) {
+        hipLaunchKernelGGL(gemm_tn_narrowk_kernel, dim3(1, a.nsplit * a.nbatch, a.ngroups), dim3(256), 0, s, a);
     } else if (a.n_out <= 32 && a.k_in <= 32 && a.csplit == a.k_in && !getenv("MPNHIP_TN_NO_SMALL")) {
         hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(1, a.nsplit * a.nbatch, a.ngroups), dim3(256), 0, s, a);
     } else {

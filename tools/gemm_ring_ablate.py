@@ -18,7 +18,7 @@ for (M, N, K) in ((20000, 2176, 512), (20000, 256, 2176), (20000, 512, 2048)):
     a.x, a.ldx, a.w, a.ldw, a.y, a.ldy, a.m, a.n, a.k, a.ksplit, a.x_bf16, a.w_bf16 = capi.ptr(x).value, K, capi.ptr(w).value, K, capi.ptr(y).value, N, M, N, K, K, 1, 1
     for tile in ("128", "256"):
         row = "%d x %d x %d tile %s:" % (M, N, K, tile)
-        for dbg in (0, 1, 2, 4, 5, 6, 3, 8):
+        for dbg in (0, 1, 2, 4):
             os.environ["MPNHIP_GEMM_RING_TILE"] = tile
             os.environ["MPNHIP_GEMM_RING_DEBUG"] = str(dbg)
             us = C.c_float(0)
