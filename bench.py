@@ -554,7 +554,7 @@ def pmc_traffic(kernel_key, cfg_name, precision="fp32", mode="fwd"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/pmc_summary*.json, made by
     tools/pmc_summary.py with the MI355X guide's corrections; newest round first), or None.  cfg-B passes: the default training
     command; cfg-E (bf16): the forward command, and from round 4 the training command (pmc_summary_cfgE_train.json)."""
-    rounds = ("r04", "r03", "r02", "r01")
+    rounds = ("r05", "r04", "r03", "r02", "r01")
     if cfg_name == "E" and precision == "bf16":
         name = "pmc_summary_cfgE_train.json" if mode == "train" else "pmc_summary_cfgE.json"
         for rnd in rounds:
@@ -726,14 +726,22 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
             # bytes (rows x (n_out + k_in) x 4 over all jobs of the launch); launches differ (groups of 5 / 4 / 3 steps, the tail
             # batch), so achieved = sum of bytes / sum of durations over the sampled launches.
             launches = per_step.get("wgrad_panel_launches", 0.0) or float(tn_) / max(args.steps, 1)
+            # round 5, bf16 rows at the 256-d widths: the profiled launch of a batch is the one-pass LDS-DMA kernel (csrc/wgrad_rows16.hip),
+            # its work figure the bytes of ITS jobs; the batch's remaining jobs (narrow / [1 x k] shapes) follow in the row-panel launch
+            rows16 = per_step.get("wgrad_rows16_launches", 0.0)
+            if rows16 > 0:
+                launches = rows16
             ach = tw / (tu * 1e-6) / 1e9
             # the same launches' products as fp32-equivalent flops (12 steps x edge-level + node-level + hoisted + encoder)
-            res["roofline_weight_grad"] = {"bound": "hbm", "kernel": "wgrad_panel_kernel: dW += dZ^T H for all products of a group of steps in one launch "
+            res["roofline_weight_grad"] = {"bound": "hbm", "kernel": ("wgrad_rows16_kernel: dW += dZ^T H over bf16 rows for the 256-d products of a group of steps in one "
+                                                                      "launch (one block per CU owns a row chunk and the whole output: every operand row fetched once; "
+                                                                      "LDS-DMA ring, ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16), side stream") if rows16 > 0 else
+                                                                     "wgrad_panel_kernel: dW += dZ^T H for all products of a group of steps in one launch "
                                                                      "(row-panel blocks, %s, ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16), side stream"
                                                                      % ("bf16 source rows as stored by the chain kernels, one product per k block" if chain == 2 else
                                                                         "three-piece bf16 operands split in the loader"),
                                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "avg_us": tu, "launches": tn_,
-                                           "traffic": pmc_traffic("wgrad_panel", args.config, args.precision, "train"),
+                                           "traffic": pmc_traffic("wgrad_rows16" if rows16 > 0 else "wgrad_panel", args.config, args.precision, "train"),
                                            "algorithmic_bytes": tw, "launches_per_step": launches, "ms_per_step": tu * launches / 1e3}
             if res["roofline_weight_grad"]["traffic"]:
                 res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / tw

@@ -832,6 +832,7 @@ int wp_batch_flush(hipStream_t s) {
     if (const char* e = getenv("MPNHIP_WP_DEBUG")) b->tab.debug = atoi(e); else b->tab.debug = 0;
     if (b->nblocks2 > 0) {
         // the bf16-row jobs of the LDS-DMA kernel (wgrad_rows16.hip): the profiled launch of a batch that has them (their bytes)
+        count_path(PC_TN_ROWS16_LAUNCH);
         prof_begin(PROF_TN, s, b->bytes2);
         const int r2 = launch_wgrad_rows16(b->tab, b->nblocks2, s);
         prof_end(PROF_TN, s);

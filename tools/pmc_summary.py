@@ -29,6 +29,9 @@ KEYS = {  # json key -> substring of the kernel name (+ optional grid filter)
     "k_aggregate": "k_aggregate",
     "gemm_tn": "gemm_tn_kernel",
     "wgrad_panel": "wgrad_panel_kernel",
+    "wgrad_rows16": "wgrad_rows16_kernel",
+    "gemm_bf16_ring": "gemm_bf16_ring_kernel",
+    "gemm_bf16_tiled": "gemm_bf16_kernel<",
     "wgrad_reduce": "wgrad_reduce_kernel",
     "segment_reduce3": "k_segment_reduce3",
 }
