@@ -129,6 +129,9 @@ __global__ void k_sum_blocks(const float* __restrict__ src, int64_t stride, int 
 
 // out[i] = sum_b src[b * stride + i] over bf16 blocks (n8 groups of eight elements, ascending b), fp32 result; up to 12 blocks'
 // 16-byte loads are in flight per lane at once (a serial chain of 8-byte loads ran at 1.9 TB/s at cfg-E)
+// OUT16: the sum leaves as bf16 (RNE) -- where every consumer rounds it to bf16 as an operand anyway (the hoisted e0 share: a bf16
+// GEMM's A operand and a one-piece weight-gradient product), the same values at half the bytes written and read twice
+template <bool OUT16>
 __global__ __launch_bounds__(256) void k_sum_blocks_bf16(const unsigned short* __restrict__ src, int64_t stride, int nb, int64_t n8,
                                                          float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,8 +156,14 @@ __global__ __launch_bounds__(256) void k_sum_blocks_bf16(const unsigned short* _
             }
         }
     }
-    *reinterpret_cast<float4*>(out + 8 * i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4*>(out + 8 * i + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    if (OUT16) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        const bf16x8 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3], (__bf16)acc[4], (__bf16)acc[5], (__bf16)acc[6], (__bf16)acc[7]};
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(out) + 8 * i) = __builtin_bit_cast(uint4, o);
+    } else {
+        *reinterpret_cast<float4*>(out + 8 * i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(out + 8 * i + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
 }
 
 __global__ void k_bf16_to_f32(const unsigned short* __restrict__ src, float* __restrict__ dst, int64_t n) {
@@ -380,6 +389,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     for (int i = 0; i < m.enc_node.n_layers; ++i) updw(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N, 1);
     for (int i = 0; i < m.enc_edge.n_layers; ++i) updw(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E, 1);
     updw(d.he, d.de, E, 1);
+    if (p.b16 && E > 0) upd((wp_slab_floats(d.he, d.de, E, 1, false, false, true) + 1) / 2);   // (the hoisted e0 share over bf16 rows)
     updw(d.pw, d.dn, N, 1);
     for (int i = 0; i < m.classifier.n_layers; ++i) updw(m.classifier.out_dims[i], i == 0 ? d.de : m.classifier.out_dims[i - 1], E, 1);
     p.slab_floats_per_group = sl;
@@ -410,6 +420,10 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
         auto addt = [&](int n_out, int k_in, int64_t rows) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, 1, false, true); };
         addt(d.pw, d.dn, N);
         addt(d.he, d.de, E);
+        if (p.b16 && E > 0) {   // (bf16-operand training keeps S = sum_s dZ1_s as bf16 rows: the bf16-row kernels' chunking)
+            const size_t f32 = wp_slab_floats(d.he, d.de, E, 1, false, true), f16 = wp_slab_floats(d.he, d.de, E, 1, false, true, true);
+            if (f16 > f32) t += f16 - f32;
+        }
         for (int i = 0; i < m.enc_node.n_layers; ++i) addt(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N);
         for (int i = 0; i < m.enc_edge.n_layers; ++i) addt(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E);
         p.slab_tail_floats = t;
@@ -518,9 +532,10 @@ static int weight_grad(const BwdPlan& p, float* slab_base, int ngroups, Operand 
 }
 
 // C = mask( A B (+ C) ) with B given as weight rows: B[k][n] = W[k * ldw + n]  (dH = dZ W)
+// a16: A is bf16 rows in memory (unsigned shorts behind the pointer, lda counts them; MPNHIP_PREC_BF16 only: gemm_bf16.hip reads them)
 static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, const float* const W[2], int64_t ldw, int K,
                     int N, float* C, int64_t ldc, const int* c_idx, const float* mask, int64_t ldmask, int accumulate,
-                    const RowRange rr[2], int64_t rows, hipStream_t s, int keep = -1) {
+                    const RowRange rr[2], int64_t rows, hipStream_t s, int keep = -1, bool a16 = false) {
     GemmArgs a = {};
     a.ngroups = ngroups;
     a.N = N;
@@ -536,6 +551,7 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
         init_group(g);
         g.A = A;
         g.lda = lda;
+        g.a16 = a16 ? 1 : 0;
         g.a_idx = a_idx;
         g.B = W[q];
         g.ldb = ldw;
@@ -1272,15 +1288,27 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     if (hoist_e0) {
         // S = sum_s dZ1_s (the blocks are all kept for the weight gradients);  dE0 += S W1[:, e0 columns];  dW1[:, e0 columns] += S^T e0
         const int64_t n4 = E * he / 4;
-        if (use_b16) hipLaunchKernelGGL(k_sum_blocks_bf16, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
-                                        E * he, (int)L, n4 / 2, p.dZ1sum);   // (he % 8 == 0: chain_bf16_train_ok)
+        // bf16-operand training: both consumers of S round it to bf16 as they stage it, so S itself is kept as bf16 rows (rounded once,
+        // the same values) and its partner e0 is the forward's bf16 mirror: half the bytes written and read twice, the GEMM reads
+        // bf16 rows, the weight-gradient product runs on the bf16-row kernels
+        const bool s16 = use_b16 && f.eb_hist && he % 8 == 0 && de % 8 == 0 && !getenv("MPNHIP_NO_S16");
+        if (s16) hipLaunchKernelGGL(k_sum_blocks_bf16<true>, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
+                                    E * he, (int)L, n4 / 2, p.dZ1sum);
+        else if (use_b16) hipLaunchKernelGGL(k_sum_blocks_bf16<false>, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p.dZed[0]),
+                                             E * he, (int)L, n4 / 2, p.dZ1sum);   // (he % 8 == 0: chain_bf16_train_ok)
         else hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p.dZed[0], E * he, (int)L, n4, p.dZ1sum);
         MPN_LAUNCH_CHECK();
         const float* Wa[2] = {m.edge.weight[0] + 2 * kx, nullptr};
-        MPN_TRY(act_grad(1, p.dZ1sum, he, nullptr, Wa, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s));
+        MPN_TRY(act_grad(1, p.dZ1sum, he, nullptr, Wa, m.edge.in_dim, he, de, p.dE0, de, nullptr, nullptr, 0, 1, nullptr, E, s, -1, s16));
         float* gw[2] = {m.edge.grad_weight[0] + 2 * kx, nullptr};
-        MPN_TRY(weight_grad(p, p.slab, 1, {p.dZ1sum, he, 0}, nullptr, {e0, de, 0}, {nullptr, 0, 0}, de, nullptr, he, de, gw, m.edge.in_dim,
-                            nullptr, nullptr, E, 1, s));
+        if (s16) {
+            Src16Scope rows16(true);
+            MPN_TRY(weight_grad(p, p.slab, 1, {p.dZ1sum, he, 0}, nullptr, {reinterpret_cast<const float*>(f.eb_hist), de, 0}, {nullptr, 0, 0}, de, nullptr,
+                                he, de, gw, m.edge.in_dim, nullptr, nullptr, E, 1, s));
+        } else {
+            MPN_TRY(weight_grad(p, p.slab, 1, {p.dZ1sum, he, 0}, nullptr, {e0, de, 0}, {nullptr, 0, 0}, de, nullptr, he, de, gw, m.edge.in_dim,
+                                nullptr, nullptr, E, 1, s));
+        }
     }
     auto unpack_node_grads = [&](hipStream_t us) -> int {
         // the packed node-projection gradient [W1r; W1c; Wfo_x; Wfi_x] back into the layers' grads (their biases were handled above)

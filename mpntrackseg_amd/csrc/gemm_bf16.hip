@@ -562,7 +562,12 @@ bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool launch_gemm_bf16_tiled(const GemmArgs& a, hipStream_t s, int* status) {
     *status = MPNHIP_OK;
     if (getenv("MPNHIP_NO_GEMM_BF16_TILED")) return false;
-    if (!a.epi_vec || a.K <= 0 || a.N < 32) return false;
+    if (!a.epi_vec || a.K <= 0) return false;
+    {   // (narrow outputs stay with the older kernel's 32-column strips -- unless an operand is bf16 rows, which only this kernel reads)
+        bool rows16 = false;
+        for (int i = 0; i < a.ngroups; ++i) rows16 = rows16 || a.g[i].a16 || a.g[i].b16 || a.g[i].C16;
+        if (a.N < 32 && !rows16) return false;
+    }
     bool a16 = false, b16 = false, full = a.accumulate != 0;
     for (int i = 0; i < a.ngroups; ++i) {
         const GemmGroup& g = a.g[i];

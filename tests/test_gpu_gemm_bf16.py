@@ -126,6 +126,13 @@ def test_linear_bf16_small_row_counts_with_bf16_rows():
         assert counts["gemm_bf16_tiled"] == 1, counts
 
 
+def test_linear_bf16_narrow_outputs_with_bf16_rows():
+    """fewer than 32 output columns: the older strip kernel's shape -- except with bf16 rows, which only the tiled kernel reads
+    (the 32-d model's hoisted e0 share: [E, 80] bf16 x [16, 80], accumulated)"""
+    counts = run_case(1000, 16, 80, 80, 1, 0, relu=0, c_in=0, mask=0, accumulate=1, y16=0)
+    assert counts["gemm_bf16_tiled"] == 1, counts
+
+
 def test_linear_bf16_rejects_misaligned_bf16_rows():
     d = dev()
     a = capi.LinearBf16Args()
