@@ -47,6 +47,8 @@ def parse():
                     help="N = 1 only: create a 1-rank process group on --backend and issue the training step's collectives anyway "
                          "(TrainStep(force_collectives=True)): the RCCL code path on the one GPU that is there; adds allreduce_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-rate", action="store_true",
+                    help="training mode: skip the forward-only rate measured beside the step (profiling runs: the kernel trace then holds training steps only)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short labelled measurements of the other BASELINE.json configurations appended to the default line")
@@ -471,7 +473,7 @@ def main():
         model.train(mode == "train")
         return E / ((time.perf_counter() - t0) * 1e3 / 20)
 
-    if mode == "train":
+    if mode == "train" and not args.no_forward_rate:
         out["forward_edges_per_ms"] = forward_rate()
     if world == 1 and args.precision in ("fp32", "fp32_split", "fp32_wgsplit") and not args.no_split_line:
         other = "fp32_split" if args.precision == "fp32" else "fp32"

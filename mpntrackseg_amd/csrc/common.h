@@ -150,6 +150,7 @@ struct WpJob {             // one product (one direction group of it), as the ke
     int n_out, k_in, nbatch, csplit;
     int pieces;            // 3: fp32 operands as three bf16 pieces, six products (MPNHIP_PREC_FP32_SPLIT); 1: operands rounded to
                            // bf16, one product (MPNHIP_PREC_BF16)
+    int lds2;              // 1: the launch provides two stage images (the pipelined split loop of the wide variants)
     int src16;             // 1: the operands are bf16 rows in memory (dZ / H point at unsigned shorts, leading dims and batch strides
                            // count them); the [1 x k] form: H only (its dZ is the fp32 logit gradient)
     int chunk, nsplit;     // rows per chunk, chunks per batch

@@ -153,6 +153,8 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
     }
     char* zdst = lds + zrow * P + zcol * 2;
     char* hdst = lds + hrow * P + (BO + hcol) * 2;
+    // (the pipelined split loop below keeps TWO stage images: stores go to image wimg, products read image rimg -- byte offsets)
+    int wimg = 0, rimg = 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -208,12 +210,12 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
                     bsum.x += __uint_as_float(v.x << 16); bsum.y += __uint_as_float(v.x & 0xffff0000u);
                     bsum.z += __uint_as_float(v.y << 16); bsum.w += __uint_as_float(v.y & 0xffff0000u);
                     if (NEG_Z) { v.x ^= sx16; v.y ^= sx16; }
-                    *reinterpret_cast<uint2*>(zdst + rpz * j * P) = v;
+                    *reinterpret_cast<uint2*>(zdst + wimg + rpz * j * P) = v;
                 } else {
                     float4 v = make_float4(zreg[B][j][0], zreg[B][j][1], zreg[B][j][2], zreg[B][j][3]);
                     if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                    put(zdst + rpz * j * P, v, NEG_Z);
+                    put(zdst + wimg + rpz * j * P, v, NEG_Z);
                 }
             }
         }
@@ -225,11 +227,11 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
                     uint2 v = hreg[B][j];
                     if (row >= nrows) v = make_uint2(0u, 0u);
                     if (!NEG_Z) { v.x ^= sx16; v.y ^= sx16; }
-                    *reinterpret_cast<uint2*>(hdst + rph * j * P) = v;
+                    *reinterpret_cast<uint2*>(hdst + wimg + rph * j * P) = v;
                 } else {
                     float4 v = make_float4(hreg[B][j][0], hreg[B][j][1], hreg[B][j][2], hreg[B][j][3]);
                     if (row >= nrows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    put(hdst + rph * j * P, v, !NEG_Z);
+                    put(hdst + wimg + rph * j * P, v, !NEG_Z);
                 }
             }
         }
@@ -237,8 +239,10 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
 
     // transposing-read lane geometry: lane 4q + p of a 16-lane group supplies row q, columns 4p .. 4p+3 of the group's block
     const int lh = lane >> 5, gi = (lane >> 4) & 1, lq = (lane & 15) >> 2, lp = lane & 3;
-    const char* rda = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + 32 * (wm * TM) * 2;
-    const char* rdb = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + (BO + 32 * (wn * TN)) * 2;
+    const char* const rda0 = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + 32 * (wm * TM) * 2;
+    const char* const rdb0 = lds + (8 * lh + lq) * P + (16 * gi + 4 * lp) * 2 + (BO + 32 * (wn * TN)) * 2;
+    const char* const rda = rda0;
+    const char* const rdb = rdb0;
     // every tile of the wave is computed (columns past n_out / k_in hold whatever the LDS held: those outputs are never stored);
     // the operand pieces of the next tile are fetched before the six products of the current one
     auto products1 = [&]() {   // one bf16 piece per operand
@@ -253,6 +257,8 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
         }
     };
     auto products6 = [&]() {
+        const char* const rda = rda0 + rimg;
+        const char* const rdb = rdb0 + rimg;
         if constexpr (TM >= TN) {
             bf16x8 b[TN][3];
 #pragma unroll
@@ -357,10 +363,73 @@ __device__ __forceinline__ void wp_block(const WpJob& J, const int tile, const i
             __syncthreads();
         }
     };
+    // MPNHIP_PREC_FP32_SPLIT, wide variants (one register stage): the split of stage st + 1 (VALU + ds_write into the OTHER image)
+    // and the products of stage st (transposing reads + MFMAs) sit in one scheduling region between two barriers -- ONE barrier
+    // per stage -- so that the operand split runs in the MFMAs' issue gaps instead of before them (ablation build, cfg-B's
+    // 50,000 x 320 x 64 product alone: loads only 60 us, split + stores only 28, products only 34, the old loop's split +
+    // products 65 = their SUM: the two blocks of a CU did not overlap one's split with the other's MFMAs).
+    auto run_pipelined = [&]() {
+        constexpr int IMG = 3 * PIECE;
+        if (nfull > 0) {
+            WP_LOAD(zreg[0], hreg[0], r0);
+            wimg = 0;
+            store(B0{}, WP_KB);
+            if (nfull > 1) WP_LOAD(zreg[0], hreg[0], r0 + WP_KB);
+            __syncthreads();
+            int st = 0;
+            for (; st + 2 < nfull; st += 2) {   // straight-line pairs: image offsets are compile-time constants
+                wimg = IMG; rimg = 0;
+                store(B0{}, WP_KB);                                   // stage st + 1 -> image 1
+                WP_LOAD(zreg[0], hreg[0], r0 + (st + 2) * WP_KB);
+                products6();                                          // stage st <- image 0
+                __syncthreads();
+                wimg = 0; rimg = IMG;
+                store(B0{}, WP_KB);                                   // stage st + 2 -> image 0
+                if (st + 3 < nfull) WP_LOAD(zreg[0], hreg[0], r0 + (st + 3) * WP_KB);
+                products6();                                          // stage st + 1 <- image 1
+                __syncthreads();
+            }
+            // one or two stages left: stage st is in image 0, stage st + 1 (if any) in the registers
+            if (st + 1 < nfull) {
+                wimg = IMG; rimg = 0;
+                store(B0{}, WP_KB);
+                products6();
+                __syncthreads();
+                rimg = IMG;
+                products6();
+                __syncthreads();
+            } else {
+                rimg = 0;
+                products6();
+                __syncthreads();
+            }
+            wimg = 0; rimg = 0;
+        }
+        if (tail > 0) {
+            const int m0 = r0 + nfull * WP_KB;
+#pragma unroll
+            for (int j = 0; j < PZ; ++j) {
+                int r = zrow + rpz * j;
+                r = (zact && r < tail) ? r : tail - 1;
+                zreg[0][j] = *reinterpret_cast<const StageT*>(zbase + ((int64_t)(m0 + r) * ldz + (zact ? zcol : 0)) * ES);
+            }
+#pragma unroll
+            for (int j = 0; j < PH; ++j) {
+                int r = hrow + rph * j;
+                r = (hact && r < tail) ? r : tail - 1;
+                hreg[0][j] = *reinterpret_cast<const StageT*>(hbase + ((int64_t)(m0 + r) * ldh + hcol) * ES);
+            }
+            store(B0{}, tail);
+            __syncthreads();
+            products6();
+            __syncthreads();
+        }
+    };
     if constexpr (B16) {
         run(products1);
     } else {
         if (one) run(products1);
+        else if (D == 1 && J.lds2) run_pipelined();
         else run(products6);
     }
 
@@ -690,7 +759,8 @@ thread_local WpBatch* g_wp = nullptr;
 size_t wp_lds_bytes() {
     // the largest variant image (BO + BC = 384): 39 KB.  MPNHIP_WP_LDS=<bytes> asks for more than the kernel uses: above 80 KB
     // only ONE block of this kernel fits a CU, which leaves the other wave slot of every SIMD to the caller's stream (A-B switch)
-    static const size_t need = 3 * WP_KB * wp_pitch(320, 64);
+    // (two stage images: the pipelined split loop; MPNHIP_WP_ONE_IMAGE=1: the older two-barrier loop on one image)
+    static const size_t need = (getenv("MPNHIP_WP_ONE_IMAGE") ? 1 : 2) * 3 * WP_KB * wp_pitch(320, 64);
     static const size_t ask = [] { const char* e = getenv("MPNHIP_WP_LDS"); const long x = e ? atol(e) : 0; return (size_t)(x > 0 ? x : 0); }();
     return ask > need ? ask : need;
 }
@@ -794,6 +864,7 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
         J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
         J.pieces = p.pieces == 1 ? 1 : 3;
+        J.lds2 = getenv("MPNHIP_WP_ONE_IMAGE") ? 0 : 1;
         J.row_begin = p.row_begin; J.row_end = p.row_end; J.m_static = p.rows; J.dz_idx = p.dz_idx; J.h_idx = p.h_idx;
         J.slab = b->slab + b->used;
         J.grad_w = p.grad_w; J.ldw = p.ldw; J.grad_b = p.grad_b;
