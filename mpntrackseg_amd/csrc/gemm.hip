@@ -586,7 +586,10 @@ int launch_gemm(const GemmArgs& a_in, int al, int bl, hipStream_t s) {
         for (int i = 0; i < a.ngroups; ++i) rows16 = rows16 || a.g[i].a16 || a.g[i].b16 || a.g[i].C16;
         int prec = g_precision;
         if (const char* e = getenv("MPNHIP_GEMM_PREC")) prec = atoi(e);
-        if (bl == B_KCONTIG && (rows16 || (prec == 1 && M >= 4096 && !a.small_tiles))) {
+        // (short K with a ragged column count -- the edge encoder's 144 / 160-wide layers over 400,000 rows -- stays on the strip
+        // kernel: 122 against 170 us at 400,000 x 160 x 144, tools/gemm_bf16_bench.py)
+        const bool shape_ok = a.K >= 192 && (N % 128 == 0 || N >= 384);
+        if (bl == B_KCONTIG && (rows16 || (prec == 1 && M >= 4096 && !a.small_tiles && shape_ok))) {
             int st = MPNHIP_OK;
             if (launch_gemm_bf16_tiled(a, s, &st)) {
                 if (st == MPNHIP_OK) count_path(PC_GEMM_BF16);

@@ -306,8 +306,8 @@ __global__ __launch_bounds__(GB_THREADS, 4) void gemm_bf16_kernel(GemmArgs args,
 // rows in memory nothing has to pass through registers:
 //   * one 768-thread block per CU, persistent (8 multiplying waves + 4 loader waves): the XCD's 32 blocks walk the XCD's contiguous
 //     run of tiles;
-//   * block tile 256 x 128 (waves 4 x 2, wave tile 64 x 64: 16 MFMAs per wave between two barriers) where the launch has at least
-//     two tiles of that size per CU, 128 x 128 (waves 2 x 4, wave tile 64 x 32) otherwise;
+//   * block tile 128 x 128 (waves 2 x 4, wave tile 64 x 32); a 256 x 128 form (waves 4 x 2, wave tile 64 x 64: 16 MFMAs per wave between
+//     two barriers) is instantiated behind MPNHIP_GEMM_RING_TILE=256 -- measured no faster;
 //   * a ring of NST stages (A rows [BM][64] | B rows [BN][64], 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7 through
 //     the per-lane SOURCE address: the LDS-DMA destination is lane-linear; conflict-free for the ds_read_b128 lane groups), filled
 //     by global_load_lds_dwordx4 in 1 KiB pieces, NST - 1 stages ahead -- across tile boundaries: the next tile's first stages
@@ -518,8 +518,9 @@ int launch_ring(const GemmArgs& a, hipStream_t s) {
     r.bias = g.bias; r.C = g.C;
     r.lda = (int)g.lda; r.lda2 = g.A2 ? (int)g.lda2 : (int)g.lda; r.ldb = (int)g.ldb; r.ldc = (int)g.ldc;
     r.M = (int)a.m_upper; r.N = a.N; r.K = a.K; r.ksplit = g.A2 ? a.ksplit : a.K; r.relu = a.relu;
-    // 256 x 128 tiles where every CU still gets at least two of them; the finer 128 x 128 tiles otherwise
-    bool big = ((a.m_upper + 255) / 256) * ((a.N + 127) / 128) >= 512;
+    // 128 x 128 tiles; MPNHIP_GEMM_RING_TILE=256: the 256 x 128 form (measured over four boxes at the projections' shape,
+    // 20,000 x 2,176 x 512: 76-80 us against 72-85 -- no faster on average and less even; 40 against 46 us at 20,000 x 256 x 2,176)
+    bool big = false;
     if (const char* e = getenv("MPNHIP_GEMM_RING_TILE")) big = atoi(e) == 256;
     const int bm = big ? 256 : 128;
     r.nbx = (a.N + 127) / 128; r.nby = (int)((a.m_upper + bm - 1) / bm);
