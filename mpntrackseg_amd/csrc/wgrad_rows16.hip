@@ -36,13 +36,6 @@ constexpr int R16_NST = 4;      // stages in the ring
 // row pitch (bytes) of an image of W bf16 columns: >= 2 W and == 64 (mod 256)
 constexpr int r16_pitch(int W) { return ((2 * W - 64 + 255) / 256) * 256 + 64; }
 
-template <int OFF>
-__device__ __forceinline__ s16x4 r16_tr(unsigned addr) {
-    s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-
 // One block: job J, column tile `tile_c` (tiles of BC columns), row chunk `by`.
 template <int WO, int WC, int TM, int TN>
 __device__ __forceinline__ void r16_block(const WpJob& J, const int tile_c, const int by, char* lds, const int dbg) {
