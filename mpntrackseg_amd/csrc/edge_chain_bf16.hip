@@ -56,7 +56,11 @@ namespace mpnhip {
 // -- the weight-gradient products -- rounds them to bf16 anyway: exact for this mode), and every ReLU decision (H1, e', HC, HF, M)
 // as one bit in a lane-private layout the backward chain kernel (edge_chain_bf16_bwd.hip) reads back with the same (block, wave,
 // lane) -> edge mapping: word w of wave tile wt at save_mask[(wt * NWORDS + w) * 64 + lane] (chain_bf16_mask_words()).
-template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2, bool SAVE = false, int DEP = DEPTH>
+// GD (round 5; the 256-d four-wave form): the COL-side gathered C-in -- Pc[col] of an H1 tile, Pf[col] of an HF tile: 128 bytes of a random
+// table row per edge -- lands by LDS-DMA in a per-wave 4 KB patch, 8 lanes x 16 bytes per row = eight whole 128-byte lines per
+// instruction, instead of 32-byte pieces of 32 different rows per instruction into registers (the line touches of those four
+// loads per tile were 16 % of the launch: with the col-side gathers pointed at the sorted ROW's table row, 513 -> 430 us).
+template <int T1, int T2, int TF, int TD, int TC, int EF, bool EXACT, int NW = 8, int CTI = 2, bool SAVE = false, int DEP = DEPTH, bool GD = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kernel(EdgeChainBf16Args A) {
     constexpr int EPB = 32 * NW;           // edges per block
     constexpr int DE = 32 * T2, DN = 32 * TD, HC = 32 * TC;
@@ -72,6 +76,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     // (the fused aggregation's per-wave slabs reuse the chunk buffers after the last chunk: 8 x [32 edges][32 RT + 1] floats)
     constexpr int AGG_RT = TD >= 2 ? 2 : 1, AGG_BYTES = NW * (32 * AGG_RT) * 36 * 4;
     constexpr int WB_BYTES = bmax(2 * CHU * 1024, (AGG_BYTES + 15) / 16 * 16);
+    static_assert(!GD || (EXACT && !SAVE && ROW_SLAB_BYTES >= 4096), "the DMA gathers fetch whole 128-byte pieces into the row slabs");
     __shared__ __attribute__((aligned(16))) char smem[WB_BYTES + (DE + 2 * HC + DN) * 4];
     // per-wave slabs of the full-line row stores (RowStage): a separate object, never the target of an LDS-DMA
     __shared__ __attribute__((aligned(16))) char rowslab[NW * ROW_SLAB_BYTES];
@@ -118,8 +123,51 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     // (the edge's end points first: the C-in gathers that depend on them then go out under the input rows' loads)
     const int row = A.srow[edge], col = A.scol[edge];
     const unsigned pro = (unsigned)row * (unsigned)A.pw;
-    const unsigned pco = (unsigned)col * (unsigned)A.pw + (unsigned)he;
+    // (timing ablation, MPNHIP_CHAIN_BF16_DEBUG_SKIP bit 16: the col-side gathers take the ROW's table row -- sorted edges, a few
+    // distinct lines per wave instruction instead of 32; results wrong)
+    const unsigned pco = (unsigned)((A.debug_skip & 16) ? row : col) * (unsigned)A.pw + (unsigned)he;
     const unsigned pfo = pco + (unsigned)(he + (grp == 1 ? hn : 0));
+    // GD: lane l of DMA instruction q fetches chunk (l & 7) ^ swizzle of edge 8 q + (l >> 3)'s row; the patch image is [edge][8 chunks],
+    // chunk positions XOR-ed with (edge >> 1) & 7 (through the SOURCE address: the DMA destination is lane-linear), which makes the
+    // read-back -- lane (lj, lh) takes chunks 2 g + lh of edge lj -- conflict-free for the ds_read_b128 lane groups
+    unsigned gco[4];
+    unsigned gp_wr = 0, gp_rd[4] = {0, 0, 0, 0};
+    if constexpr (GD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int eq_raw = tile0 + wave * 32 + 8 * q + (lane >> 3);
+            const int eq = eq_raw < end ? eq_raw : end - 1;
+            const int cq = (A.debug_skip & 16) ? A.srow[eq] : A.scol[eq];
+            const int rq = 8 * q + (lane >> 3);
+            gco[q] = (unsigned)cq * (unsigned)A.pw + (unsigned)he + (unsigned)(((lane & 7) ^ ((rq >> 1) & 7)) * 4);
+        }
+        gp_wr = lds_addr(rowslab + wave * ROW_SLAB_BYTES);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gp_rd[g] = gp_wr + (unsigned)(lj * 128 + (((2 * g + lh) ^ ((lj >> 1) & 7)) * 16));
+    }
+    // (the per-wave gather patch [32 edges][128 B] IS the wave's row slab: inference uses the slab only for the e' rows between the
+    // H1 and the HF tiles, when no gather is in flight -- the first Pf gather goes out after those stores; the SAVE variant stores
+    // rows through its slab in every tile, and a separate 16 KB of patches would cost the second block per CU: it keeps the register form)
+    char* const gp_ptr = rowslab + wave * ROW_SLAB_BYTES;
+    // the four row pieces of the patch as this lane's C-in (waits for the wave's own DMA first: nothing else orders them)
+    auto gd_take = [&](float4& v0, float4& v1, float4& v2, float4& v3) {
+        typedef float gdx4 __attribute__((ext_vector_type(4)));   // (a native vector: HIP's float4 struct is no "+v" operand)
+        gdx4 a, b, c4, d;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(gp_rd[0]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(gp_rd[1]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(c4) : "v"(gp_rd[2]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(gp_rd[3]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c4), "+v"(d)::"memory");
+        v0 = make_float4(a[0], a[1], a[2], a[3]); v1 = make_float4(b[0], b[1], b[2], b[3]);
+        v2 = make_float4(c4[0], c4[1], c4[2], c4[3]); v3 = make_float4(d[0], d[1], d[2], d[3]);
+    };
+    auto gd_issue = [&](unsigned extra) {   // extra: float offset past the Pc block (0: Pc tile t -> 32 t; the Pf blocks: + he + ...)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.P + gco[q] + extra),
+                                             (__attribute__((address_space(3))) void*)(gp_ptr + q * 1024), 16, 0, 0);
+    };
     // training saves: mask words of this wave tile (sections H1 | e' | HC | HF | M, two tiles per word)
     constexpr int WB_E = (T1 + 1) / 2, WB_C = WB_E + (T2 + 1) / 2, WB_F = WB_C + (TC + 1) / 2, WB_M = WB_F + (TF + 1) / 2;
     constexpr int NWORDS = WB_M + (TD + 1) / 2;
@@ -184,17 +232,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
     float4 cin[CIN_LOADS];
     static_assert(sizeof(cin) / sizeof(cin[0]) == 2 * 4 && CIN_LOADS == 2 * 4, "cin_issue issues 2 x 4 row loads");
     auto cin_issue = [&](int t) {
+        if constexpr (GD) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            cin[g] = ldrow<EXACT>(A.P, pro, 32 * t + 8 * g + 4 * lh, he);
-            cin[4 + g] = ldrow<EXACT>(A.P, pco, 32 * t + 8 * g + 4 * lh, he);
+            for (int g = 0; g < 4; ++g) cin[g] = ldrow<EXACT>(A.P, pro, 32 * t + 8 * g + 4 * lh, he);
+            gd_issue((unsigned)(32 * t));          // (4 register loads + 4 DMA pieces = CIN_LOADS vector-memory operations)
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cin[g] = ldrow<EXACT>(A.P, pro, 32 * t + 8 * g + 4 * lh, he);
+                cin[4 + g] = ldrow<EXACT>(A.P, pco, 32 * t + 8 * g + 4 * lh, he);
+            }
         }
     };
     float4 pf[PF_LOADS];
     static_assert(sizeof(pf) / sizeof(pf[0]) == 4 && PF_LOADS == 4, "pf_issue issues 4 row loads");
     auto pf_issue = [&](int t) {
+        if constexpr (GD) {
+            gd_issue((unsigned)(he + (grp == 1 ? hn : 0) + 32 * t));   // (PF_LOADS DMA pieces)
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pf[g] = ldrow<EXACT>(A.P, pfo, 32 * t + 8 * g + 4 * lh, hn);
+            for (int g = 0; g < 4; ++g) pf[g] = ldrow<EXACT>(A.P, pfo, 32 * t + 8 * g + 4 * lh, hn);
+        }
     };
     cin_issue(0);
     f32x16 en[T2];
@@ -226,6 +284,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if (tt < nt) {
                 const int t = ch * CT + tt;
                 f32x16 acc;
+                if constexpr (GD) gd_take(cin[4], cin[5], cin[6], cin[7]);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     acc[4 * g + 0] = cin[g].x + cin[4 + g].x; acc[4 * g + 1] = cin[g].y + cin[4 + g].y;
@@ -233,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
                 }
                 if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }   // (acc is formed before the DMA goes out)
                 if (t + 1 < T1) cin_issue(t + 1);
-                else if (flow) pf_issue(0);
+                else if (flow && !GD) pf_issue(0);
                 auto fin = [&](const bf16x8& h0, const bf16x8& h1) {
                     if constexpr (SAVE) {
                         save_tile(A.save_h1, he, t, T1, h0, h1, true);
@@ -276,6 +335,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if constexpr (SAVE) mask_put(WB_E, o, T2, tile_mask_bits(eb[2 * o], eb[2 * o + 1], ones));
         }
     }
+    if constexpr (GD) { if (flow) pf_issue(0); }   // (after the e' rows left through the slab the patch shares)
     TS16(22);
     // ---- phase 3: classifier (its image is in the current buffer) -------------------------------------------------------
     if (flow) chunk_fetch<bmin(CT, TF) * SECF, NW>(imgf, WBUF(c + 1), wave, lane);
@@ -343,6 +403,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void edge_chain_bf16_kern
             if (tt < nt) {
                 const int t = ch * CT + tt;
                 f32x16 acc;
+                if constexpr (GD) gd_take(pf[0], pf[1], pf[2], pf[3]);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = pf[g].x; acc[4 * g + 1] = pf[g].y; acc[4 * g + 2] = pf[g].z; acc[4 * g + 3] = pf[g].w; }
                 if (tt == 0) { asm volatile("" : "+v"(acc)::"memory"); fetch_next(); }
@@ -633,6 +694,8 @@ int launch_edge_chain_bf16(const EdgeChainBf16Args& a_in, hipStream_t s) {
             // (widths that are multiples of 32 only: the masked form of this variant does not fit the register budget)
             if (four && !save && dep_env == 8) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1, false, 8>), dim3(blocks), dim3(256), s, a);
             else if (four && !save && dep_env == 6) MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1, false, 6>), dim3(blocks), dim3(256), s, a);
+            else if (four && !save && !getenv("MPNHIP_CHAIN_BF16_NO_GDMA"))
+                MPN_LAUNCH_PROFILED((edge_chain_bf16_kernel<20, 4, 14, 8, 2, 2, true, 4, 1, false, DEPTH, true>), dim3(blocks), dim3(256), s, a);
             else if (four) MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 4, 1);
             else MPN_CB16(save, 20, 4, 14, 8, 2, 2, true, 8, 2);
             break;
