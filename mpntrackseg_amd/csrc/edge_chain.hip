@@ -1235,6 +1235,7 @@ int launch_edge_chain(const EdgeChainArgs& a_in, hipStream_t s) {
         return MPNHIP_ERR_UNSUPPORTED;
     }
     const unsigned blocks = (unsigned)((a.E + 127) / 128 + 3);
+    if (getenv("MPNHIP_CHAIN_ABLATE_COL")) a.scol = a.srow;   // timing ablation: the col-side gathers read the (sorted) row's table row; results wrong
     count_path(a.split ? PC_CHAIN_FWD_SPLIT : PC_CHAIN_FWD);
 #ifdef MPNHIP_CHAIN_TS
     a.ts = g_stamp_fwd.prepare(blocks, s);
