@@ -747,6 +747,15 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                                            "algorithmic_bytes": tw, "launches_per_step": launches, "ms_per_step": tu * launches / 1e3}
             if res["roofline_weight_grad"]["traffic"]:
                 res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / tw
+                if rows16 > 0:
+                    # the PMC figure is the average over ALL launches of a step (two six-step groups and the tail's one product), the
+                    # sampled `algorithmic_bytes` the average of the few launches that carried events: compare the PMC average with
+                    # the operand bytes of a step's bf16-row jobs / launches per step instead (edge L1 / L2, flow L1 / L2 over L steps,
+                    # + the hoisted e0 share's one product)
+                    step_bytes = c["L"] * E * 2.0 * ((he + de) + (de + he) + (hn + de) + (dn + hn)) + E * 2.0 * (he + de)
+                    avg = step_bytes / launches
+                    res["roofline_weight_grad"]["algorithmic_bytes_avg_per_launch"] = avg
+                    res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / avg
             cand["roofline_weight_grad"] = res["roofline_weight_grad"]["ms_per_step"]
         elif tn_:
             per = per_step.get("gemm_tn_mfma", 0.0)
