@@ -256,6 +256,12 @@ struct BwdPlan {
     float* dZ1sum;                      // [E, he] sum over the steps of the edge MLP's first-layer dZ (the re-attached e0's share)
     float* dZn;                         // [L][N, dn]
     float* dP;                          // [L][N, pw]
+    unsigned short* dP16;               // bf16-operand training: the same blocks rounded to bf16 rows (the node-level weight-gradient
+    unsigned short* dPsum16;            // products over bf16 rows, wgrad_rows16.hip), and the rounded sum over the steps [N, pw]
+    unsigned short* dZn16;              // ... and the node update's operands: [L][N, dn] pre-activation gradients, [L][N, 2 dn] aggregated
+    unsigned short* AGG16;              // messages, rounded on the side stream just before the group's products
+    unsigned short* enc16;              // ... and the node encoder's dZ / input blocks [N, sum of (out_i + in_i)] (rounded on the tail's stream)
+    size_t enc16_elems;
     float* dZfl[MPNHIP_MAX_LAYERS];     // flow MLP layer i:   [L][E, out_i]
     float* dZed[MPNHIP_MAX_LAYERS];     // edge MLP layer i:   [L][E, out_i]  (last layer: the masked dE_s)
     float* dZcl[MPNHIP_MAX_LAYERS];     // classifier layer i: [L][E, out_i]  (i < n-1; the last one is grad_logits)
@@ -330,6 +336,19 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     p.dZn = a.f(L * N * d.dn);
     p.dP = a.f(L * N * d.pw);
     p.b16 = chain_bf16_train_ok(m, d);
+    p.dP16 = p.dPsum16 = p.dZn16 = p.AGG16 = p.enc16 = nullptr;
+    p.enc16_elems = 0;
+    const bool node16 = p.b16 && d.pw % 8 == 0 && d.dn % 8 == 0;   // (not `p.dP16 != nullptr`: a size query plans without a base)
+    if (node16) {
+        p.dP16 = reinterpret_cast<unsigned short*>(a.f((L * N * d.pw + 1) / 2));
+        p.dPsum16 = reinterpret_cast<unsigned short*>(a.f(((size_t)N * d.pw + 1) / 2));
+        p.dZn16 = reinterpret_cast<unsigned short*>(a.f((L * N * d.dn + 1) / 2));
+        p.AGG16 = reinterpret_cast<unsigned short*>(a.f((L * N * 2 * d.dn + 1) / 2));
+        size_t w = 0;
+        for (int i = 0; i < m.enc_node.n_layers; ++i) w += (size_t)m.enc_node.out_dims[i] + (i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1]);
+        p.enc16_elems = (size_t)N * w;
+        p.enc16 = reinterpret_cast<unsigned short*>(a.f((p.enc16_elems + 1) / 2));
+    }
     auto dzb = [&](int width) { return a.f(p.b16 ? (L * E * width + 1) / 2 : L * E * width); };
     for (int i = 0; i < m.flow_in.n_layers; ++i) p.dZfl[i] = dzb(m.flow_in.out_dims[i]);
     for (int i = 0; i < m.edge.n_layers; ++i) p.dZed[i] = dzb(m.edge.out_dims[i]);
@@ -391,6 +410,7 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     updw(d.he, d.de, E, 1);
     if (p.b16 && E > 0) upd((wp_slab_floats(d.he, d.de, E, 1, false, false, true) + 1) / 2);   // (the hoisted e0 share over bf16 rows)
     updw(d.pw, d.dn, N, 1);
+    if (node16 && N > 0) upd((wp_slab_floats(d.pw, d.dn, N, 1, false, false, true) + 1) / 2);   // (the hoisted x0 share over bf16 rows)
     for (int i = 0; i < m.classifier.n_layers; ++i) updw(m.classifier.out_dims[i], i == 0 ? d.de : m.classifier.out_dims[i - 1], E, 1);
     p.slab_floats_per_group = sl;
     p.slab = a.f(2 * sl);
@@ -409,8 +429,18 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
         addw(d.hn, d.de, E, true); addw(d.hn, d.de, E, true);
         for (int i = 0; i < m.classifier.n_layers; ++i) addw(m.classifier.out_dims[i], i == 0 ? d.de : m.classifier.out_dims[i - 1], E, false);
         for (int i = 1; i < m.edge.n_layers; ++i) addw(m.edge.out_dims[i], m.edge.out_dims[i - 1], E, false);
-        addw(d.he, d.ke > d.de ? d.ke : d.de, E, false);
-        addw(d.pw, d.kx, N, false);
+        // (a product that runs in one of two forms -- the first-layer inputs whole or with the re-attached share hoisted -- reserves
+        // the larger of the two: a narrower k_in can mean MORE row chunks, i.e. more slabs)
+        auto addw2 = [&](int n_out, int k_a, int k_b, int64_t rows) {
+            const size_t before = t;
+            addw(n_out, k_a, rows, false);
+            const size_t fa = t - before;
+            t = before;
+            addw(n_out, k_b, rows, false);
+            if (t - before < fa) t = before + fa;
+        };
+        addw2(d.he, d.ke, d.de, E);
+        addw2(d.pw, d.kx, d.dn, N);
         wpmax = t > wpmax ? t : wpmax;
     }
     p.slab_wp_floats = wpmax;
@@ -418,13 +448,26 @@ static size_t plan_backward(const mpnhip_model& m, const Dims& d, int64_t N, int
     {   // the tail batch: hoisted shares + encoder layers
         size_t t = 0;
         auto addt = [&](int n_out, int k_in, int64_t rows) { if (rows > 0) t += wp_slab_floats(n_out, k_in, rows, 1, false, true); };
-        addt(d.pw, d.dn, N);
+        if (node16 && N > 0) {
+            const size_t f32 = wp_slab_floats(d.pw, d.dn, N, 1, false, true), f16 = wp_slab_floats(d.pw, d.dn, N, 1, false, true, true);
+            t += f32 > f16 ? f32 : f16;
+        } else {
+            addt(d.pw, d.dn, N);
+        }
         addt(d.he, d.de, E);
         if (p.b16 && E > 0) {   // (bf16-operand training keeps S = sum_s dZ1_s as bf16 rows: the bf16-row kernels' chunking)
             const size_t f32 = wp_slab_floats(d.he, d.de, E, 1, false, true), f16 = wp_slab_floats(d.he, d.de, E, 1, false, true, true);
             if (f16 > f32) t += f16 - f32;
         }
-        for (int i = 0; i < m.enc_node.n_layers; ++i) addt(m.enc_node.out_dims[i], i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1], N);
+        for (int i = 0; i < m.enc_node.n_layers; ++i) {
+            const int n_out = m.enc_node.out_dims[i], k_in = i == 0 ? m.enc_node.in_dim : m.enc_node.out_dims[i - 1];
+            if (node16 && N > 0) {
+                const size_t f32 = wp_slab_floats(n_out, k_in, N, 1, false, true), f16 = wp_slab_floats(n_out, k_in, N, 1, false, true, true);
+                t += f32 > f16 ? f32 : f16;
+            } else {
+                addt(n_out, k_in, N);
+            }
+        }
         for (int i = 0; i < m.enc_edge.n_layers; ++i) addt(m.enc_edge.out_dims[i], i == 0 ? m.enc_edge.in_dim : m.enc_edge.out_dims[i - 1], E);
         p.slab_tail_floats = t;
         p.slab_tail = a.f(t);
@@ -650,14 +693,52 @@ __global__ __launch_bounds__(256) void k_edge_encoder_bwd(const float* __restric
     }
 }
 
+// bf16-operand training, deferred tail batch: the GEMM-shaped weight-gradient products of the node encoder ([1024 x 2048] over 20,000 rows
+// at cfg-E: 128 output tiles of the row-panel kernel, every block walking all rows) read bf16 ROWS on the LDS-DMA kernel's 256 x 256
+// tiles instead.  Their operands are fp32 blocks that stay put until the batch runs (BwdPlan::Tn, the saved hidden activations, the
+// input features): the roundings are RECORDED here and launched on the tail's own stream just before its products.
+struct Rows16Later {
+    struct Item { const float* src; unsigned short* dst; int64_t n; };
+    Item item[2 * MPNHIP_MAX_LAYERS];
+    int n = 0;
+    unsigned short* pool = nullptr;
+    size_t pool_elems = 0, used = 0;
+    unsigned short* take(const float* src, int64_t elems) {
+        if (n >= 2 * MPNHIP_MAX_LAYERS || used + (size_t)elems > pool_elems || elems % 8 != 0 || (((uintptr_t)src) & 15) != 0) return nullptr;
+        unsigned short* d = pool + used;
+        item[n++] = {src, d, elems};
+        used += (size_t)elems;
+        return d;
+    }
+};
+static thread_local Rows16Later* g_rows16_later = nullptr;
+
+// one weight-gradient product of an encoder layer: over bf16 rows when a Rows16Later is open and the shape is one of the tiled ones
+static int encoder_weight_grad(const BwdPlan& p, const float* dz, const float* h, int n_out, int k_in, float* gw0, float* gb0, int64_t rows,
+                               hipStream_t s) {
+    float* gw[2] = {gw0, nullptr};
+    float* gb[2] = {gb0, nullptr};
+    Rows16Later* L16 = g_rows16_later;
+    int to = 1, tc = 1;
+    if (L16 && wp_batch_open() && (int64_t)n_out * k_in >= 65536 && r16_variant(n_out, k_in, &to, &tc) >= 16 && L16->n + 2 <= 2 * MPNHIP_MAX_LAYERS &&
+        L16->used + (size_t)rows * (n_out + k_in) <= L16->pool_elems) {
+        const unsigned short* z16 = L16->take(dz, rows * n_out);
+        const unsigned short* h16 = z16 ? L16->take(h, rows * k_in) : nullptr;
+        if (z16 && h16) {
+            Src16Scope rows16(true);
+            return weight_grad(p, p.slab, 1, {reinterpret_cast<const float*>(z16), n_out, 0}, nullptr, {reinterpret_cast<const float*>(h16), k_in, 0},
+                               {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, nullptr, rows, 1, s);
+        }
+        if (z16) { --L16->n; L16->used -= (size_t)rows * n_out; }   // (the partner did not qualify: fp32 rows for both)
+    }
+    return weight_grad(p, p.slab, 1, {dz, n_out, 0}, nullptr, {h, k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out, k_in, gw, k_in, gb, nullptr, rows, 1, s);
+}
+
 static int mlp_tail_backward(const BwdPlan& p, float* const* T, const mpnhip_mlp& m0, float* const* hidden, const float** dz, int* cur_buf,
                              int64_t rows, hipStream_t s) {
     for (int i = m0.n_layers - 1; i >= 1; --i) {
         const int n_out = m0.out_dims[i], k_in = m0.out_dims[i - 1];
-        float* gw[2] = {m0.grad_weight[i], nullptr};
-        float* gb[2] = {m0.grad_bias[i], nullptr};
-        MPN_TRY(weight_grad(p, p.slab, 1, {*dz, n_out, 0}, nullptr, {hidden[i - 1], k_in, 0}, {nullptr, 0, 0}, k_in, nullptr, n_out,
-                            k_in, gw, k_in, gb, nullptr, rows, 1, s));
+        MPN_TRY(encoder_weight_grad(p, *dz, hidden[i - 1], n_out, k_in, m0.grad_weight[i], m0.grad_bias[i], rows, s));
         const float* Wq[2] = {m0.weight[i], nullptr};
         float* dst = T[(*cur_buf + 1) % 3];
         MPN_TRY(act_grad(1, *dz, n_out, nullptr, Wq, k_in, n_out, k_in, dst, k_in, nullptr,
@@ -864,6 +945,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // (2 x 2.05 of ~31 GFLOP per step at cfg-B), for one pass over the kept dZ1 blocks.
     // (the bf16 backward chain kernel never contracts the e0 columns: always hoisted there, also at L = 1)
     const bool hoist_e0 = use_b16 || (use_chain && d.ef == 2 && L > 1 && pad32(de) == 64 && he % 4 == 0 && de % 4 == 0 && !getenv("MPNHIP_NO_DE0_HOIST"));
+    // bf16-operand training: the per-node projections' weight gradient over bf16 ROWS -- dP_s rounded once by the scatter-add kernel that
+    // produces it, x_{s-1} from the forward's bf16 mirror -- on the LDS-DMA kernel in 256 x 256 output tiles (wgrad_rows16.hip)
+    // (f.xb_hist is filled under the forward's own run-time test, mpn.hip `rows16`: repeated here)
+    const bool node16 = use_b16 && hoist_x && p.dP16 && f.Wnode16 && f.xb_hist && ((size_t)pw * kx) % 4 == 0 &&
+                        (((uintptr_t)m.node.weight[0]) & 15) == 0 && !getenv("MPNHIP_NO_NODE_ROWS16");
     // bf16 rows: pointer `elems` unsigned shorts into a buffer the plans type as float*
     auto u16 = [](const float* p0, int64_t elems) { return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p0) + elems); };
     // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per
@@ -880,8 +966,20 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         {   // node update Linear
             float* gw[2] = {m.node.grad_weight[0], nullptr};
             float* gb[2] = {m.node.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, slab, 1, {p.dZn + zb * xs, dn, (int64_t)xs}, nullptr, {f.step0.AGG + zb * sstride, 2 * dn, sstride},
-                                {nullptr, 0, 0}, 2 * dn, nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, nb, st));
+            if (node16 && p.dZn16 && sstride % 4 == 0) {
+                // bf16 rows (rounded here, on the products' own stream, ahead of the recorded batch): [dn x 2 dn] = two column tiles of
+                // the LDS-DMA kernel instead of 2 x 4 tiles of the row-panel kernel over fp32 rows
+                MPN_TRY(to_bf16_rows(p.dZn + zb * xs, p.dZn16 + zb * xs, (int64_t)nb * xs, st));
+                for (int q = 0; q < nb; ++q)
+                    MPN_TRY(to_bf16_rows(f.step0.AGG + (zb + q) * sstride, p.AGG16 + (zb + q) * N * 2 * dn, N * 2 * dn, st));
+                Src16Scope rows16(true);
+                MPN_TRY(weight_grad(p, slab, 1, {reinterpret_cast<const float*>(p.dZn16 + zb * xs), dn, (int64_t)xs}, nullptr,
+                                    {reinterpret_cast<const float*>(p.AGG16 + zb * N * 2 * dn), 2 * dn, N * 2 * dn}, {nullptr, 0, 0}, 2 * dn, nullptr, dn,
+                                    2 * dn, gw, 2 * dn, gb, nullptr, N, nb, st));
+            } else {
+                MPN_TRY(weight_grad(p, slab, 1, {p.dZn + zb * xs, dn, (int64_t)xs}, nullptr, {f.step0.AGG + zb * sstride, 2 * dn, sstride},
+                                    {nullptr, 0, 0}, 2 * dn, nullptr, dn, 2 * dn, gw, 2 * dn, gb, nullptr, N, nb, st));
+            }
         }
         if (use_b16) {
             // every operand of these products is a bf16 row block: the backward chain kernel's dZ outputs, the forward chain kernel's
@@ -977,6 +1075,13 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             if (hoist_x) {
                 // columns [dn, 2 dn) (the current features) here; the x0 columns are one product with the summed dP after the loop
                 float* gw[2] = {p.gWnode + dn, nullptr};
+                if (node16) {
+                    Src16Scope rows16(true);
+                    MPN_TRY(weight_grad(p, slab, 1, {reinterpret_cast<const float*>(p.dP16 + zb * N * pw), pw, (int64_t)N * pw}, nullptr,
+                                        {reinterpret_cast<const float*>(f.xb_hist + xs * zb), dn, (int64_t)xs}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx,
+                                        nullptr, nullptr, N, nb, st));
+                    return finish();
+                }
                 MPN_TRY(weight_grad(p, slab, 1, {p.dP + zb * N * pw, pw, (int64_t)N * pw}, nullptr, {f.x_hist + xs * zb, dn, (int64_t)xs},
                                     {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr, N, nb, st));
                 return finish();
@@ -1111,9 +1216,10 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
             // index_put_(accumulate) of the gathers x[flow_col] (mpn.py:87,93) and x[row], x[col] (mpn.py:69) over the bf16 dZ rows
             const float* zf = reinterpret_cast<const float*>(a.dZF);
             const float* z1 = reinterpret_cast<const float*>(a.dZ1);
-            const SegReduce2 c3[3] = {{zf, hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, 0, 0},
-                                      {z1, he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, 3, (int)N},
-                                      {z1, he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, 0, 0}};
+            unsigned short* const dP16 = node16 ? p.dP16 + (size_t)b_ * N * pw : nullptr;
+            const SegReduce2 c3[3] = {{zf, hn, g.cperm, g.cseg_ptr, 2 * (int)N, hn, dP, pw, (int)N, 2 * he, 2 * he + hn, 0, 0, dP16, pw},
+                                      {z1, he, nullptr, g.seg_ptr, (int)N, he, dP, pw, (int)N, 0, 0, 3, (int)N, dP16, pw},
+                                      {z1, he, g.cperm_all, g.cseg_all, (int)N, he, dP, pw, (int)N, he, he, 0, 0, dP16, pw}};
             MPN_TRY(segment_reduce_csr2_x3_bf16(c3, s));
         } else if (use_chain) {
             // ---- B-E fused: every activation-gradient product of the per-edge modules in one kernel --------
@@ -1261,11 +1367,16 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // end with ~0.3 ms in which only the side stream worked: last group 0.78 ms, then this batch 0.19 ms.  The first side stream is
     // ordered behind it, so what follows there -- the unpacking of the packed projection gradient, a trainer's collective -- sees both.)
     static const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2");
+    Rows16Later later16;
+    later16.pool = p.enc16;
+    later16.pool_elems = p.enc16_elems;
     auto flush_tail = [&]() -> int {
         if (!wp_batch_open()) return MPNHIP_OK;
         hipStream_t st = tail_beside ? side->stream2 : side->stream;
         MPN_HIP(hipEventRecord(side->ready, s));
         MPN_HIP(hipStreamWaitEvent(st, side->ready, 0));
+        for (int i = 0; i < later16.n; ++i) MPN_TRY(to_bf16_rows(later16.item[i].src, later16.item[i].dst, later16.item[i].n, st));
+        later16.n = 0;
         MPN_TRY(wp_batch_flush(st));
         if (tail_beside) {
             MPN_HIP(hipEventRecord(side->done2, side->stream2));
@@ -1282,8 +1393,15 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         // ... and the x0 columns [0, dn) of the packed projection weight's gradient: (sum of dP)^T x0 (disjoint from the columns the
         // side stream accumulates; main-stream slab buffer)
         float* gw[2] = {p.gWnode, nullptr};
-        MPN_TRY(weight_grad(p, p.slab, 1, {p.dPsum, pw, 0}, nullptr, {x0, dn, 0}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr,
-                            N, 1, s));
+        if (node16) {
+            MPN_TRY(to_bf16_rows(p.dPsum, p.dPsum16, N * pw, s));
+            Src16Scope rows16(true);
+            MPN_TRY(weight_grad(p, p.slab, 1, {reinterpret_cast<const float*>(p.dPsum16), pw, 0}, nullptr, {reinterpret_cast<const float*>(f.xb_hist), dn, 0},
+                                {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr, N, 1, s));
+        } else {
+            MPN_TRY(weight_grad(p, p.slab, 1, {p.dPsum, pw, 0}, nullptr, {x0, dn, 0}, {nullptr, 0, 0}, dn, nullptr, pw, dn, gw, kx, nullptr, nullptr,
+                                N, 1, s));
+        }
     }
     if (hoist_e0) {
         // S = sum_s dZ1_s (the blocks are all kept for the weight gradients);  dE0 += S W1[:, e0 columns];  dW1[:, e0 columns] += S^T e0
@@ -1389,11 +1507,11 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
                 MPN_TRY(relu_mask(p.dX0, x0, p.Tn[0], (int64_t)xs, s));
                 dz = p.Tn[0];
             }
+            // (bf16-operand training with the deferred tail batch: the wide layers' products over bf16 rows, rounded on the tail's stream)
+            struct LaterScope { explicit LaterScope(Rows16Later* l) { g_rows16_later = l; } ~LaterScope() { g_rows16_later = nullptr; } };
+            LaterScope later_scope(defer_encoder && node16 && p.enc16 ? &later16 : nullptr);
             MPN_TRY(mlp_tail_backward(p, p.Tn, en, hid, &dz, &cur, N, s));
-            float* gw[2] = {en.grad_weight[0], nullptr};
-            float* gb[2] = {en.grad_bias[0], nullptr};
-            MPN_TRY(weight_grad(p, p.slab, 1, {dz, en.out_dims[0], 0}, nullptr, {x, en.in_dim, 0}, {nullptr, 0, 0}, en.in_dim, nullptr,
-                                en.out_dims[0], en.in_dim, gw, en.in_dim, gb, nullptr, N, 1, s));
+            MPN_TRY(encoder_weight_grad(p, dz, x, en.out_dims[0], en.in_dim, en.grad_weight[0], en.grad_bias[0], N, s));
             if (grad_x) {
                 const float* Wq[2] = {en.weight[0], nullptr};
                 MPN_TRY(act_grad(1, dz, en.out_dims[0], nullptr, Wq, en.in_dim, en.out_dims[0], en.in_dim, grad_x, en.in_dim,

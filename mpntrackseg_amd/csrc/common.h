@@ -179,7 +179,7 @@ struct WpBatch { WpTable tab; float* slab; size_t slab_floats, used; double flop
                  hipStream_t stream; bool has_stream; };   // has_stream: the stream every flush of this batch goes to is known (wp_batch_roll)
 bool wp_eligible(const WpProduct& p);
 // wgrad_rows16.hip: the one-pass LDS-DMA kernel for bf16 rows at the 256-d widths
-int r16_variant(int n_out, int k_in, int* tiles_c);
+int r16_variant(int n_out, int k_in, int* tiles_o, int* tiles_c);
 int launch_wgrad_rows16(const WpTable& tab, int nblocks, hipStream_t s);
 // (batched: the job shares its launch with the other products of a group of steps -- fewer row chunks per job)
 size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged, bool batched, bool src16 = false);
@@ -307,6 +307,7 @@ int launch_persist32(Persist32Args a, hipStream_t s);
 struct SegReduce2 {
     const float* src; int64_t lds; const int* list; const int* ptr; int nseg; int dim; float* out; int64_t ldo; int nmod; int off0; int off1;
     int runs; int run_stride;   // (segment_reduce_csr2's `runs` form: a segment as the union of `runs` CSR runs; 0 / 1 = plain)
+    unsigned short* out16; int64_t ldo16;   // (segment_reduce_csr2_x3_bf16 only) the same sums rounded to bf16 rows as well, or nullptr
 };
 int segment_reduce_csr2_x3(const SegReduce2 c[3], int64_t total_rows, hipStream_t stream);
 // the same over bf16 source rows (c[i].src points at unsigned shorts, c[i].lds counts them): short-segment kernel, one launch

@@ -33,6 +33,8 @@ struct SegArgs {
     int runs, run_stride;  // runs > 1 (sum only, no list): segment s is the union of the runs [ptr[s + r * run_stride],
                       // ptr[s + r * run_stride + 1]), r < runs -- e.g. a node's rows of all three directions of the (dir,row) CSR
     int nblk;         // column blocks per segment: work item = (segment, block of sub * VEC columns); 0 / 1 = one item per segment
+    unsigned short* out16;  // (bf16-row sources, float4 path) the sums also as bf16 rows (RNE), same geometry with ld = ldo16; or nullptr
+    int64_t ldo16;
 };
 
 template <int VEC>
@@ -151,6 +153,14 @@ __device__ __forceinline__ void seg_short_body(const SegArgs& a, const int gtid)
             vadd(acc, old);
         }
         Vec<VEC>::store(op, acc);
+        if constexpr (B16 && VEC == 4) {
+            if (a.out16) {   // (the consumers of these sums in the bf16-operand backward round them to bf16 anyway: once, here)
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 lo = {(__bf16)acc.x, (__bf16)acc.y}, hi = {(__bf16)acc.z, (__bf16)acc.w};
+                const int64_t o16 = (int64_t)(s % a.nmod) * a.ldo16 + ((s / a.nmod) == 0 ? a.off0 : a.off1) + c;
+                *reinterpret_cast<uint2*>(a.out16 + o16) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+            }
+        }
         if (a.argmax) {
             int* ap = a.argmax + orow + c;
 #pragma unroll
@@ -640,6 +650,7 @@ static SegArgs seg_args2(const SegReduce2& c) {
     a.src = c.src; a.lds = c.lds; a.list = c.list; a.ptr = c.ptr; a.nseg = c.nseg; a.dim = c.dim; a.agg = MPNHIP_AGG_SUM;
     a.out = c.out; a.ldo = c.ldo; a.nmod = c.nmod > 0 ? c.nmod : 1; a.off0 = c.off0; a.off1 = c.off1;
     a.runs = c.runs; a.run_stride = c.run_stride;
+    a.out16 = c.out16; a.ldo16 = c.ldo16;
     return a;
 }
 
@@ -685,7 +696,8 @@ int segment_reduce_csr2_x3_bf16(const SegReduce2 c[3], hipStream_t stream) {
         bool v = false;
         // (the geometry's 16-byte source alignment test is the fp32 kernels'; bf16 rows need 8 bytes per 4 columns)
         MPN_CHECK_ARG(a[i].dim % 4 == 0 && a[i].lds % 4 == 0 && a[i].ldo % 4 == 0 && a[i].off0 % 4 == 0 && a[i].off1 % 4 == 0 &&
-                      (((uintptr_t)a[i].src) & 7) == 0 && (((uintptr_t)a[i].out) & 15) == 0, "segment_reduce (bf16 rows): alignment");
+                      (((uintptr_t)a[i].src) & 7) == 0 && (((uintptr_t)a[i].out) & 15) == 0 && a[i].ldo16 % 4 == 0 &&
+                      (((uintptr_t)a[i].out16) & 7) == 0, "segment_reduce (bf16 rows): alignment");
         const float* keep = a[i].src;
         a[i].src = reinterpret_cast<const float*>(((uintptr_t)keep) & ~(uintptr_t)15);   // (only for the geometry's alignment test)
         nb[i] = a[i].nseg > 0 && a[i].dim > 0 ? seg_short_geometry(a[i], &v) : 0;

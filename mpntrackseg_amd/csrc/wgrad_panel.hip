@@ -485,23 +485,44 @@ __device__ __forceinline__ void wp_block_vec(const WpJob& J, const int by, char*
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float bs = 0.f;
     if (rlane < rl) {
-        for (int r = r0 + rlane; r < r1; r += rl) {
-            float zz = z[(int64_t)(zi ? zi[r] : r) * J.ldz];
-            float4 hv;
-            if (J.src16) {   // H as bf16 rows (J.H points at unsigned shorts; ldh / h_bstride count them); dZ stays fp32 here
-                const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(J.H) + (int64_t)batch * J.h_bstride +
-                                                                4 * cg + (int64_t)r * J.ldh);
-                hv = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
-                                 __uint_as_float(q.y & 0xffff0000u));
-            } else {
-                hv = *reinterpret_cast<const float4*>(h + (int64_t)r * J.ldh);
+        // eight rows in flight per thread: the index, the gathered dZ element and the H piece of a row are a chain of dependent loads
+        // (one row at a time this loop ran at one memory round trip per 16 rows: 1.57 ms alone for the 19,056-row chunks of cfg-E)
+        constexpr int U = 8;
+        for (int r = r0 + rlane; r < r1; r += rl * U) {
+            int64_t zo[U];
+            int rc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rc[u] = r + u * rl < r1 ? r + u * rl : r;   // clamped: unconditional loads, predicated accumulation
+                zo[u] = (int64_t)(zi ? zi[rc[u]] : rc[u]) * J.ldz;
             }
-            if (J.pieces == 1) {   // (MPNHIP_PREC_BF16: the same operand rounding as the MFMA jobs)
-                zz = (float)(__bf16)zz;
-                hv = make_float4((float)(__bf16)hv.x, (float)(__bf16)hv.y, (float)(__bf16)hv.z, (float)(__bf16)hv.w);
+            float zr[U];
+            float4 hq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                zr[u] = z[zo[u]];
+                if (J.src16) {   // H as bf16 rows (J.H points at unsigned shorts; ldh / h_bstride count them); dZ stays fp32 here
+                    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(J.H) + (int64_t)batch * J.h_bstride +
+                                                                    4 * cg + (int64_t)rc[u] * J.ldh);
+                    hq[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                        __uint_as_float(q.y & 0xffff0000u));
+                } else {
+                    hq[u] = *reinterpret_cast<const float4*>(h + (int64_t)rc[u] * J.ldh);
+                }
             }
-            acc.x = fmaf(zz, hv.x, acc.x); acc.y = fmaf(zz, hv.y, acc.y); acc.z = fmaf(zz, hv.z, acc.z); acc.w = fmaf(zz, hv.w, acc.w);
-            bs += z[(int64_t)(zi ? zi[r] : r) * J.ldz];   // (the bias gradient is a plain sum: not a product, nothing rounded)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u * rl < r1) {
+                    float zz = zr[u];
+                    float4 hv = hq[u];
+                    if (J.pieces == 1) {   // (MPNHIP_PREC_BF16: the same operand rounding as the MFMA jobs)
+                        zz = (float)(__bf16)zz;
+                        hv = make_float4((float)(__bf16)hv.x, (float)(__bf16)hv.y, (float)(__bf16)hv.z, (float)(__bf16)hv.w);
+                    }
+                    acc.x = fmaf(zz, hv.x, acc.x); acc.y = fmaf(zz, hv.y, acc.y); acc.z = fmaf(zz, hv.z, acc.z); acc.w = fmaf(zz, hv.w, acc.w);
+                    bs += zr[u];   // (the bias gradient is a plain sum: not a product, nothing rounded)
+                }
+            }
         }
     }
     float* part = reinterpret_cast<float*>(lds);   // [rl][kc + 4]
@@ -702,9 +723,9 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bo
     if (n_out == 1 && k_in % 4 == 0 && k_in <= 64) { *variant = 6; *tiles_o = 1; *tiles_c = 1; return; }   // wp_block_vec
     if (wp_is_small(n_out, k_in)) { *variant = 7; *tiles_o = 1; *tiles_c = 1; return; }                   // wp_block_small
     if (src16 && rows16) {
-        int tc = 1;
-        const int v = r16_variant(n_out, k_in, &tc);
-        if (v >= 0) { *variant = v; *tiles_o = 1; *tiles_c = tc; return; }
+        int to = 1, tc = 1;
+        const int v = r16_variant(n_out, k_in, &to, &tc);
+        if (v >= 0) { *variant = v; *tiles_o = to; *tiles_c = tc; return; }
     }
     if (src16) {
         // cost = the columns every operand row is staged with, summed over the output tiles (a partial last tile stages only its
@@ -742,17 +763,26 @@ int wp_target_blocks(bool batched) {
 }
 
 // rows per chunk / chunks per batch of one job: ~wp_target_blocks() blocks per job, chunks of at least 256 rows
-void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit, int min_chunk = 256) {
+// light (a slab of at most 16K floats per chunk: [1 x k], the small shapes, skinny products like the classifier's [64 x 128]): chunks of
+// at most 4096 rows -- a block of this kernel walks its rows at ~0.7 - 1.5 us per 16-row stage whatever the width (one stage in
+// flight), and extra chunks of these jobs cost next to nothing in slabs (the three skinny jobs of a six-step group at cfg-E,
+// 19,056-row chunks: 1.76 ms alone at the end of the step for 1.2 GB)
+void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit, int min_chunk = 256,
+             bool light = false) {
     if (rows_expected < 1) rows_expected = 1;
     int want = wp_target_blocks(batched) / (nbatch * tiles);
     if (want < 1) want = 1;
     int64_t c = (rows_expected + want - 1) / want;
+    static const bool cap = !getenv("MPNHIP_WP_NO_LIGHT_CAP");
+    if (light && cap && c > 4096) c = 4096;
     if (c < min_chunk) c = min_chunk;
     c = (c + WP_KB - 1) / WP_KB * WP_KB;
     *chunk = (int)c;
     *nsplit = (int)((rows_upper + c - 1) / c);
     if (*nsplit < 1) *nsplit = 1;
 }
+
+bool wp_light(int variant, int n_out, int k_in) { return variant < 16 && (size_t)n_out * tn_kpad(k_in) <= 16384; }
 
 thread_local WpBatch* g_wp = nullptr;
 
@@ -796,7 +826,7 @@ size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged
     // reserve for the one that cuts more row chunks)
     for (int pass = 0; pass < (src16 ? 2 : 1); ++pass) {
         wp_choose(n_out, k_in, &v, &to, &tc, src16, pass == 1);
-        wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit);
+        wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit, 256, wp_light(v, n_out, k_in));
         const size_t f = ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
         need = f > need ? f : need;
     }
@@ -849,7 +879,12 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         if (!wp_eligible(ps[i])) return false;
         need += wp_slab_floats(ps[i].n_out, ps[i].k_in, ps[i].rows, ps[i].nbatch, ps[i].row_begin || ps[i].row_end, b->batched, ps[i].src16 != 0);
     }
-    if (b->used + need > b->slab_floats) return false;
+    if (b->used + need > b->slab_floats) {
+        if (getenv("MPNHIP_WP_TRACE"))
+            fprintf(stderr, "wp batch: job %d [%d x %d] rows %lld x%d needs %zu slab floats, %zu of %zu used\n", b->tab.njobs, ps[0].n_out, ps[0].k_in,
+                    (long long)ps[0].rows, ps[0].nbatch, need, b->used, b->slab_floats);
+        return false;
+    }
     for (int i = 0; i < n; ++i) {
         const WpProduct& p = ps[i];
         const bool ranged = p.row_begin || p.row_end;
@@ -860,7 +895,8 @@ bool wp_batch_add(const WpProduct* ps, int n) {
                             p.h_bstride % 8 == 0 && p.ldz < ((int64_t)1 << 28) && p.ldh < ((int64_t)1 << 28);
         wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c, p.src16 != 0, rows16);
         J.src16 = p.src16 ? 1 : 0;
-        wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit);
+        wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit, 256,
+                wp_light(J.variant, p.n_out, p.k_in));
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
         J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
         J.pieces = p.pieces == 1 ? 1 : 3;
@@ -901,6 +937,15 @@ int wp_batch_flush(hipStream_t s) {
     (void)attr_set;
     count_path(PC_TN_PANEL_LAUNCH);
     if (const char* e = getenv("MPNHIP_WP_DEBUG")) b->tab.debug = atoi(e); else b->tab.debug = 0;
+    static const bool trace = getenv("MPNHIP_WP_TRACE") != nullptr;   // diagnosis: the jobs of every flush, one line each
+    if (trace) {
+        for (int i = 0; i < b->tab.njobs; ++i) {
+            const WpJob& J = b->tab.job[i];
+            fprintf(stderr, "wp job %2d/%d: rows %lld x%d  [%d x %d]  variant %d tiles %dx%d chunk %d nsplit %d  %s pieces %d%s%s\n", i, b->tab.njobs,
+                    (long long)J.m_static, J.nbatch, J.n_out, J.k_in, J.variant, J.tiles_o, J.tiles_c, J.chunk, J.nsplit, J.src16 ? "bf16 rows" : "fp32 rows",
+                    J.pieces, (J.row_begin || J.row_end) ? " ranged" : "", (J.dz_idx || J.h_idx) ? " gathered" : "");
+        }
+    }
     if (b->nblocks2 > 0) {
         // the bf16-row jobs of the LDS-DMA kernel (wgrad_rows16.hip): the profiled launch of a batch that has them (their bytes)
         count_path(PC_TN_ROWS16_LAUNCH);

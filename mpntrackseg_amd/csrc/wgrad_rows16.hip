@@ -36,9 +36,9 @@ constexpr int R16_NST = 4;      // stages in the ring
 // row pitch (bytes) of an image of W bf16 columns: >= 2 W and == 64 (mod 256)
 constexpr int r16_pitch(int W) { return ((2 * W - 64 + 255) / 256) * 256 + 64; }
 
-// One block: job J, column tile `tile_c` (tiles of BC columns), row chunk `by`.
+// One block: job J, output tile (`tile_o`: BO dZ columns = output rows, `tile_c`: BC H columns), row chunk `by`.
 template <int WO, int WC, int TM, int TN>
-__device__ __forceinline__ void r16_block(const WpJob& J, const int tile_c, const int by, char* lds, const int dbg) {
+__device__ __forceinline__ void r16_block(const WpJob& J, const int tile_o, const int tile_c, const int by, char* lds, const int dbg) {
     static_assert(WO * WC == 8, "8 waves");
     constexpr int BO = 32 * TM * WO, BC = 32 * TN * WC;
     constexpr int PZ = r16_pitch(BO), PH = r16_pitch(BC);
@@ -61,10 +61,10 @@ __device__ __forceinline__ void r16_block(const WpJob& J, const int tile_c, cons
     if (r0 >= r1) return;   // empty chunk: the slab sum skips it too
     const bool odd = ci & 1;
 
-    const int c0 = tile_c * BC;
-    const int wz = J.n_out;                                  // live dZ columns (<= BO), a multiple of 8
+    const int c0 = tile_c * BC, o0 = tile_o * BO;
+    const int wz = J.n_out - o0 < BO ? J.n_out - o0 : BO;    // live dZ columns of this tile, a multiple of 8
     const int wh = J.k_in - c0 < BC ? J.k_in - c0 : BC;      // live H columns of this tile, a multiple of 8
-    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(J.dZ) + (int64_t)batch * J.z_bstride;
+    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(J.dZ) + (int64_t)batch * J.z_bstride + o0;
     const unsigned short* const hsrc = reinterpret_cast<const unsigned short*>(J.H) + (int64_t)batch * J.h_bstride + c0;
     const int64_t ldz = J.ldz, ldh = J.ldh;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -234,13 +234,13 @@ __device__ __forceinline__ void r16_block(const WpJob& J, const int tile_c, cons
             const int c = c0 + 32 * (wc * TN + j) + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int o = 32 * (wo * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int o = o0 + 32 * (wo * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (o < J.n_out && c < J.k_in && c < c0 + BC) slab[(size_t)o * kpad + c] = acc[i][j][r];
             }
         }
     if (bias_thread) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) slab[(size_t)(tid * 4 + e) * kpad + J.k_in] = odd ? -bsum[e] : bsum[e];
+        for (int e = 0; e < 4; ++e) slab[(size_t)(o0 + tid * 4 + e) * kpad + J.k_in] = odd ? -bsum[e] : bsum[e];
     }
 }
 
@@ -255,24 +255,36 @@ __global__ __launch_bounds__(R16_NT, 2) void wgrad_rows16_kernel(WpTable tab) {
     if (j < 0) return;
     const WpJob& J = tab.job[j];
     const int local = b - J.block0;
-    const int by = local / J.tiles_c, tile = local - by * J.tiles_c;
+    const int ntiles = J.tiles_o * J.tiles_c;
+    const int by = local / ntiles, tile = local - by * ntiles;
+    const int tile_o = tile / J.tiles_c, tile_c = tile - tile_o * J.tiles_c;
     switch (J.variant) {
-        case 16: r16_block<2, 4, 10, 1>(J, tile, by, r16_lds, tab.debug); break;   // 640 x 128
-        case 17: r16_block<4, 2, 1, 10>(J, tile, by, r16_lds, tab.debug); break;   // 128 x 640
-        case 18: r16_block<2, 4, 7, 1>(J, tile, by, r16_lds, tab.debug); break;    // 448 x 128
-        default: r16_block<2, 4, 4, 2>(J, tile, by, r16_lds, tab.debug); break;    // 256 x (256 + 192)
+        case 16: r16_block<2, 4, 10, 1>(J, tile_o, tile_c, by, r16_lds, tab.debug); break;   // 640 x 128
+        case 17: r16_block<4, 2, 1, 10>(J, tile_o, tile_c, by, r16_lds, tab.debug); break;   // 128 x 640
+        case 18: r16_block<2, 4, 7, 1>(J, tile_o, tile_c, by, r16_lds, tab.debug); break;    // 448 x 128
+        default: r16_block<2, 4, 4, 2>(J, tile_o, tile_c, by, r16_lds, tab.debug); break;    // tiles of 256 x 256
     }
 }
 
-// the variant (16 .. 19) of this kernel for an [n_out x k_in] product over bf16 rows, or -1: its shapes are the 256-d model's --
-// every 1 KiB piece of a row must have a live lane (the counted vmcnt waits assume every DMA instruction was issued)
-int r16_variant(int n_out, int k_in, int* tiles_c) {
+// the variant (16 .. 19) of this kernel for an [n_out x k_in] product over bf16 rows, or -1: the one-pass shapes of the 256-d model,
+// and -- variant 19 in tiles of 256 x 256 -- what needs several output tiles anyway: the node-level products ([2176 x 256] per-node
+// projections, [1024 x 2048] encoder layers: GEMM-shaped, few rows and a wide output; the row-panel kernel's 128 x 128 tiles re-read
+// the fp32 operand rows 17 / 2 times there).  Every 1 KiB piece of a row must have a live lane (the counted vmcnt waits assume every DMA
+// instruction was issued): 256-column tiles are one piece per row, live for any non-empty tile.
+int r16_variant(int n_out, int k_in, int* tiles_o, int* tiles_c) {
     if (getenv("MPNHIP_NO_WGRAD_ROWS16") || n_out % 8 != 0 || k_in % 8 != 0) return -1;
+    *tiles_o = 1;
     *tiles_c = 1;
     if (n_out > 512 && n_out <= 640 && k_in <= 128) return 16;
     if (n_out <= 128 && k_in > 512 && k_in <= 640) return 17;
     if (n_out > 256 && n_out <= 448 && k_in <= 128) return 18;
     if (n_out > 128 && n_out <= 256 && k_in > 256 && k_in <= 512) { *tiles_c = 2; return 19; }
+    static const bool tiled = !getenv("MPNHIP_NO_WGRAD_ROWS16_TILED");
+    if (tiled && ((n_out > 640 && k_in > 128) || (n_out > 128 && k_in > 640))) {
+        *tiles_o = (n_out + 255) / 256;
+        *tiles_c = (k_in + 255) / 256;
+        return 19;
+    }
     return -1;
 }
 

@@ -61,6 +61,36 @@ def test_bf16_training_at_cfgB_size_matches_the_bf16_oracle():
     assert max(worst.values()) < 2e-2, {k: v for k, v in worst.items() if v >= 2e-2}
 
 
+def test_bf16_node_level_weight_gradients_run_over_bf16_rows(monkeypatch):
+    """Round 5: the GEMM-shaped node-level products of the 256-d model -- per-node projections [2176 x 256] (dP rounded by the scatter-add
+    kernel, x from the forward's bf16 mirror), node update [256 x 512], the hoisted x0 share, the node encoder's [1024 x 2048] and
+    [256 x 1024] (rounded on the tail batch's stream) -- on the LDS-DMA kernel's 256 x 256 tiles.  L = 4: the groups run on the side
+    stream, the tail batch is deferred.  Against the bf16 oracle, and against the same step with these products left on fp32 rows
+    (MPNHIP_NO_NODE_ROWS16=1: the same roundings, another kernel and summation order)."""
+    from pinned import hip_run, oracle_run, rel_l2
+    N, E, d, L = 1200, 9000, 256, 4
+    g = synth.make_graph(N, E, seed=33, node_in_dim=2048)
+    params = synth.model_params(d, L, "sum", node_in_dim=2048)
+    W = synth.make_weights(params, seed=11, gain=0.8)
+    model = bf16_model(params, W)
+    r = synth.normal(19, (L, E))
+    lg, grads, given, counts = hip_run(model, g, r, dev())
+    assert counts["edge_chain_bwd_bf16"] == L and counts["wgrad_panel_fallback"] <= 1, {k: v for k, v in counts.items() if v}
+    monkeypatch.setenv("MPNHIP_NO_NODE_ROWS16", "1")
+    lg0, grads0, _, counts0 = hip_run(model, g, r, dev())
+    monkeypatch.delenv("MPNHIP_NO_NODE_ROWS16")
+    # per group of steps: projections + node update; the tail: x0 share + the two wide encoder layers
+    assert counts["wgrad_rows16"] - counts0["wgrad_rows16"] >= 2 * 2 + 3, (counts["wgrad_rows16"], counts0["wgrad_rows16"])
+    assert np.array_equal(lg, lg0)
+    diff = {k: rel_l2(grads[k], grads0[k]) for k in grads0 if np.linalg.norm(grads0[k]) > 0}
+    assert max(diff.values()) < 2e-3, {k: v for k, v in diff.items() if v >= 2e-3}
+    with O.precision("bf16"):
+        l32, ref, _ = oracle_run(params, W, g, r, given, "impose", dtype=torch.float32)
+    worst = {k: rel_l2(grads[k], ref[k]) for k in ref if np.linalg.norm(ref[k]) > 0}
+    print({k: "%.2e" % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    assert max(worst.values()) < 2e-2, {k: v for k, v in worst.items() if v >= 2e-2}
+
+
 def _fuzz_cases(n, seed):
     from tools.diag import fuzz_parity as fz
     rng = np.random.RandomState(seed)

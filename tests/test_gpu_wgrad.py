@@ -57,7 +57,9 @@ def test_weight_grad_is_bitwise_reproducible():
 
 
 SHAPES16 = [(640, 128), (128, 640), (448, 128), (256, 448), (64, 128), (320, 64), (64, 320), (224, 64), (128, 224), (32, 64), (80, 16),
-            (16, 80), (56, 16), (32, 56), (8, 16), (160, 32), (32, 160), (112, 32), (64, 112), (16, 32), (24, 8)]
+            (16, 80), (56, 16), (32, 56), (8, 16), (160, 32), (32, 160), (112, 32), (64, 112), (16, 32), (24, 8),
+            # GEMM-shaped node-level products: 256 x 256 output tiles of the LDS-DMA kernel (partial last tiles in both directions)
+            (2176, 256), (680, 328), (264, 648), (1024, 2048)]
 
 
 @pytest.mark.parametrize("n_out,k_in", SHAPES16)

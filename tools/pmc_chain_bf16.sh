@@ -9,17 +9,21 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmcb$i -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmcb$i.log 2>&1
 done
 cd $R
-python - <<'PY'
+python - > gpurun_out/pmc_bf16_fwd.txt <<'PY'
 import csv, glob, collections
+print('# tools/pmc_chain_bf16.sh: rocprofv3 --kernel-trace --pmc <group> (one group per pass), cfg-E bf16 inference forward; averages per launch')
 for i in range(1, 7):
     fs = glob.glob('gpurun_out/pmcb%d/*/*counter_collection.csv' % i)
     if not fs: print('no file', i); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         k = r['Kernel_Name']
-        if 'edge_chain_bf16' not in k and 'k_aggregate' not in k: continue
-        acc[k[:40]][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'edge_chain_bf16' not in k and 'k_aggregate' not in k and 'gemm_bf16' not in k: continue
+        k = k.replace('void mpnhip::', '').replace('(anonymous namespace)::', '')
+        acc[k[:64]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, d in sorted(acc.items()):
         for c, v in d.items():
             print(k, c, 'n=%d' % len(v), 'avg=%.6g' % (sum(v) / len(v)))
 PY
+rm -rf gpurun_out/pmcb[1-9]
+cat gpurun_out/pmc_bf16_fwd.txt

@@ -12,8 +12,9 @@ done
 cd $R
 python - > gpurun_out/pmc_bf16_train.txt <<'PY'
 import csv, glob, collections
-KEYS = {"edge_chain_bf16_kernel<…, SAVE>": "1, true, 4>(mpnhip::EdgeChainBf16Args", "edge_chain_bf16_bwd_kernel": "edge_chain_bf16_bwd_kernel",
-        "k_segment_reduce3_b16": "k_segment_reduce3_b16", "wgrad_panel_kernel": "wgrad_panel_kernel", "k_sum_blocks_bf16": "k_sum_blocks_bf16"}
+KEYS = {"edge_chain_bf16_kernel<…, SAVE>": "1, true, 4, false>(mpnhip::EdgeChainBf16Args", "edge_chain_bf16_bwd_kernel": "edge_chain_bf16_bwd_kernel",
+        "k_segment_reduce3_b16": "k_segment_reduce3_b16", "wgrad_panel_kernel": "wgrad_panel_kernel", "k_sum_blocks_bf16": "k_sum_blocks_bf16",
+        "wgrad_rows16_kernel": "wgrad_rows16_kernel", "gemm_bf16_ring_kernel": "gemm_bf16_ring_kernel"}
 print("# tools/pmc_chain_bf16_train.sh: rocprofv3 --kernel-trace --pmc <group> (one group per pass), cfg-E bf16 training step; averages per launch")
 for i in range(1, 6):
     fs = glob.glob('gpurun_out/pmct%d/*/*counter_collection.csv' % i)

@@ -9,7 +9,10 @@ import torch
 from mpntrackseg_amd import capi, synth
 
 CFG_E = [(400000, 640, 128, "edge L1 e part"), (400000, 128, 640, "edge L2"), (200000, 448, 128, "flow L1 e part (one dir)"),
-         (200000, 256, 448, "flow L2 (one dir)"), (400000, 64, 128, "classifier L1")]
+         (200000, 256, 448, "flow L2 (one dir)"), (400000, 64, 128, "classifier L1"),
+         # node level (20,000 rows): GEMM-shaped, 256 x 256 output tiles
+         (20000, 2176, 256, "node projections"), (20000, 256, 512, "node update"), (20000, 1024, 2048, "node encoder L0"),
+         (20000, 256, 1024, "node encoder L1")]
 
 
 def main():
