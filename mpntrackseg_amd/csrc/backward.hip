@@ -1366,15 +1366,23 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // (round 4: on a SECOND side stream, beside the last group of steps -- their "+=" go to disjoint gradient columns; the step used to
     // end with ~0.3 ms in which only the side stream worked: last group 0.78 ms, then this batch 0.19 ms.  The first side stream is
     // ordered behind it, so what follows there -- the unpacking of the packed projection gradient, a trainer's collective -- sees both.)
-    static const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2");
+    // (small graphs: every hop between streams -- event record, wait -- costs 10 - 18 us of the step's tail; behind a last group of
+    // ~45 us the tail batch loses nothing on the first side stream and saves a hop: cfg-D 0.494 -> 0.470 ms, cfg-C 1.933 -> 1.960 the
+    // other way round.  MPNHIP_TAIL_STREAM2=1 / MPNHIP_NO_TAIL_STREAM2=1 force either.)
+    const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2") && (getenv("MPNHIP_TAIL_STREAM2") || (double)E * dn >= 1e6);
     Rows16Later later16;
     later16.pool = p.enc16;
     later16.pool_elems = p.enc16_elems;
+    // ... and with the encoder's products deferred to the end anyway, a small graph's tail batch runs on the CALLER's stream itself, then
+    // the join, the unpacking and whatever the caller enqueues next: no hop ahead of the batch and one instead of two behind it
+    const bool tail_inline = defer_encoder && !tail_beside && !getenv("MPNHIP_NO_TAIL_INLINE");
     auto flush_tail = [&]() -> int {
         if (!wp_batch_open()) return MPNHIP_OK;
-        hipStream_t st = tail_beside ? side->stream2 : side->stream;
-        MPN_HIP(hipEventRecord(side->ready, s));
-        MPN_HIP(hipStreamWaitEvent(st, side->ready, 0));
+        hipStream_t st = tail_inline ? s : tail_beside ? side->stream2 : side->stream;
+        if (!tail_inline) {
+            MPN_HIP(hipEventRecord(side->ready, s));
+            MPN_HIP(hipStreamWaitEvent(st, side->ready, 0));
+        }
         for (int i = 0; i < later16.n; ++i) MPN_TRY(to_bf16_rows(later16.item[i].src, later16.item[i].dst, later16.item[i].n, st));
         later16.n = 0;
         MPN_TRY(wp_batch_flush(st));
@@ -1571,7 +1579,15 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     }
     if (unpack_pending) {
         MPN_TRY(flush_tail());
-        MPN_TRY(unpack_node_grads(side->stream));
+        if (tail_inline) {
+            // the groups' "+=" first (side stream), then the unpacking on the caller's stream
+            MPN_HIP(hipEventRecord(side->done, side->stream));
+            MPN_HIP(hipStreamWaitEvent(s, side->done, 0));
+            join.joined = true;
+            MPN_TRY(unpack_node_grads(s));
+        } else {
+            MPN_TRY(unpack_node_grads(side->stream));
+        }
     }
     if ((flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && !forked && side) {
         // nothing was forked (no side stream work: few steps, or the fork was not possible), but the caller was promised that the
@@ -1585,7 +1601,7 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         // gradients on the side stream, where it overlaps the encoder's backward still running on the caller's stream.
         if (flags & MPNHIP_BWD_DEFER_SIDE_JOIN) {
             join.joined = true;
-        } else {
+        } else if (!join.joined) {   // (tail_inline: joined ahead of the unpacking)
             MPN_HIP(hipEventRecord(side->done, side->stream));
             MPN_HIP(hipStreamWaitEvent(s, side->done, 0));
             join.joined = true;

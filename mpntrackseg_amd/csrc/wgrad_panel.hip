@@ -18,6 +18,7 @@
 //     bias across neighbouring chunks instead of adding it up over all rows.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -619,7 +620,8 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
     const int b = blockIdx.x;
     int j = -1;
     for (int i = 0; i < tab.njobs; ++i)
-        if (tab.job[i].variant < 16 && b >= tab.job[i].block0) j = i;   // (variants >= 16: wgrad_rows16.hip's launch)
+        if (tab.job[i].variant < 16 && b >= tab.job[i].block0 &&
+            b < tab.job[i].block0 + tab.job[i].tiles_o * tab.job[i].tiles_c * tab.job[i].nsplit * tab.job[i].nbatch) j = i;   // (variants >= 16: wgrad_rows16.hip's launch)
     if (j < 0) return;
     const WpJob& J = tab.job[j];
     const int local = b - J.block0;
@@ -944,6 +946,31 @@ int wp_batch_flush(hipStream_t s) {
             fprintf(stderr, "wp job %2d/%d: rows %lld x%d  [%d x %d]  variant %d tiles %dx%d chunk %d nsplit %d  %s pieces %d%s%s\n", i, b->tab.njobs,
                     (long long)J.m_static, J.nbatch, J.n_out, J.k_in, J.variant, J.tiles_o, J.tiles_c, J.chunk, J.nsplit, J.src16 ? "bf16 rows" : "fp32 rows",
                     J.pieces, (J.row_begin || J.row_end) ? " ranged" : "", (J.dz_idx || J.h_idx) ? " gathered" : "");
+        }
+    }
+    // Blocks are dispatched in index order: the jobs with the longest blocks get the lowest indices, so that a launch ends on its short
+    // blocks (longest-processing-time-first; the order the products were recorded in put the widest -- edge layer 0 / 1, the per-node
+    // projections -- last).  A block's length ~ its chunk's rows x the columns it stages per row.  MPNHIP_WP_NO_LPT=1: recording order.
+    static const bool lpt = !getenv("MPNHIP_WP_NO_LPT");
+    if (lpt) {
+        for (int pass = 0; pass < 2; ++pass) {   // the row-panel kernel's jobs, then wgrad_rows16.hip's: each launch has its own indices
+            int idx[WP_MAX_JOBS], n = 0;
+            double w[WP_MAX_JOBS];
+            for (int i = 0; i < b->tab.njobs; ++i) {
+                const WpJob& J = b->tab.job[i];
+                if ((J.variant >= 16) != (pass == 1)) continue;
+                const double rows = (J.row_begin || J.row_end) ? 0.5 * J.chunk : (double)J.chunk;
+                w[n] = rows * ((double)J.n_out / J.tiles_o + (double)J.k_in / J.tiles_c);
+                idx[n++] = i;
+            }
+            for (int a = 1; a < n; ++a)   // (insertion sort, stable: equal weights keep the recording order)
+                for (int c = a; c > 0 && w[c] > w[c - 1]; --c) { std::swap(w[c], w[c - 1]); std::swap(idx[c], idx[c - 1]); }
+            int next = 0;
+            for (int a = 0; a < n; ++a) {
+                WpJob& J = b->tab.job[idx[a]];
+                J.block0 = next;
+                next += J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
+            }
         }
     }
     if (b->nblocks2 > 0) {

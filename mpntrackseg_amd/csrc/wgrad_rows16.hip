@@ -251,7 +251,8 @@ __global__ __launch_bounds__(R16_NT, 2) void wgrad_rows16_kernel(WpTable tab) {
     const int b = blockIdx.x;
     int j = -1;
     for (int i = 0; i < tab.njobs; ++i)
-        if (tab.job[i].variant >= 16 && b >= tab.job[i].block0) j = i;
+        if (tab.job[i].variant >= 16 && b >= tab.job[i].block0 &&
+            b < tab.job[i].block0 + tab.job[i].tiles_o * tab.job[i].tiles_c * tab.job[i].nsplit * tab.job[i].nbatch) j = i;
     if (j < 0) return;
     const WpJob& J = tab.job[j];
     const int local = b - J.block0;
