@@ -181,6 +181,15 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int* __restri
     dst[i] = src[(int64_t)idx[r] * cols + c];
 }
 
+// 16-byte zeros over two regions (grid-stride)
+__global__ __launch_bounds__(256) void k_zero_pair(uint4* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (int64_t)gridDim.x * 256) {
+        if (i < na) a[i] = z;
+        else b[i - na] = z;
+    }
+}
+
 static int relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s, const float* g2 = nullptr) {
     if (n <= 0) return MPNHIP_OK;
     hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, g, g2, act, out, n);
@@ -847,21 +856,34 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
 
     // ---- seeds ----------------------------------------------------------------------------------
     int cx = 0;
-    {   // zeros: dX[0] (unless the caller seeds it) | dX0 | dE0 | gWnode, contiguous in the plan
-        char* z0 = reinterpret_cast<char*>(grad_x_out ? p.dX0 : p.dX[0]);
-        MPN_HIP(hipMemsetAsync(z0, 0, (size_t)(reinterpret_cast<char*>(p.zero_end) - z0), s));
-    }
+    // zeros: dX[0] (unless the caller seeds it) | dX0 | dE0 | gWnode, contiguous in the plan -- and, below, the seed of the gradient
+    // w.r.t. e_L: ONE launch of a plain kernel for both (hipMemsetAsync's fill was preceded by ~18 us of idle queue in every step
+    // of the cfg-D timeline; two of them opened every backward)
+    char* const z0 = reinterpret_cast<char*>(grad_x_out ? p.dX0 : p.dX[0]);
+    const size_t z0_bytes = (size_t)(reinterpret_cast<char*>(p.zero_end) - z0);
     if (grad_x_out) MPN_HIP(hipMemcpyAsync(p.dX[0], grad_x_out, xs * 4, hipMemcpyDeviceToDevice, s));
     // the gradient w.r.t. e_s lives in the LAST edge-layer dZ block of step s (it becomes that dZ once masked)
     if (f.b16 != p.b16) { set_error("backward: the forward workspace was saved in another mode (bf16 fused training %d vs %d)", (int)f.b16, (int)p.b16); return MPNHIP_ERR_ARG; }
     const bool use_b16 = p.b16 && E > 0 && L > 0;   // bf16-operand training on the fused kernels (plan.h: chain_bf16_train_ok)
     int ce = 0;                                      // ... the gradient w.r.t. e_s travels in p.dEpp[ce]
     float* dE_last = use_b16 ? p.dEpp[0] : (L > 0 ? p.dZed[ne - 1] + (size_t)(L - 1) * es : p.dE0);
+    {
+        bool zero_e = !(grad_e_out && es) && es && L > 0;
+        if (zero_e && ((((uintptr_t)dE_last) & 15) != 0 || (es * 4) % 16 != 0)) {   // (odd E de: a block inside the dZ array is not 16-byte aligned)
+            MPN_HIP(hipMemsetAsync(dE_last, 0, es * 4, s));
+            zero_e = false;
+        }
+        const int64_t n0 = (int64_t)(z0_bytes / 16), n1 = zero_e ? (int64_t)(es * 4 / 16) : 0;   // (arena blocks: 256-byte multiples)
+        if (n0 + n1 > 0) {
+            int64_t blocks = (n0 + n1 + 255) / 256;
+            blocks = blocks > 4096 ? 4096 : blocks;
+            hipLaunchKernelGGL(k_zero_pair, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(z0), n0, reinterpret_cast<uint4*>(dE_last), n1);
+            MPN_LAUNCH_CHECK();
+        }
+    }
     if (grad_e_out && es) {
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((es + 255) / 256)), dim3(256), 0, s, grad_e_out, g.perm, dE_last, E, de);
         MPN_LAUNCH_CHECK();
-    } else if (es && L > 0) {
-        MPN_HIP(hipMemsetAsync(dE_last, 0, es * 4, s));
     }
     const float* x0 = f.x_hist;
     const float* e0 = f.e_hist;
