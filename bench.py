@@ -738,7 +738,8 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
             res["roofline_weight_grad"] = {"bound": "hbm", "kernel": ("wgrad_rows16_kernel: dW += dZ^T H over bf16 rows for the 256-d products of a group of steps in one "
                                                                       "launch (one block per CU owns a row chunk and the whole output: every operand row fetched once; "
                                                                       "LDS-DMA ring, ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16), side stream") if rows16 > 0 else
-                                                                     "wgrad_panel_kernel: dW += dZ^T H for all products of a group of steps in one launch "
+                                                                     ("wgrad_panel_narrow_kernel (64 x 64 tiles, four blocks per CU)" if per_step.get("wgrad_panel_narrow_launches", 0.0) > 0
+                                                                      else "wgrad_panel_kernel") + ": dW += dZ^T H for all products of a group of steps in one launch "
                                                                      "(row-panel blocks, %s, ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16), side stream"
                                                                      % ("bf16 source rows as stored by the chain kernels, one product per k block" if chain == 2 else
                                                                         "three-piece bf16 operands split in the loader"),
@@ -752,7 +753,12 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                     # sampled `algorithmic_bytes` the average of the few launches that carried events: compare the PMC average with
                     # the operand bytes of a step's bf16-row jobs / launches per step instead (edge L1 / L2, flow L1 / L2 over L steps,
                     # + the hoisted e0 share's one product)
+                    # (late round 5: + the node-level products -- per-node projections [pw x dn], node update [dn x 2 dn] over L steps,
+                    # the hoisted x0 share; the node encoder's wide layers are left out of the figure: they depend on the input width)
+                    pw = 2 * he + 2 * hn
                     step_bytes = c["L"] * E * 2.0 * ((he + de) + (de + he) + (hn + de) + (dn + hn)) + E * 2.0 * (he + de)
+                    if per_step.get("wgrad_rows16", 0.0) > 5.5 * launches:   # (13 edge-level jobs per step over 3 launches; 20 with the node level)
+                        step_bytes += c["L"] * N * 2.0 * ((pw + dn) + (dn + 2 * dn)) + N * 2.0 * (pw + dn)
                     avg = step_bytes / launches
                     res["roofline_weight_grad"]["algorithmic_bytes_avg_per_launch"] = avg
                     res["roofline_weight_grad"]["traffic_over_algorithmic"] = res["roofline_weight_grad"]["traffic"] / avg

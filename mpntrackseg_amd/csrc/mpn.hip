@@ -34,7 +34,7 @@ static std::atomic<long long> g_path_counts[PC_COUNT];
 static const char* const g_path_names[PC_COUNT] = {
     "edge_chain_fwd", "edge_chain_fwd_split", "edge_chain_bwd", "edge_chain_bwd_split", "aggregate", "aggregate_block",
     "node_step32", "node_step32_bwd", "segment_reduce", "segment_reduce_block", "segment_reduce_block3", "edge_encoder",
-    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback", "edge_chain_bwd_bf16", "node_chain_bwd", "gemm_bf16_tiled", "gemm_bf16_ring", "wgrad_rows16", "wgrad_rows16_launches"};
+    "edge_encoder_bwd", "gemm_tn_mfma", "gemm_tn_small", "gemm_tn_generic", "gemm_fp32", "gemm_split", "gemm_bf16", "weight_pack", "segment_reduce3", "gemm_splitk", "edge_chain_fwd_bf16", "gemm_tn_panel", "wgrad_panel_launches", "node_chain", "persist32", "wgrad_panel_fallback", "edge_chain_bwd_bf16", "node_chain_bwd", "gemm_bf16_tiled", "gemm_bf16_ring", "wgrad_rows16", "wgrad_rows16_launches", "wgrad_panel_narrow_launches"};
 void count_path(int id) {
     if (id >= 0 && id < PC_COUNT) g_path_counts[id].fetch_add(1, std::memory_order_relaxed);
 }

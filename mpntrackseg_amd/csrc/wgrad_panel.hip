@@ -35,6 +35,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define WP_LDS __attribute__((address_space(3)))
 
 constexpr int WP_NT = 256;   // threads per block: 4 waves as 2 (output rows) x 2 (output columns)
+// wgrad_panel_narrow_kernel: <1, 1> (three 5 KB piece images), wp_block_vec, wp_block_small (up to 33.5 KB).  34 KB also keeps the
+// CU at FOUR blocks (the kernel needs 100 registers: five would fit, and measured slower -- cfg-C 1.86 - 1.89 against 1.84 ms)
+constexpr int WP_NARROW_LDS = 34 * 1024;
 constexpr int WP_KB = 16;    // operand rows per stage = one k block of the bf16 MFMA
 
 // loader passes for an operand of at most B columns: B / 4 threads cover a row, 256 / (B / 4) rows per pass (at most 16)
@@ -615,8 +618,11 @@ __device__ __forceinline__ void wp_block_small(const WpJob& J, const int by, cha
 
 }  // namespace
 
-__global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
-    extern __shared__ __attribute__((aligned(16))) char wp_lds[];
+// NARROW: the launch holds <1, 1> tiles, [1 x k] and small-shape jobs only (the 32-d models: every job re-tiled to 64 x 64 at flush time,
+// wp_batch_flush) -- 128 registers and 34 KB of LDS per block, FOUR blocks per CU instead of two: such a block spends its time in the
+// two barriers and the LDS round trip of 16-row stages that hold six MFMAs per wave, and more resident blocks are what hides them
+template <bool NARROW>
+__device__ __forceinline__ void wp_kernel_body(const WpTable& tab, char* wp_lds) {
     const int b = blockIdx.x;
     int j = -1;
     for (int i = 0; i < tab.njobs; ++i)
@@ -627,24 +633,41 @@ __global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
     const int local = b - J.block0;
     const int ntiles = J.tiles_o * J.tiles_c;
     const int by = local / ntiles, tile = local - by * ntiles;
-    switch (J.variant) {
-        case 0: wp_block<5, 1>(J, tile, by, wp_lds, tab.debug); break;
-        case 1: wp_block<1, 5>(J, tile, by, wp_lds, tab.debug); break;
-        case 2: wp_block<4, 1>(J, tile, by, wp_lds, tab.debug); break;
-        case 3: wp_block<1, 1>(J, tile, by, wp_lds, tab.debug); break;
-        case 6: wp_block_vec(J, by, wp_lds); break;
-        case 7: wp_block_small(J, by, wp_lds); break;
-        // bf16 source rows (one piece: ten accumulator tiles per wave fit): the shapes of the 256-d / 128-d / narrower models
-        case 8: wp_block<5, 2, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 9: wp_block<2, 5, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 10: wp_block<4, 2, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 11: wp_block<2, 4, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 12: wp_block<1, 2, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 13: wp_block<2, 1, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 14: wp_block<1, 1, true>(J, tile, by, wp_lds, tab.debug); break;
-        case 15: wp_block<2, 2, true>(J, tile, by, wp_lds, tab.debug); break;
-        default: wp_block<2, 2>(J, tile, by, wp_lds, tab.debug); break;
+    if constexpr (NARROW) {
+        switch (J.variant) {
+            case 6: wp_block_vec(J, by, wp_lds); break;
+            case 7: wp_block_small(J, by, wp_lds); break;
+            default: wp_block<1, 1>(J, tile, by, wp_lds, tab.debug); break;
+        }
+    } else {
+        switch (J.variant) {
+            case 0: wp_block<5, 1>(J, tile, by, wp_lds, tab.debug); break;
+            case 1: wp_block<1, 5>(J, tile, by, wp_lds, tab.debug); break;
+            case 2: wp_block<4, 1>(J, tile, by, wp_lds, tab.debug); break;
+            case 3: wp_block<1, 1>(J, tile, by, wp_lds, tab.debug); break;
+            case 6: wp_block_vec(J, by, wp_lds); break;
+            case 7: wp_block_small(J, by, wp_lds); break;
+            // bf16 source rows (one piece: ten accumulator tiles per wave fit): the shapes of the 256-d / 128-d / narrower models
+            case 8: wp_block<5, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 9: wp_block<2, 5, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 10: wp_block<4, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 11: wp_block<2, 4, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 12: wp_block<1, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 13: wp_block<2, 1, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 14: wp_block<1, 1, true>(J, tile, by, wp_lds, tab.debug); break;
+            case 15: wp_block<2, 2, true>(J, tile, by, wp_lds, tab.debug); break;
+            default: wp_block<2, 2>(J, tile, by, wp_lds, tab.debug); break;
+        }
     }
+}
+
+__global__ __launch_bounds__(WP_NT, 2) void wgrad_panel_kernel(WpTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char wp_lds[];
+    wp_kernel_body<false>(tab, wp_lds);
+}
+__global__ __launch_bounds__(WP_NT, 4) void wgrad_panel_narrow_kernel(WpTable tab) {
+    extern __shared__ __attribute__((aligned(16))) char wp_lds[];
+    wp_kernel_body<true>(tab, wp_lds);
 }
 
 // grad_w[o * ldw + c] += sum_j (-1)^chunk(j) slab_j[o][c];  grad_b[o] += ... slab_j[o][k_in]  over the non-empty chunks of every
@@ -951,7 +974,47 @@ int wp_batch_flush(hipStream_t s) {
     // Blocks are dispatched in index order: the jobs with the longest blocks get the lowest indices, so that a launch ends on its short
     // blocks (longest-processing-time-first; the order the products were recorded in put the widest -- edge layer 0 / 1, the per-node
     // projections -- last).  A block's length ~ its chunk's rows x the columns it stages per row.  MPNHIP_WP_NO_LPT=1: recording order.
+    // A launch of narrow jobs only (the reference's own widths, d = 32): every MFMA job re-tiled to <1, 1> (64 x 64) tiles -- slabs and
+    // chunks are untouched by the tiling -- and run by the four-blocks-per-CU instantiation.  Taken when the re-tiling re-reads
+    // at most 15 % more operand columns over the whole launch (a [80 x 32] product as 2 x 1 tiles reads its 32 H columns twice).
+    static const bool narrow_on = !getenv("MPNHIP_WP_NO_NARROW");
+    bool narrow = narrow_on && b->nblocks > 0;
+    const int narrow_lds = WP_NARROW_LDS;
+    {
+        double cols = 0.0, extra = 0.0;
+        for (int i = 0; i < b->tab.njobs && narrow; ++i) {
+            const WpJob& J = b->tab.job[i];
+            if (J.variant >= 16) continue;
+            if (J.src16 || J.variant > 7 || J.variant == 4) { narrow = false; break; }
+            const double rows = (double)J.m_static * J.nbatch * ((J.row_begin || J.row_end) ? 0.5 : 1.0);
+            if (J.variant == 6 || J.variant == 7) { cols += rows * (J.n_out + J.k_in); continue; }
+            const int to = (J.n_out + 63) / 64, tc = (J.k_in + 63) / 64;
+            cols += rows * ((double)J.n_out * J.tiles_c + (double)J.k_in * J.tiles_o);
+            extra += rows * ((double)J.n_out * tc + (double)J.k_in * to) - rows * ((double)J.n_out * J.tiles_c + (double)J.k_in * J.tiles_o);
+        }
+        if (narrow && extra > 0.15 * cols) narrow = false;
+        if (narrow) {
+            for (int i = 0; i < b->tab.njobs; ++i) {
+                WpJob& J = b->tab.job[i];
+                if (J.variant >= 16 || J.variant == 6 || J.variant == 7) continue;
+                J.variant = 3;
+                J.tiles_o = (J.n_out + 63) / 64;
+                J.tiles_c = (J.k_in + 63) / 64;
+            }
+            count_path(PC_TN_PANEL_NARROW);
+        }
+    }
     static const bool lpt = !getenv("MPNHIP_WP_NO_LPT");
+    {   // (block counts follow the tiling: recomputed here, in recording order unless re-indexed below)
+        int n1 = 0, n2 = 0;
+        for (int i = 0; i < b->tab.njobs; ++i) {
+            WpJob& J = b->tab.job[i];
+            const int nb = J.tiles_o * J.tiles_c * J.nsplit * J.nbatch;
+            if (J.variant >= 16) { J.block0 = n2; n2 += nb; } else { J.block0 = n1; n1 += nb; }
+        }
+        b->nblocks = n1;
+        b->nblocks2 = n2;
+    }
     if (lpt) {
         for (int pass = 0; pass < 2; ++pass) {   // the row-panel kernel's jobs, then wgrad_rows16.hip's: each launch has its own indices
             int idx[WP_MAX_JOBS], n = 0;
@@ -980,16 +1043,20 @@ int wp_batch_flush(hipStream_t s) {
         const int r2 = launch_wgrad_rows16(b->tab, b->nblocks2, s);
         prof_end(PROF_TN, s);
         MPN_TRY(r2);
-        if (b->nblocks > 0) hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+        if (b->nblocks > 0) {
+            if (narrow) hipLaunchKernelGGL(wgrad_panel_narrow_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), narrow_lds, s, b->tab);
+            else hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+        }
         MPN_LAUNCH_CHECK();
     } else if (b->nblocks > 0) {
         prof_begin(PROF_TN, s, b->bytes);   // (HBM-bound by design: the hook's work figure is the launch's operand bytes)
         {
             hipEvent_t e0, e1;
-            if (prof_launch_events(&e0, &e1))
-                hipExtLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, e0, e1, 0, b->tab);
-            else
-                hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
+            const bool ev = prof_launch_events(&e0, &e1);
+            if (narrow && ev) hipExtLaunchKernelGGL(wgrad_panel_narrow_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), narrow_lds, s, e0, e1, 0, b->tab);
+            else if (narrow) hipLaunchKernelGGL(wgrad_panel_narrow_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), narrow_lds, s, b->tab);
+            else if (ev) hipExtLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, e0, e1, 0, b->tab);
+            else hipLaunchKernelGGL(wgrad_panel_kernel, dim3((unsigned)b->nblocks), dim3(WP_NT), wp_lds_bytes(), s, b->tab);
         }
         prof_end(PROF_TN, s);
         MPN_LAUNCH_CHECK();
