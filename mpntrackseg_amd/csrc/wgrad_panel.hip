@@ -780,10 +780,13 @@ void wp_choose(int n_out, int k_in, int* variant, int* tiles_o, int* tiles_c, bo
 
 // blocks wanted per job: a job alone needs enough row chunks to fill the chip (2 blocks per CU); the jobs of a batch run side by
 // side in one launch, and every extra chunk costs a slab (written, then read by the slab sum: at 512 chunks per job the slabs of a
-// cfg-B group were 30 % of the launch's traffic; measured: cfg-B step 5.43 / 5.37 / 5.29 ms at 320 / 192 / 128 chunks per job)
+// cfg-B group were 30 % of the launch's traffic).  192 per batched job -- same-box sweeps, three runs each, with the launches' blocks
+// dispatched longest first: cfg-B step 5.27 / 4.93 - 4.97 / 4.91 - 4.93 / 4.94 - 4.96 / 4.98 - 4.99 / 5.02 - 5.08 ms at 96 / 128 / 192 / 224 /
+// 256 / 320; cfg-C 1.82 - 1.83 / 1.75 / 1.74 - 1.76 at 128 / 192 / 256; cfg-E (every job) 33.74 - 33.85 / 33.48 - 33.57 / 33.02 - 33.24 /
+// 33.47 - 33.58 / 33.40 - 33.57 at 128 / 160 / 192 / 224 / 256 (round 3, before the dispatch order: 5.43 / 5.37 / 5.29 at 320 / 192 / 128)
 int wp_target_blocks(bool batched) {
     static const int alone = [] { const char* e = getenv("MPNHIP_WP_BLOCKS"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 512; }();
-    static const int shared = [] { const char* e = getenv("MPNHIP_WP_BLOCKS_BATCH"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 128; }();
+    static const int shared = [] { const char* e = getenv("MPNHIP_WP_BLOCKS_BATCH"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 192; }();
     return batched ? shared : alone;
 }
 
@@ -792,16 +795,10 @@ int wp_target_blocks(bool batched) {
 // at most 4096 rows -- a block of this kernel walks its rows at ~0.7 - 1.5 us per 16-row stage whatever the width (one stage in
 // flight), and extra chunks of these jobs cost next to nothing in slabs (the three skinny jobs of a six-step group at cfg-E,
 // 19,056-row chunks: 1.76 ms alone at the end of the step for 1.2 GB)
-// dma (a job of wgrad_rows16.hip's kernel -- one block per CU, a batched launch is 5 - 8 rounds of blocks of ~1 ms): half as many blocks
-// again, each shorter: the rounds pack better and these jobs' slabs are nothing beside their rows.  cfg-E step on one box, three runs
-// each, MPNHIP_WP_BLOCKS_BATCH = 128 / 160 / 192 / 224 / 256 for every job: 33.74 - 33.85 / 33.48 - 33.57 / 33.02 - 33.24 / 33.47 - 33.58 /
-// 33.40 - 33.57 ms; on another, 128 against 192: 33.50 against 32.84 - 33.09 (the tail batch's target makes no difference)
 void wp_plan(int64_t rows_expected, int64_t rows_upper, int nbatch, int tiles, bool batched, int* chunk, int* nsplit, int min_chunk = 256,
-             bool light = false, bool dma = false) {
+             bool light = false) {
     if (rows_expected < 1) rows_expected = 1;
-    int target = wp_target_blocks(batched);
-    if (batched && dma) target += target / 2;
-    int want = target / (nbatch * tiles);
+    int want = wp_target_blocks(batched) / (nbatch * tiles);
     if (want < 1) want = 1;
     int64_t c = (rows_expected + want - 1) / want;
     static const bool cap = !getenv("MPNHIP_WP_NO_LIGHT_CAP");
@@ -857,7 +854,7 @@ size_t wp_slab_floats(int n_out, int k_in, int64_t rows, int nbatch, bool ranged
     // reserve for the one that cuts more row chunks)
     for (int pass = 0; pass < (src16 ? 2 : 1); ++pass) {
         wp_choose(n_out, k_in, &v, &to, &tc, src16, pass == 1);
-        wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit, 256, wp_light(v, n_out, k_in), v >= 16);
+        wp_plan(ranged ? (rows + 1) / 2 : rows, rows, nbatch, to * tc, batched, &chunk, &nsplit, 256, wp_light(v, n_out, k_in));
         const size_t f = ((size_t)nsplit * nbatch * n_out * tn_kpad(k_in) + 63) / 64 * 64;
         need = f > need ? f : need;
     }
@@ -927,7 +924,7 @@ bool wp_batch_add(const WpProduct* ps, int n) {
         wp_choose(p.n_out, p.k_in, &J.variant, &J.tiles_o, &J.tiles_c, p.src16 != 0, rows16);
         J.src16 = p.src16 ? 1 : 0;
         wp_plan(ranged ? (p.rows + 1) / 2 : p.rows, p.rows, p.nbatch, J.tiles_o * J.tiles_c, b->batched, &J.chunk, &J.nsplit, 256,
-                wp_light(J.variant, p.n_out, p.k_in), J.variant >= 16);
+                wp_light(J.variant, p.n_out, p.k_in));
         J.dZ = p.dZ; J.H = p.H; J.ldz = p.ldz; J.ldh = p.ldh; J.z_bstride = p.z_bstride; J.h_bstride = p.h_bstride;
         J.H2 = p.H2; J.ldh2 = p.ldh2; J.h2_bstride = p.h2_bstride; J.csplit = p.H2 ? p.csplit : p.k_in;
         J.pieces = p.pieces == 1 ? 1 : 3;
