@@ -1388,16 +1388,21 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     // (round 4: on a SECOND side stream, beside the last group of steps -- their "+=" go to disjoint gradient columns; the step used to
     // end with ~0.3 ms in which only the side stream worked: last group 0.78 ms, then this batch 0.19 ms.  The first side stream is
     // ordered behind it, so what follows there -- the unpacking of the packed projection gradient, a trainer's collective -- sees both.)
-    // (small graphs: every hop between streams -- event record, wait -- costs 10 - 18 us of the step's tail; behind a last group of
-    // ~45 us the tail batch loses nothing on the first side stream and saves a hop: cfg-D 0.494 -> 0.470 ms, cfg-C 1.933 -> 1.960 the
-    // other way round.  MPNHIP_TAIL_STREAM2=1 / MPNHIP_NO_TAIL_STREAM2=1 force either.)
-    const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2") && (getenv("MPNHIP_TAIL_STREAM2") || (double)E * dn >= 1e6);
+    // Where the tail batch runs.  With the encoder's products deferred to the end anyway (no MPNHIP_BWD_DEFER_SIDE_JOIN) it runs on the
+    // CALLER's stream itself, then the join, the unpacking and whatever the caller enqueues next: no hop ahead of the batch (event
+    // record -> wait: 10 - 18 us each) and one instead of two behind it.  Same-box A-B, three runs each, second side stream / caller's
+    // stream / first side stream: cfg-B 4.94 - 5.00 / 4.90 - 4.93 / 4.92 - 4.97 ms, cfg-C 1.76 - 1.78 / 1.72 - 1.74 / 1.80 - 1.82, cfg-E 33.5 - 33.6 /
+    // 33.6 / 34.0, cfg-D 0.494 / 0.444 / 0.470 -- the second stream was round 4's answer to a tail of ~0.3 ms behind the last group; with
+    // the launches' blocks dispatched longest first it no longer pays.  A trainer's path (MPNHIP_BWD_DEFER_SIDE_JOIN: the hoisted
+    // shares' products run early, the message-passing gradients' collective follows on the first side stream) keeps the second stream
+    // on large graphs.  MPNHIP_TAIL_STREAM2=1 / MPNHIP_NO_TAIL_STREAM2=1 force either, MPNHIP_NO_TAIL_INLINE=1 keeps the batch off the
+    // caller's stream.
+    const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2") &&
+                             (getenv("MPNHIP_TAIL_STREAM2") || ((flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && (double)E * dn >= 1e6));
+    const bool tail_inline = defer_encoder && !tail_beside && !getenv("MPNHIP_NO_TAIL_INLINE");
     Rows16Later later16;
     later16.pool = p.enc16;
     later16.pool_elems = p.enc16_elems;
-    // ... and with the encoder's products deferred to the end anyway, a small graph's tail batch runs on the CALLER's stream itself, then
-    // the join, the unpacking and whatever the caller enqueues next: no hop ahead of the batch and one instead of two behind it
-    const bool tail_inline = defer_encoder && !tail_beside && !getenv("MPNHIP_NO_TAIL_INLINE");
     auto flush_tail = [&]() -> int {
         if (!wp_batch_open()) return MPNHIP_OK;
         hipStream_t st = tail_inline ? s : tail_beside ? side->stream2 : side->stream;
