@@ -1374,29 +1374,26 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
         MPN_TRY(mp_weight_grads(0, last_n, side->stream, p.slab_side));
     }
     // MPNHIP_PREC_FP32_SPLIT with a side stream: the weight-gradient products of this tail (hoisted shares, encoder layers) are
-    // leaves -- nothing on the caller's stream reads their results -- so they are RECORDED here and run as one batch on the side
-    // stream behind the last group, while the caller's stream goes on with the activation-gradient chain (the encoder chains keep
-    // every dZ block of <= 3 layers: BwdPlan::T / Tn).  With MPNHIP_BWD_DEFER_SIDE_JOIN the encoder's products stay on the caller's
-    // stream: there the side stream's order must end with the message-passing modules' gradients (a trainer puts their all-reduce
-    // behind it while the encoder's backward still runs).
+    // leaves -- nothing on the caller's stream reads their results -- so they are RECORDED here and run as ONE batch at the end
+    // (flush_tail below), while the caller's stream goes on with the activation-gradient chain (the encoder chains keep every dZ
+    // block of <= 3 layers: BwdPlan::T / Tn).  With MPNHIP_BWD_DEFER_SIDE_JOIN the encoder's products stay on the caller's stream
+    // as separate launches and only the hoisted shares are batched: there the side stream's order must end with the
+    // message-passing modules' gradients (a trainer puts their all-reduce behind it while the encoder's backward still runs).
     WpBatch tailb;
     WpBatchGuard tail_guard;
     const bool defer_tail = g_wgrad_split && L > 0 && forked && !getenv("MPNHIP_NO_TAIL_DEFER");
     const bool defer_encoder = defer_tail && !(flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && m.enc_node.n_layers <= 3 && m.enc_edge.n_layers <= 3;
     if (defer_tail) wp_batch_begin(&tailb, p.slab_tail, p.slab_tail_floats, true);
-    // runs what was recorded (on the side stream, behind everything the caller's stream has enqueued so far) and closes the batch
-    // (round 4: on a SECOND side stream, beside the last group of steps -- their "+=" go to disjoint gradient columns; the step used to
-    // end with ~0.3 ms in which only the side stream worked: last group 0.78 ms, then this batch 0.19 ms.  The first side stream is
-    // ordered behind it, so what follows there -- the unpacking of the packed projection gradient, a trainer's collective -- sees both.)
-    // Where the tail batch runs.  With the encoder's products deferred to the end anyway (no MPNHIP_BWD_DEFER_SIDE_JOIN) it runs on the
+    // flush_tail runs what was recorded and closes the batch (its "+=" go to gradient columns disjoint from the groups': it may run
+    // beside the last group of steps).  Where it runs.  With the encoder's products deferred to the end anyway (no MPNHIP_BWD_DEFER_SIDE_JOIN) it runs on the
     // CALLER's stream itself, then the join, the unpacking and whatever the caller enqueues next: no hop ahead of the batch (event
     // record -> wait: 10 - 18 us each) and one instead of two behind it.  Same-box A-B, three runs each, second side stream / caller's
     // stream / first side stream: cfg-B 4.94 - 5.00 / 4.90 - 4.93 / 4.92 - 4.97 ms, cfg-C 1.76 - 1.78 / 1.72 - 1.74 / 1.80 - 1.82, cfg-E 33.5 - 33.6 /
     // 33.6 / 34.0, cfg-D 0.494 / 0.444 / 0.470 -- the second stream was round 4's answer to a tail of ~0.3 ms behind the last group; with
     // the launches' blocks dispatched longest first it no longer pays.  A trainer's path (MPNHIP_BWD_DEFER_SIDE_JOIN: the hoisted
     // shares' products run early, the message-passing gradients' collective follows on the first side stream) keeps the second stream
-    // on large graphs.  MPNHIP_TAIL_STREAM2=1 / MPNHIP_NO_TAIL_STREAM2=1 force either, MPNHIP_NO_TAIL_INLINE=1 keeps the batch off the
-    // caller's stream.
+    // on large graphs -- the first side stream is ordered behind it, so the unpacking and the collective that follow there see both.
+    // MPNHIP_TAIL_STREAM2=1 / MPNHIP_NO_TAIL_STREAM2=1 force either, MPNHIP_NO_TAIL_INLINE=1 keeps the batch off the caller's stream.
     const bool tail_beside = !getenv("MPNHIP_NO_TAIL_STREAM2") &&
                              (getenv("MPNHIP_TAIL_STREAM2") || ((flags & MPNHIP_BWD_DEFER_SIDE_JOIN) && (double)E * dn >= 1e6));
     const bool tail_inline = defer_encoder && !tail_beside && !getenv("MPNHIP_NO_TAIL_INLINE");
