@@ -995,10 +995,7 @@ int wp_batch_flush(hipStream_t s) {
             cols += rows * ((double)J.n_out * J.tiles_c + (double)J.k_in * J.tiles_o);
             extra += rows * ((double)J.n_out * tc + (double)J.k_in * to) - rows * ((double)J.n_out * J.tiles_c + (double)J.k_in * J.tiles_o);
         }
-        // (... or at most 32 MB more in absolute terms: the tail batch of a 32-d model holds the node encoder's [128 x 2048] over a few
-        // hundred rows -- 64 tiles of 64 x 64, 3.8 x its columns, 12 MB)
-        static const bool abs_ok = !getenv("MPNHIP_WP_NARROW_NO_ABS");
-        if (narrow && extra > 0.15 * cols && !(abs_ok && extra * 4.0 <= 32e6)) narrow = false;
+        if (narrow && extra > 0.15 * cols) narrow = false;
         if (narrow) {
             for (int i = 0; i < b->tab.njobs; ++i) {
                 WpJob& J = b->tab.job[i];
