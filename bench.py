@@ -9,7 +9,9 @@ steps, fp32).  Each rank owns one graph (graphs shard by sequence; weak scaling)
 sum_ranks(E) * K / max_rank(time).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd|train] [--config B] [--agg sum]
-N>1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+N>1: either the driver's launcher form  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or plain  python bench.py --gpus N ...  -- with no WORLD_SIZE in the env the
+parent starts the N ranks itself as fresh child processes (spawn_ranks) before it touches the GPU, and rank 0 prints the ONE line.
 """
 import argparse
 import ctypes
@@ -235,7 +237,7 @@ def measure_case(cfg_name, mode, precision, steps, warmup, dev, agg="sum", seed=
         torch.cuda.empty_cache()
 
 
-def extras(dev, budget_s=60.0):
+def extras(dev, budget_s=90.0):
     """Short labelled measurements of the other BASELINE.json configurations: configs[4] (cfg-E, bf16-operand
     forward, plus its aggregation kernel as a separate launch -- the HBM-streaming figure), the configs[2] / configs[3] stand-ins
     (cfg-C / cfg-D training step, cfg-D forward).  Each is its own model and graph; a failure or the time budget drops the rest."""
@@ -246,17 +248,25 @@ def extras(dev, budget_s=60.0):
             ("cfgC_fwd", ("C", "fwd", "auto", 60, 10), None),
             ("cfgE_bf16_fwd", ("E", "fwd", "bf16", 5, 2), None),
             ("cfgE_bf16_train", ("E", "train", "bf16", 5, 1), None),   # (5 steps = 15 weight-gradient launches: every 5th samples each of the three sizes once)
-            ("cfgE_bf16_fwd_unfused_aggregation", ("E", "fwd", "bf16", 3, 1), {"MPNHIP_NO_AGG_FUSION": "1"})]
+            ("cfgE_bf16_fwd_unfused_aggregation", ("E", "fwd", "bf16", 3, 1), {"MPNHIP_NO_AGG_FUSION": "1"}),
+            # node_agg_fn = mean / max (north_star: "scatter-mean/max neighbour aggregation"; reference models/mpn.py:266-273 selects the
+            # lambda by config) on the headline workload, beside the shipped default `sum` the headline itself runs
+            ("cfgB_train_mean", ("B", "train", "auto", 12, 4), {"__agg": "mean"}),
+            ("cfgB_train_max", ("B", "train", "auto", 12, 4), {"__agg": "max"}),
+            ("cfgB_fwd_mean", ("B", "fwd", "auto", 20, 5), {"__agg": "mean"}),
+            ("cfgB_fwd_max", ("B", "fwd", "auto", 20, 5), {"__agg": "max"})]
     res, t_start, cache = {}, time.time(), {}
     for name, (cfg, mode, prec, steps, warm), env in plan:
         if time.time() - t_start > budget_s:
             res[name] = {"skipped": "time budget of the extra measurements (%.0f s) used up" % budget_s}
             continue
         try:
-            nb = 1
+            nb, agg = 1, "sum"
             if env and "__n_batch" in env:
                 nb, env = int(env["__n_batch"]), None
-            res[name] = measure_case(cfg, mode, prec, steps, warm, dev, env=env, n_batch=nb)
+            if env and "__agg" in env:
+                agg, env = env["__agg"], None
+            res[name] = measure_case(cfg, mode, prec, steps, warm, dev, agg=agg, env=env, n_batch=nb)
             if nb > 1 and "cfgD_train" in res and "value" in res["cfgD_train"]:
                 res[name]["edges_per_ms_over_one_graph_per_step"] = res[name]["value"] / res["cfgD_train"]["value"]
             if env:
@@ -269,11 +279,56 @@ def extras(dev, budget_s=60.0):
     return res
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes of this one (never by replacing it;
+    the parent makes no HIP call -- torch.cuda.device_count() does not initialise the device), each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in its env: the same shape torch.distributed.run gives them
+    (reference: Trainer(gpus=1, accumulate_grad_batches=8), scripts/train.py:65-77 -- eight graphs per optimizer step, here in space).
+    Rank 0's stdout (the ONE JSON line) is this process's stdout.  A rank that fails takes the others down; exit code = the worst."""
+    import socket
+    import subprocess
+    n = int(args.gpus)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and n > ndev:
+        raise SystemExit("bench.py --gpus %d --backend nccl: only %d HIP device(s) visible; RCCL needs one GPU per rank "
+                         "(--backend gloo shares devices: a functional run, not a scaling number)" % (n, ndev))
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:      # (exact PIDs of the children started above)
+                    q.terminate()
+    sys.exit(worst if 0 <= worst < 256 else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks on backend nccl with %d HIP device(s) visible -- one GPU per rank, or --backend gloo"
+                         % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
     if args.backend == "gloo":

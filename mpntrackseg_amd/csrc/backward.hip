@@ -614,7 +614,8 @@ static int act_grad(int ngroups, const float* A, int64_t lda, const int* a_idx, 
             if (kp) wt = kp->wt;
             if (!kp || !kp->valid) MPN_TRY(transpose_padded(W[q], ldw, 0, K, N, wt, K, N, s));
             // the kept blocks also as bf16 rows (rounded once per backward instead of in every block of every step's product)
-            const bool img16 = kp && kp->wt16 && K % 8 == 0 && ((size_t)K * N) % 4 == 0 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
+            // (N % 4: launch_gemm's bf16-row path needs whole 16-byte result vectors; otherwise the fp32 image on the register-staged path)
+            const bool img16 = kp && kp->wt16 && K % 8 == 0 && N % 4 == 0 && ((size_t)K * N) % 4 == 0 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
             if (img16 && !kp->valid) MPN_TRY(to_bf16_rows(wt, kp->wt16, (int64_t)K * N, s));
             if (kp) kp->valid = true;   // (one stream: the later steps' products are ordered behind this transposition)
             g.B = img16 ? reinterpret_cast<const float*>(kp->wt16) : wt;
@@ -969,9 +970,8 @@ extern "C" int mpnhip_backward_flags(const mpnhip_model* model, const void* grap
     const bool hoist_e0 = use_b16 || (use_chain && d.ef == 2 && L > 1 && pad32(de) == 64 && he % 4 == 0 && de % 4 == 0 && !getenv("MPNHIP_NO_DE0_HOIST"));
     // bf16-operand training: the per-node projections' weight gradient over bf16 ROWS -- dP_s rounded once by the scatter-add kernel that
     // produces it, x_{s-1} from the forward's bf16 mirror -- on the LDS-DMA kernel in 256 x 256 output tiles (wgrad_rows16.hip)
-    // (f.xb_hist is filled under the forward's own run-time test, mpn.hip `rows16`: repeated here)
-    const bool node16 = use_b16 && hoist_x && p.dP16 && f.Wnode16 && f.xb_hist && ((size_t)pw * kx) % 4 == 0 &&
-                        (((uintptr_t)m.node.weight[0]) & 15) == 0 && !getenv("MPNHIP_NO_NODE_ROWS16");
+    // (f.xb_hist is filled under the forward's own run-time test: plan.h node_rows16_runtime, the one definition both sides use)
+    const bool node16 = use_b16 && hoist_x && p.dP16 && node_rows16_runtime(f, m, d) && !getenv("MPNHIP_NO_NODE_ROWS16");
     // bf16 rows: pointer `elems` unsigned shorts into a buffer the plans type as float*
     auto u16 = [](const float* p0, int64_t elems) { return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p0) + elems); };
     // Weight gradients of the message-passing modules for steps b0+1 .. b0+nb: ONE batched split-row product per

@@ -257,6 +257,7 @@ struct NodeChainArgs {
     float* P_next;                  // [N, pw] or nullptr (last step)
     float* x_new;                   // [N, dn]
     float* agg_out;                 // [N, 2 dn] or nullptr
+    int debug;                      // ablation bits, read only by a build with -DMPNHIP_NODE_FWD_DEBUG (tools/node_chain_ablate.sh)
 };
 bool node_chain_supported(int dn, int pw, int kx);
 size_t node_chain_image_shorts(int dn, int pw, size_t* off_wx);

@@ -734,7 +734,7 @@ extern "C" int mpnhip_forward(const mpnhip_model* model, const void* graph_buf, 
         }
     }
     // bf16 rows for the node-side products of this call (weights at the head of the workspace: kept with the other images)
-    const bool rows16 = p.Wnode16 && p.xb_hist && ((size_t)d.pw * d.kx) % 4 == 0 && (((uintptr_t)m.node.weight[0]) & 15) == 0;
+    const bool rows16 = node_rows16_runtime(p, m, d);   // (plan.h: the backward applies the same test)
     // encoder (MLPGraphIndependent, mpn.py:355 -> :164-178); the edge encoder reads edge_attr through
     // the sort permutation so that every per-edge tensor downstream lives in sorted order
     float* hid[MPNHIP_MAX_LAYERS];

@@ -50,15 +50,18 @@ __device__ __forceinline__ void ld_units(const unsigned short* img, int unit0, i
     for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x8, p[q * 64]);
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
-    constexpr int DN = 32 * DT, K2 = 2 * DN, KB2 = K2 / 16, KB1 = DN / 16;
+// NWV waves per block (round 6: 8 -- two per SIMD; 4 was round 3's form): phases A and C are latency chains over a block's own rows
+// (ablation, profiles/r06/node_chain_ablation_before.txt: of 35 us at cfg-B, aggregation 10, node update 5.4, projections 19.6 of which
+// the MFMAs are 1.2), so more waves = more rows / tiles in flight per CU; 157 blocks leave 99 of the 256 CUs idle either way.
+template <int DT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
+    constexpr int DN = 32 * DT, K2 = 2 * DN, KB2 = K2 / 16, KB1 = DN / 16, NTHR = 64 * NWV;
     constexpr int AP = K2 + 4, XP = DN + 4;      // LDS row pitches (floats): a lane's 16-byte pieces of 16 rows cover the banks once
     constexpr int RD = 4;                        // k blocks of weight units in flight (phase B)
-    constexpr int RC = KB1;                      // ... phase C: a whole output tile ahead (L2 latency under 157 blocks' streams ~ 1 us)
     static_assert(KB2 % RD == 0, "ring depth");
     __shared__ __attribute__((aligned(16))) float agg_s[32 * AP];
     __shared__ __attribute__((aligned(16))) float x_s[32 * XP];
+    __shared__ __attribute__((aligned(16))) float part_s[(NWV / DT > 1 ? NWV / DT - 1 : 1) * DT * 4 * 64 * 4];   // [k share - 1][tile][g][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * 32;
@@ -69,8 +72,10 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
     // row); two rows in flight per lane, added in segment order.  (One round: the offsets -> rows latency chain is paid once,
     // not once per round of a few wide workers.)
     {
-        constexpr int PC = DN / 16;              // 16-byte pieces per lane and row
-        const int sgm = tid >> 2, c0 = (tid & 3) * (DN / 4);
+        constexpr int LPS = NWV;                 // lanes per (node, direction) segment: 64 segments over 64 NWV threads
+        constexpr int PC = DN / LPS / 4;         // 16-byte pieces per lane and row (a segment's lanes read one row's consecutive pieces)
+        static_assert(DN % (4 * LPS) == 0 && PC >= 1, "row pieces");
+        const int sgm = tid / LPS, c0 = (tid % LPS) * (DN / LPS);
         const int nl = sgm >> 1, q = sgm & 1;    // q = 0: flow_out (keys [0, N)), 1: flow_in ([N, 2N))
         const int node = n0 + nl;
         float4 acc[PC];
@@ -80,11 +85,28 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
             const int key = q * N + node;
             const int b = A.seg_ptr[key], e = A.seg_ptr[key + 1];
             const float* src = A.M + c0;
+#ifdef MPNHIP_NODE_FWD_DEBUG
+            if (A.debug & 1) { if (e < b) acc[0].x = 1.f; } else
+#endif
             if (A.agg == MPNHIP_AGG_MAX) {
                 if (e > b) {
 #pragma unroll
                     for (int u = 0; u < PC; ++u) acc[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    for (int j = b; j < e; ++j) {
+                    int j = b;
+                    for (; j + 2 <= e; j += 2) {
+                        float4 v0[PC], v1[PC];
+#pragma unroll
+                        for (int u = 0; u < PC; ++u) {
+                            v0[u] = *reinterpret_cast<const float4*>(src + (int64_t)j * DN + 4 * u);
+                            v1[u] = *reinterpret_cast<const float4*>(src + (int64_t)(j + 1) * DN + 4 * u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < PC; ++u) {
+                            acc[u].x = fmaxf(fmaxf(acc[u].x, v0[u].x), v1[u].x); acc[u].y = fmaxf(fmaxf(acc[u].y, v0[u].y), v1[u].y);
+                            acc[u].z = fmaxf(fmaxf(acc[u].z, v0[u].z), v1[u].z); acc[u].w = fmaxf(fmaxf(acc[u].w, v0[u].w), v1[u].w);
+                        }
+                    }
+                    if (j < e) {
 #pragma unroll
                         for (int u = 0; u < PC; ++u) {
                             const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * DN + 4 * u);
@@ -93,8 +115,20 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
                     }
                 }                                 // empty segment -> 0 (torch_scatter fills with 0)
             } else {
+                // up to four rows in flight per lane, added in segment order (ascending sorted edge position: the reference's CPU order)
                 int j = b;
-                for (; j + 2 <= e; j += 2) {
+                for (; j + 4 <= e; j += 4) {
+                    float4 v[4][PC];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int u = 0; u < PC; ++u) v[r][u] = *reinterpret_cast<const float4*>(src + (int64_t)(j + r) * DN + 4 * u);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int u = 0; u < PC; ++u) { acc[u].x += v[r][u].x; acc[u].y += v[r][u].y; acc[u].z += v[r][u].z; acc[u].w += v[r][u].w; }
+                }
+                if (j + 2 <= e) {
                     float4 v0[PC], v1[PC];
 #pragma unroll
                     for (int u = 0; u < PC; ++u) {
@@ -106,6 +140,7 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
                         acc[u].x += v0[u].x; acc[u].y += v0[u].y; acc[u].z += v0[u].z; acc[u].w += v0[u].w;
                         acc[u].x += v1[u].x; acc[u].y += v1[u].y; acc[u].z += v1[u].z; acc[u].w += v1[u].w;
                     }
+                    j += 2;
                 }
                 if (j < e) {
 #pragma unroll
@@ -127,78 +162,121 @@ __global__ __launch_bounds__(256) void node_chain_kernel(NodeChainArgs A) {
     }
     __syncthreads();
     if (A.agg_out) {   // kept for the backward pass
-        for (int i = tid; i < 32 * (K2 / 4); i += 256) {
+        for (int i = tid; i < 32 * (K2 / 4); i += NTHR) {
             const int nl = i / (K2 / 4), c = (i - nl * (K2 / 4)) * 4;
             if (n0 + nl < N) *reinterpret_cast<float4*>(A.agg_out + (int64_t)(n0 + nl) * K2 + c) = *reinterpret_cast<const float4*>(&agg_s[nl * AP + c]);
         }
     }
 
-    // ---- B. x' = relu(Wu AGG + bu): output tile `wave` ----------------------------------------------------------------------
-    if (wave < DT) {
+#ifdef MPNHIP_NODE_FWD_DEBUG
+    if (A.debug & 2) return;
+#endif
+    // ---- C's first loads: issued BEFORE phase B (they depend on nothing computed here) -- the waves beyond the DT that compute the
+    // node update would otherwise sit at the barrier with nothing in flight ------------------------------------------------------------
+    const int NT = A.pw / 32;
+    const int node = n0 + lj < N ? n0 + lj : N - 1;
+    const bool ok = n0 + lj < N;
+    const float* p0r = A.P0 + (int64_t)node * A.pw + 4 * lh;
+    float* pnr = A.P_next + (int64_t)node * A.pw + 4 * lh;
+    // this wave's tiles: wave, wave + NWV, ...; every block walks them from a different starting tile (all blocks stream the same
+    // 1 MB image: started together on the same units they queue on the same L2 channels)
+    const bool has_c = A.P_next != nullptr && wave < NT;
+    const int cnt = has_c ? (NT - wave + NWV - 1) / NWV : 1;
+    int ii = (int)((blockIdx.x * 5u) % (unsigned)cnt);
+    int t = has_c ? wave + NWV * ii : 0;
+    constexpr int RC = KB1;                      // a whole output tile of weight units ahead (L2 latency under 157 blocks' streams ~ 1 us)
+    bf16x8 ringc[RC][3];
+    float4 cin[4];
+    if (has_c) {
+#pragma unroll
+        for (int s = 0; s < RC; ++s) ld_units(A.wx_img, (t * KB1 + s) * 3, lane, ringc[s]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * t + 8 * g);
+    }
+
+    // ---- B. x' = relu(Wu AGG + bu): tile (wave % DT), the contraction split over the NWV / DT waves that share a tile; the partial
+    // tiles of the upper shares meet the first share's in LDS (fixed order: reproducible) -----------------------------------------------
+    {
+        constexpr int KS = NWV / DT, KPW = KB2 / KS, RB = KPW < RD ? KPW : RD;
+        static_assert(NWV % DT == 0 && KB2 % KS == 0 && KPW % RB == 0, "k shares");
+        const int tb = wave % DT, ks = wave / DT, kb0 = ks * KPW;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        bf16x8 ring[RD][3];
+        bf16x8 ring[RB][3];
 #pragma unroll
-        for (int s = 0; s < RD; ++s) ld_units(A.wu_img, (wave * KB2 + s) * 3, lane, ring[s]);
+        for (int s = 0; s < RB; ++s) ld_units(A.wu_img, (tb * KB2 + kb0 + s) * 3, lane, ring[s]);
 #pragma unroll
-        for (int kb = 0; kb < KB2; ++kb) {
-            const float* xr = &agg_s[lj * AP + 16 * kb + 8 * lh];
+        for (int k = 0; k < KPW; ++k) {
+            const float* xr = &agg_s[lj * AP + 16 * (kb0 + k) + 8 * lh];
             const NSplit8 b = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
-            nmfma6(acc, ring[kb % RD], b);
-            if (kb + RD < KB2) ld_units(A.wu_img, (wave * KB2 + kb + RD) * 3, lane, ring[kb % RD]);
+            nmfma6(acc, ring[k % RB], b);
+            if (k + RB < KPW) ld_units(A.wu_img, (tb * KB2 + kb0 + k + RB) * 3, lane, ring[k % RB]);
         }
-        const bool ok = n0 + lj < N;
+        if (KS > 1) {
+            if (ks > 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = 32 * wave + 8 * g + 4 * lh;
-            const float4 bias = *reinterpret_cast<const float4*>(A.bu + n);
-            const float4 v = make_float4(fmaxf(acc[4 * g + 0] + bias.x, 0.f), fmaxf(acc[4 * g + 1] + bias.y, 0.f),
-                                         fmaxf(acc[4 * g + 2] + bias.z, 0.f), fmaxf(acc[4 * g + 3] + bias.w, 0.f));
-            *reinterpret_cast<float4*>(&x_s[lj * XP + n]) = v;
-            if (ok) *reinterpret_cast<float4*>(A.x_new + (int64_t)(n0 + lj) * DN + n) = v;
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(&part_s[((((ks - 1) * DT + tb) * 4 + g) * 64 + lane) * 4]) =
+                        make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            }
+            __syncthreads();
+        }
+        if (ks == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 a4 = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+#pragma unroll
+                for (int q = 1; q < KS; ++q) {
+                    const float4 u = *reinterpret_cast<const float4*>(&part_s[((((q - 1) * DT + tb) * 4 + g) * 64 + lane) * 4]);
+                    a4.x += u.x; a4.y += u.y; a4.z += u.z; a4.w += u.w;
+                }
+                const int n = 32 * tb + 8 * g + 4 * lh;
+                const float4 bias = *reinterpret_cast<const float4*>(A.bu + n);
+                const float4 v = make_float4(fmaxf(a4.x + bias.x, 0.f), fmaxf(a4.y + bias.y, 0.f), fmaxf(a4.z + bias.z, 0.f), fmaxf(a4.w + bias.w, 0.f));
+                *reinterpret_cast<float4*>(&x_s[lj * XP + n]) = v;
+                if (ok) *reinterpret_cast<float4*>(A.x_new + (int64_t)(n0 + lj) * DN + n) = v;
+            }
         }
     }
     __syncthreads();
-    if (!A.P_next) return;   // last step: no projections needed
+    if (!has_c) return;      // last step (no projections needed), or more waves than tiles
+#ifdef MPNHIP_NODE_FWD_DEBUG
+    if (A.debug & 4) return;
+#endif
 
-    // ---- C. P' = P0 + Wx x': tiles wave, wave + 4, ... -----------------------------------------------------------------------
+    // ---- C. P' = P0 + Wx x': tiles wave, wave + NWV, ... ----------------------------------------------------------------------
     NSplit8 bx[KB1];
 #pragma unroll
     for (int kb = 0; kb < KB1; ++kb) {
         const float* xr = &x_s[lj * XP + 16 * kb + 8 * lh];
         bx[kb] = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
     }
-    const int NT = A.pw / 32;
-    const int node = n0 + lj < N ? n0 + lj : N - 1;
-    const bool ok = n0 + lj < N;
-    const float* p0r = A.P0 + (int64_t)node * A.pw + 4 * lh;
-    float* pnr = A.P_next + (int64_t)node * A.pw + 4 * lh;
-    if (wave >= NT) return;
-    // this wave's tiles: wave, wave + 4, ...; every block walks them from a different starting tile (all blocks stream the same
-    // 1 MB image: started together on the same units they queue on the same L2 channels)
-    const int cnt = (NT - wave + 3) / 4;
-    int ii = (int)((blockIdx.x * 5u) % (unsigned)cnt);
-    int t = wave + 4 * ii;
-    bf16x8 ring[RC][3];
-#pragma unroll
-    for (int s = 0; s < RC; ++s) ld_units(A.wx_img, (t * KB1 + s) * 3, lane, ring[s]);
-    float4 cin[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * t + 8 * g);
     for (int it = 0; it < cnt; ++it) {
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = cin[g].x; acc[4 * g + 1] = cin[g].y; acc[4 * g + 2] = cin[g].z; acc[4 * g + 3] = cin[g].w; }
         ii = ii + 1 < cnt ? ii + 1 : 0;
-        const int tn = wave + 4 * ii;            // (after the last tile: the first one again -- unconditional loads)
+        const int tn = wave + NWV * ii;          // (after the last tile: the first one again -- unconditional loads)
 #pragma unroll
         for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * tn + 8 * g);
 #pragma unroll
         for (int kb = 0; kb < KB1; ++kb) {
-            nmfma6(acc, ring[kb], bx[kb]);
-            ld_units(A.wx_img, (tn * KB1 + kb) * 3, lane, ring[kb]);
+#ifdef MPNHIP_NODE_FWD_DEBUG
+            if (A.debug & 8) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) asm volatile("" ::"v"(ringc[kb][u]), "v"(bx[kb].p[u]));
+            } else
+#endif
+            nmfma6(acc, ringc[kb], bx[kb]);
+#ifdef MPNHIP_NODE_FWD_DEBUG
+            if (!(A.debug & 16))
+#endif
+            ld_units(A.wx_img, (tn * KB1 + kb) * 3, lane, ringc[kb]);
         }
+#ifdef MPNHIP_NODE_FWD_DEBUG
+        if (A.debug & 32) { t = tn; continue; }
+#endif
         if (ok) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -412,12 +490,22 @@ int pack_node_chain(const float* Wu, const float* Wnode, int dn, int pw, int kx,
     return MPNHIP_OK;
 }
 
-int launch_node_chain(const NodeChainArgs& a, hipStream_t s) {
-    if (a.N <= 0) return MPNHIP_OK;
+int launch_node_chain(const NodeChainArgs& a_in, hipStream_t s) {
+    if (a_in.N <= 0) return MPNHIP_OK;
     count_path(PC_NODE_CHAIN);
+#ifdef MPNHIP_NODE_FWD_DEBUG
+    NodeChainArgs a = a_in;
+    a.debug = getenv("MPNHIP_NODE_FWD_DEBUG") ? atoi(getenv("MPNHIP_NODE_FWD_DEBUG")) : 0;
+#else
+    const NodeChainArgs& a = a_in;
+#endif
     const unsigned blocks = (unsigned)((a.N + 31) / 32);
-    if (a.dn == 128) hipLaunchKernelGGL(node_chain_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
-    else if (a.dn == 64) hipLaunchKernelGGL(node_chain_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    // (MPNHIP_NODE_CHAIN_WAVES=4: round 3's four-wave blocks, A-B)
+    static const int nwv = getenv("MPNHIP_NODE_CHAIN_WAVES") ? atoi(getenv("MPNHIP_NODE_CHAIN_WAVES")) : 8;
+    if (a.dn == 128 && nwv == 4) hipLaunchKernelGGL((node_chain_kernel<4, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.dn == 128) hipLaunchKernelGGL((node_chain_kernel<4, 8>), dim3(blocks), dim3(512), 0, s, a);
+    else if (a.dn == 64 && nwv == 4) hipLaunchKernelGGL((node_chain_kernel<2, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.dn == 64) hipLaunchKernelGGL((node_chain_kernel<2, 8>), dim3(blocks), dim3(512), 0, s, a);
     else { set_error("node_chain: unsupported width %d", a.dn); return MPNHIP_ERR_UNSUPPORTED; }
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;

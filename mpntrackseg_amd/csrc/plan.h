@@ -207,6 +207,16 @@ static inline StepBufs step_at(const FwdPlan& p, int s) {
     return b;
 }
 
+// ONE definition, for the forward (mpn.hip) and the backward (backward.hip), of "the node side of this call runs over bf16 rows": the
+// plan carved the images (dims + environment: `rows16` in plan_forward) AND the run-time alignments launch_gemm's bf16-row path insists
+// on hold (16-byte weight / bias bases, whole 16-byte result vectors).  The forward fills xb_hist only under this test; the backward
+// reads it only under the same one.
+static inline bool node_rows16_runtime(const FwdPlan& p, const mpnhip_model& m, const Dims& d) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return p.Wnode16 && p.xb_hist && ((size_t)d.pw * d.kx) % 4 == 0 && d.pw % 4 == 0 && d.dn % 4 == 0 &&
+           al(m.node.weight[0]) && (!m.node.bias[0] || al(m.node.bias[0]));
+}
+
 static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t N, int64_t E, int save, void* base, FwdPlan* out) {
     Arena a = {static_cast<char*>(base), 0};
     FwdPlan p = {};
@@ -241,7 +251,8 @@ static inline size_t plan_forward(const mpnhip_model& m, const Dims& d, int64_t 
     if (node_chain_supported(d.dn, d.pw, d.kx) && m.node.n_layers == 1)
         p.nc_img = reinterpret_cast<unsigned short*>(a.f((node_chain_image_shorts(d.dn, d.pw, nullptr) + 1) / 2));
     // (bf16 rows for the tiled / ring GEMM kernels: 16-byte pieces of 8 elements)
-    const bool rows16 = m.precision == MPNHIP_PREC_BF16 && d.kx % 8 == 0 && d.dn % 8 == 0 && m.node.n_layers == 1 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
+    // (d.pw % 4: launch_gemm's bf16-row path stores 16-byte result vectors -- N = pw of the projections, N = dn of the node update)
+    const bool rows16 = m.precision == MPNHIP_PREC_BF16 && d.kx % 8 == 0 && d.dn % 8 == 0 && d.pw % 4 == 0 && m.node.n_layers == 1 && !getenv("MPNHIP_NO_GEMM_BF16_ROWS");
     p.Wnode16 = rows16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)d.pw * d.kx + 1) / 2)) : nullptr;
     p.Wu16 = rows16 ? reinterpret_cast<unsigned short*>(a.f(((size_t)d.dn * 2 * d.dn + 1) / 2)) : nullptr;
     p.P0 = a.f((size_t)N * d.pw);

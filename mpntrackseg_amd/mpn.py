@@ -20,15 +20,18 @@ from .mlp import MLP
 def _prepared(edge_index, n_nodes, holder=None, full=True):
     """Graph prep (``mpnhip_graph_prep``) cached on the object that owns edge_index (the reference's
     ``Graph`` sample), validated by tensor identity and version counter.  ``full=False`` (inference forward) accepts
-    or builds a prep with the primary order only; a cached forward-only prep is replaced when a full one is asked for."""
+    or builds a prep with the primary order only; a cached forward-only prep is replaced when a full one is asked for.
+    The cache attribute is a dunder name on purpose: torch_geometric's ``Data.keys`` (what ``.to()``, ``Batch.from_data_list`` and the
+    reference's ``Graph._change_attrs_types`` walk, data/mot_graph.py:27-52) skips ``__x__`` names, so the sample's own protocol never
+    sees it."""
     if holder is not None:
-        c = getattr(holder, "_mpnhip_prep", None)
+        c = getattr(holder, "__mpnhip_prep__", None)
         if c is not None and c[0] is edge_index and c[1] == edge_index._version and c[2].N == n_nodes and (c[2].full or not full):
             return c[2]
     g = capi.PreparedGraph(edge_index, n_nodes, full=full)
     if holder is not None:
         try:
-            object.__setattr__(holder, "_mpnhip_prep", (edge_index, edge_index._version, g))
+            object.__setattr__(holder, "__mpnhip_prep__", (edge_index, edge_index._version, g))
         except Exception:
             pass
     return g

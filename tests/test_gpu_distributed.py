@@ -101,3 +101,18 @@ def test_bench_eight_ranks_on_one_gpu_reports_the_sum_of_the_ranks_edges():
     assert d["config"]["edges_all_ranks"] == sum(per_rank)
     assert abs(d["value"] - sum(per_rank) / d["ms_per_step"]) <= 1e-6 * d["value"], (d["value"], per_rank, d["ms_per_step"])
     assert d["scaling"] == "weak" and d["allreduce_ms"] > 0
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the env -- the parent starts the two
+    ranks as child processes (bench.spawn_ranks) and rank 0 prints the one line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--config", "D", "--steps", "3", "--warmup", "2"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["config"]["edges_per_rank"]) == 2 and d["scaling"] == "weak" and d["value"] > 0, d
+    assert d["allreduce_ms"] > 0 and d["bus_gbs"] > 0 and d["config"]["mode"] == "train", d
+

@@ -176,3 +176,14 @@ def test_frame_embedding_files_have_the_reference_layout(tmp_path):
     assert tuple(a.shape) == (2, 5) and a[:, 0].tolist() == [10.0, 11.0] and a[1, 1:].tolist() == [4.0, 5.0, 6.0, 7.0]
     b = torch.load(str(tmp_path / "processed_data" / "node" / "9.pt"))
     assert tuple(b.shape) == (1, 3, 2, 2) and bool((b[:, 0] == 12).all()) and bool((b[:, 1:] == 1).all())
+
+
+def test_bench_gpus_flag_refuses_more_rccl_ranks_than_devices():
+    """--backend nccl with more ranks than visible devices exits non-zero instead of silently sharing a device."""
+    import os, subprocess, sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = max(2, torch.cuda.device_count() + 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--config", "D", "--steps", "2", "--warmup", "1"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one GPU per rank" in (r.stderr + r.stdout), r.stdout[-1000:] + r.stderr[-1000:]
