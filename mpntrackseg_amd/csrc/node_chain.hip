@@ -56,18 +56,28 @@ __device__ __forceinline__ void ld_units(const unsigned short* img, int unit0, i
 template <int DT, int NWV>
 __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
     constexpr int DN = 32 * DT, K2 = 2 * DN, KB2 = K2 / 16, KB1 = DN / 16, NTHR = 64 * NWV;
-    constexpr int AP = K2 + 4, XP = DN + 4;      // LDS row pitches (floats): a lane's 16-byte pieces of 16 rows cover the banks once
+    constexpr int XP = DN + 4;                   // LDS row pitch (floats) of the x' tile
     constexpr int RD = 4;                        // k blocks of weight units in flight (phase B)
     static_assert(KB2 % RD == 0, "ring depth");
-    __shared__ __attribute__((aligned(16))) float agg_s[32 * AP];
-    __shared__ __attribute__((aligned(16))) float x_s[32 * XP];
-    __shared__ __attribute__((aligned(16))) float part_s[(NWV / DT > 1 ? NWV / DT - 1 : 1) * DT * 4 * 64 * 4];   // [k share - 1][tile][g][lane][4]
+    // one LDS block: [asp | part_s | x_s | xsp].  asp / xsp: the aggregate tile / the x' tile as three bf16 pieces in MFMA B-operand
+    // order -- 16-byte units [piece][k block][lane (node lj, k half lh)], written once, read conflict free by every wave that multiplies.
+    // Phase C's per-wave [32][36] transposition patches re-use the asp | part_s region (dead behind the barrier that ends phase B).
+    constexpr int ASPN = 3 * KB2 * 64 * 4;
+    constexpr int PARTN = (NWV / DT > 1 ? NWV / DT - 1 : 0) * DT * 4 * 64 * 4;   // [k share - 1][tile][g][lane][4]
+    constexpr int PATCH = 32 * 36;
+    constexpr int HEADN = (ASPN + PARTN) > NWV * PATCH ? (ASPN + PARTN) : NWV * PATCH;
+    constexpr int XSPN = 3 * KB1 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) float smem[HEADN + 32 * XP + XSPN];
+    uint4* const asp = reinterpret_cast<uint4*>(smem);
+    float* const part_s = smem + ASPN;
+    float* const x_s = smem + HEADN;
+    uint4* const xsp = reinterpret_cast<uint4*>(smem + HEADN + 32 * XP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * 32;
     const int N = A.N;
 
-    // ---- A. aggregation into LDS ------------------------------------------------------------------------------------------
+    // ---- A. aggregation (into LDS as split B-operand units) ------------------------------------------------------------------------------------------
     // all 64 (node, direction) segments at once, 4 lanes each (a lane owns DN / 4 consecutive features = DN / 16 16-byte pieces of a
     // row); two rows in flight per lane, added in segment order.  (One round: the offsets -> rows latency chain is paid once,
     // not once per round of a few wide workers.)
@@ -156,17 +166,24 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
                 }
             }
         }
-        // torch.cat((flow_in, flow_out)) (mpn.py:97): flow_in on the left
+        // torch.cat((flow_in, flow_out)) (mpn.py:97): flow_in on the left.  The lane's DN / LPS consecutive features are whole 8-column
+        // halves of k blocks of node nl's row: split here, once, and left as B-operand units; the fp32 row (kept for the backward pass)
+        // leaves from the registers -- a segment's lanes cover consecutive pieces of one row
+        const int col0 = (q == 0 ? DN : 0) + c0;
+        static_assert(PC % 2 == 0, "whole 8-column halves per lane");
 #pragma unroll
-        for (int u = 0; u < PC; ++u) *reinterpret_cast<float4*>(&agg_s[nl * AP + (q == 0 ? DN : 0) + c0 + 4 * u]) = acc[u];
-    }
-    __syncthreads();
-    if (A.agg_out) {   // kept for the backward pass
-        for (int i = tid; i < 32 * (K2 / 4); i += NTHR) {
-            const int nl = i / (K2 / 4), c = (i - nl * (K2 / 4)) * 4;
-            if (n0 + nl < N) *reinterpret_cast<float4*>(A.agg_out + (int64_t)(n0 + nl) * K2 + c) = *reinterpret_cast<const float4*>(&agg_s[nl * AP + c]);
+        for (int h = 0; h < PC / 2; ++h) {
+            const int col = col0 + 8 * h;
+            const NSplit8 sp = nsplit8(acc[2 * h], acc[2 * h + 1]);
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) asp[(pz * KB2 + (col >> 4)) * 64 + nl + 32 * ((col >> 3) & 1)] = __builtin_bit_cast(uint4, sp.p[pz]);
+        }
+        if (A.agg_out && node < N) {
+#pragma unroll
+            for (int u = 0; u < PC; ++u) *reinterpret_cast<float4*>(A.agg_out + (int64_t)node * K2 + col0 + 4 * u) = acc[u];
         }
     }
+    __syncthreads();
 
 #ifdef MPNHIP_NODE_FWD_DEBUG
     if (A.debug & 2) return;
@@ -174,10 +191,6 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
     // ---- C's first loads: issued BEFORE phase B (they depend on nothing computed here) -- the waves beyond the DT that compute the
     // node update would otherwise sit at the barrier with nothing in flight ------------------------------------------------------------
     const int NT = A.pw / 32;
-    const int node = n0 + lj < N ? n0 + lj : N - 1;
-    const bool ok = n0 + lj < N;
-    const float* p0r = A.P0 + (int64_t)node * A.pw + 4 * lh;
-    float* pnr = A.P_next + (int64_t)node * A.pw + 4 * lh;
     // this wave's tiles: wave, wave + NWV, ...; every block walks them from a different starting tile (all blocks stream the same
     // 1 MB image: started together on the same units they queue on the same L2 channels)
     const bool has_c = A.P_next != nullptr && wave < NT;
@@ -186,12 +199,24 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
     int t = has_c ? wave + NWV * ii : 0;
     constexpr int RC = KB1;                      // a whole output tile of weight units ahead (L2 latency under 157 blocks' streams ~ 1 us)
     bf16x8 ringc[RC][3];
-    float4 cin[4];
+    // P0 rows in and P' rows out travel as WHOLE 128-byte lines: lane -> row (lane / 8 + 8 p), columns 4 (lane % 8) .. +3 of the tile --
+    // four instructions of eight full lines each.  In the accumulator layout (lane = node, 32 bytes per row and instruction) the same
+    // 4 KB are 128 partial-line accesses, and the launch is bound by exactly that count (profiles/r06/node_chain_ablation.txt: weight
+    // units 192 line accesses per tile / 5 us, P0 128 / 5 us, stores 128 / 5.5 us, additive).  The transposition between the two layouts
+    // goes through a per-wave LDS patch (LDS operations of one wave complete in order: no barrier).
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    // (named scalars, not arrays: hipcc left `float4 pr[4]` in scratch memory -- or, at 8 waves, promoted it to 32 KB of LDS)
+#define NC_ROWS4(X) X(0) X(1) X(2) X(3)
+#define NC_DECL(P) float4 pr##P = make_float4(0.f, 0.f, 0.f, 0.f); const bool rok##P = n0 + er + 8 * P < N; \
+                   const int64_t rowoff##P = (int64_t)(rok##P ? n0 + er + 8 * P : N - 1) * A.pw + ec;
+    NC_ROWS4(NC_DECL)
+#undef NC_DECL
     if (has_c) {
 #pragma unroll
         for (int s = 0; s < RC; ++s) ld_units(A.wx_img, (t * KB1 + s) * 3, lane, ringc[s]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * t + 8 * g);
+#define NC_LOAD(P) pr##P = *reinterpret_cast<const float4*>(A.P0 + rowoff##P + 32 * t);
+        NC_ROWS4(NC_LOAD)
+#undef NC_LOAD
     }
 
     // ---- B. x' = relu(Wu AGG + bu): tile (wave % DT), the contraction split over the NWV / DT waves that share a tile; the partial
@@ -206,12 +231,26 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
         bf16x8 ring[RB][3];
 #pragma unroll
         for (int s = 0; s < RB; ++s) ld_units(A.wu_img, (tb * KB2 + kb0 + s) * 3, lane, ring[s]);
+        float4 bias4[4];     // (requested here, not behind the products: an L2 round trip off the block's critical path)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const float4*>(A.bu + 32 * tb + 8 * g + 4 * lh);
+        NSplit8 bq[2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[0].p[q] = __builtin_bit_cast(bf16x8, asp[(q * KB2 + kb0) * 64 + lane]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KPW; ++k) {
-            const float* xr = &agg_s[lj * AP + 16 * (kb0 + k) + 8 * lh];
-            const NSplit8 b = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
-            nmfma6(acc, ring[k % RB], b);
-            if (k + RB < KPW) ld_units(A.wu_img, (tb * KB2 + kb0 + k + RB) * 3, lane, ring[k % RB]);
+            if (k + 1 < KPW) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bq[(k + 1) & 1].p[q] = __builtin_bit_cast(bf16x8, asp[(q * KB2 + kb0 + k + 1) * 64 + lane]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            nmfma6(acc, ring[k % RB], bq[k & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + RB < KPW) {
+                ld_units(A.wu_img, (tb * KB2 + kb0 + k + RB) * 3, lane, ring[k % RB]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (KS > 1) {
             if (ks > 0) {
@@ -232,58 +271,97 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_kernel(NodeChainArgs A) {
                     a4.x += u.x; a4.y += u.y; a4.z += u.z; a4.w += u.w;
                 }
                 const int n = 32 * tb + 8 * g + 4 * lh;
-                const float4 bias = *reinterpret_cast<const float4*>(A.bu + n);
+                const float4 bias = bias4[g];
                 const float4 v = make_float4(fmaxf(a4.x + bias.x, 0.f), fmaxf(a4.y + bias.y, 0.f), fmaxf(a4.z + bias.z, 0.f), fmaxf(a4.w + bias.w, 0.f));
                 *reinterpret_cast<float4*>(&x_s[lj * XP + n]) = v;
-                if (ok) *reinterpret_cast<float4*>(A.x_new + (int64_t)(n0 + lj) * DN + n) = v;
             }
         }
     }
     __syncthreads();
-    if (!has_c) return;      // last step (no projections needed), or more waves than tiles
+    // x' rows leave from the LDS tile as whole lines (all waves; the accumulator layout would store 32 bytes per row and instruction)
+    for (int i = tid; i < 32 * (DN / 4); i += NTHR) {
+        const int nl = i / (DN / 4), c = (i - nl * (DN / 4)) * 4;
+        if (n0 + nl < N) *reinterpret_cast<float4*>(A.x_new + (int64_t)(n0 + nl) * DN + c) = *reinterpret_cast<const float4*>(&x_s[nl * XP + c]);
+    }
+    if (!A.P_next) return;   // last step: no projections needed (block-uniform)
 #ifdef MPNHIP_NODE_FWD_DEBUG
     if (A.debug & 4) return;
 #endif
+    // x' split ONCE into its three bf16 pieces, k block kb by wave kb (round 3's form: every wave split the whole tile into 96 registers
+    // of its own -- with the ring and the row staging that spilled); phase C reads the pieces as 16-byte units, conflict free
+    for (int kb = wave; kb < KB1; kb += NWV) {
+        const float* xr = &x_s[lj * XP + 16 * kb + 8 * lh];
+        const NSplit8 b = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xsp[(q * KB1 + kb) * 64 + lane] = __builtin_bit_cast(uint4, b.p[q]);
+    }
+    __syncthreads();
+    if (!has_c) return;      // more waves than tiles
 
     // ---- C. P' = P0 + Wx x': tiles wave, wave + NWV, ... ----------------------------------------------------------------------
-    NSplit8 bx[KB1];
+    float* const patch = smem + wave * PATCH;
+    // hipcc's scheduler, left alone, sinks all 24 weight-unit loads of the next tile below the tile's last MFMA and the wait-count pass
+    // then drains them in front of the next tile's first one: load latency and MFMAs in series, ~10k cycles per tile for 1.5k of MFMA
+    // (round 3's form of this loop; seen in the ISA in round 6).  The sched_barriers pin the intended order: MFMAs of k block kb, then
+    // the loads that refill its ring slot for the next tile.
+    const bool full = n0 + 32 <= N;
+    {
+        for (int it = 0; it < cnt; ++it) {
+            f32x16 acc;
+            // C-in: the P0 tile, rows -> patch -> accumulator layout
+#define NC_STAGE(P) *reinterpret_cast<float4*>(&patch[(er + 8 * P) * 36 + ec]) = pr##P;
+            NC_ROWS4(NC_STAGE)
+#undef NC_STAGE
 #pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) {
-        const float* xr = &x_s[lj * XP + 16 * kb + 8 * lh];
-        bx[kb] = nsplit8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4));
-    }
-    for (int it = 0; it < cnt; ++it) {
-        f32x16 acc;
+            for (int g = 0; g < 4; ++g) {
+                const float4 c = *reinterpret_cast<const float4*>(&patch[lj * 36 + 8 * g + 4 * lh]);
+                acc[4 * g + 0] = c.x; acc[4 * g + 1] = c.y; acc[4 * g + 2] = c.z; acc[4 * g + 3] = c.w;
+            }
+            ii = ii + 1 < cnt ? ii + 1 : 0;
+            const int tn = wave + NWV * ii;          // (after the last tile: the first one again -- unconditional loads)
+#define NC_LOAD(P) pr##P = *reinterpret_cast<const float4*>(A.P0 + rowoff##P + 32 * tn);
+            NC_ROWS4(NC_LOAD)
+#undef NC_LOAD
+            NSplit8 bq[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { acc[4 * g + 0] = cin[g].x; acc[4 * g + 1] = cin[g].y; acc[4 * g + 2] = cin[g].z; acc[4 * g + 3] = cin[g].w; }
-        ii = ii + 1 < cnt ? ii + 1 : 0;
-        const int tn = wave + NWV * ii;          // (after the last tile: the first one again -- unconditional loads)
+            for (int q = 0; q < 3; ++q) bq[0].p[q] = __builtin_bit_cast(bf16x8, xsp[(q * KB1 + 0) * 64 + lane]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cin[g] = *reinterpret_cast<const float4*>(p0r + 32 * tn + 8 * g);
+            for (int kb = 0; kb < KB1; ++kb) {
+                if (kb + 1 < KB1) {
 #pragma unroll
-        for (int kb = 0; kb < KB1; ++kb) {
+                    for (int q = 0; q < 3; ++q) bq[(kb + 1) & 1].p[q] = __builtin_bit_cast(bf16x8, xsp[(q * KB1 + kb + 1) * 64 + lane]);
+                    __builtin_amdgcn_sched_barrier(0);   // (the next block's pieces are requested before this block's six MFMAs, not after the fifth)
+                }
 #ifdef MPNHIP_NODE_FWD_DEBUG
-            if (A.debug & 8) {
+                if (A.debug & 8) {
 #pragma unroll
-                for (int u = 0; u < 3; ++u) asm volatile("" ::"v"(ringc[kb][u]), "v"(bx[kb].p[u]));
-            } else
+                    for (int u = 0; u < 3; ++u) asm volatile("" ::"v"(ringc[kb][u]), "v"(bq[kb & 1].p[u]));
+                } else
 #endif
-            nmfma6(acc, ringc[kb], bx[kb]);
+                nmfma6(acc, ringc[kb], bq[kb & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #ifdef MPNHIP_NODE_FWD_DEBUG
-            if (!(A.debug & 16))
+                if (!(A.debug & 16))
 #endif
-            ld_units(A.wx_img, (tn * KB1 + kb) * 3, lane, ringc[kb]);
-        }
+                ld_units(A.wx_img, (tn * KB1 + kb) * 3, lane, ringc[kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #ifdef MPNHIP_NODE_FWD_DEBUG
-        if (A.debug & 32) { t = tn; continue; }
+            if (A.debug & 32) { t = tn; continue; }
 #endif
-        if (ok) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(pnr + 32 * t + 8 * g) = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                *reinterpret_cast<float4*>(&patch[lj * 36 + 8 * g + 4 * lh]) = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+#define NC_STORE(P) { const float4 v = *reinterpret_cast<const float4*>(&patch[(er + 8 * P) * 36 + ec]); \
+                      if (full || rok##P) *reinterpret_cast<float4*>(A.P_next + rowoff##P + 32 * t) = v; }
+            NC_ROWS4(NC_STORE)
+#undef NC_STORE
+            __builtin_amdgcn_sched_barrier(0);
+            t = tn;
         }
-        t = tn;
     }
+#undef NC_ROWS4
 }
 
 

@@ -116,12 +116,13 @@ def test_cfgD_graphs_and_their_batch(precision):
         assert counts["segment_reduce_block3"] == c["L"], counts
 
 
-@pytest.mark.parametrize("agg,L,gain,precision", [("sum", 12, 0.7, "fp32"), ("sum", 12, 0.7, "fp32_split"), ("mean", 12, 1.0, "fp32"),
+@pytest.mark.parametrize("agg,L,gain,precision", [("sum", 6, 0.7, "fp32"), ("sum", 12, 0.7, "fp32_split"), ("mean", 8, 1.0, "fp32"),
                                                   ("max", 6, 1.0, "fp32"), ("max", 4, 1.0, "fp32_split"), ("sum", 5, 1.0, "fp32"),
                                                   ("sum", 12, 1.0, "fp32_split")])
 def test_cfgB(agg, L, gain, precision):
     """BASELINE.json configs[1] graph and widths (5k nodes / 50k edges / 128-d): the headline training workload
-    ('sum', 12 steps, O(1) logits as in the g11 fixture) in both precisions, mean over 12 steps, max, and sum with unit-gain
+    ('sum', 12 steps, O(1) logits as in the g11 fixture) in the default precision (6 steps on fp32 MFMAs: round 6 trimmed the host
+    float64 time of the suite, the twelve-step depth stays on the precision the headline runs), mean over 8 steps, max, and sum with unit-gain
     weights (each case differentiates the float64 oracle twice at this size: ~40 s of host time).  The last case IS the workload
     bench.py times: sum, 12 steps, unit-gain weights (logits to 3.7e7), the default precision (fp32_split: split chain kernels and
     the row-panel weight-gradient kernel)."""
