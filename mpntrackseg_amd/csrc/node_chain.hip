@@ -470,6 +470,13 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_bwd_kernel(NodeChainBwdAr
                 *reinterpret_cast<float4*>(&part_s[(((wave * DT + t) * 4 + g) * 64 + lane) * 4]) =
                     make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
     }
+    // (the ReLU source rows of phase 2 are requested in front of the barrier, not one by one behind it: written in place the compiler
+    // waits each of the four loads out before the next is issued -- four L2 round trips in a row on the block's critical path)
+    float4 xp[4];
+    if (wave < DT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[g] = *reinterpret_cast<const float4*>(A.x_prev + (int64_t)node * DN + 32 * wave + 8 * g + 4 * lh);
+    }
     __syncthreads();
 
     // ---- 2. dZn tile `wave` = (sum of the partials) (.) [x_prev > 0] -----------------------------------------------------
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(64 * NWV) void node_chain_bwd_kernel(NodeChainBwdAr
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
             const int n = 32 * wave + 8 * g + 4 * lh;
-            const float4 x = *reinterpret_cast<const float4*>(A.x_prev + (int64_t)node * DN + n);
+            const float4 x = xp[g];
             v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
             *reinterpret_cast<float4*>(&z_s[lj * XP + n]) = v;
             if (ok) *reinterpret_cast<float4*>(A.dZn + (int64_t)(n0 + lj) * DN + n) = fx4(v);
