@@ -611,7 +611,7 @@ def pmc_traffic(kernel_key, cfg_name, precision="fp32", mode="fwd"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/pmc_summary*.json, made by
     tools/pmc_summary.py with the MI355X guide's corrections; newest round first), or None.  cfg-B passes: the default training
     command; cfg-E (bf16): the forward command, and from round 4 the training command (pmc_summary_cfgE_train.json)."""
-    rounds = ("r05", "r04", "r03", "r02", "r01")
+    rounds = ("r06", "r05", "r04", "r03", "r02", "r01")
     if cfg_name == "E" and precision == "bf16":
         name = "pmc_summary_cfgE_train.json" if mode == "train" else "pmc_summary_cfgE.json"
         for rnd in rounds:
@@ -633,6 +633,25 @@ def pmc_traffic(kernel_key, cfg_name, precision="fp32", mode="fwd"):
             v = None
         if v is not None:
             return v
+    return None
+
+
+def pmc_counters(kernel_key, cfg_name, precision):
+    """SQ / TCC counter figures of the kernels the headline runs, from the committed rocprofv3 --pmc passes of the default command
+    (tools/pmc_cfgB.sh -> profiles/rNN/pmc_cfgB_split.json: one counter group per pass, kernel-trace only): MFMA-busy fraction
+    (SQ_VALU_MFMA_BUSY_CYCLES / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8)), SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, L2 hit rate.  cfg-B in the
+    split mode only (that is what the passes ran); None otherwise."""
+    if cfg_name != "B" or precision != "fp32_split":
+        return None
+    for rnd in ("r06",):
+        try:
+            v = json.load(open(os.path.join(REPO, "profiles", rnd, "pmc_cfgB_split.json"))).get(kernel_key)
+        except Exception:
+            v = None
+        if v:
+            out = {k: round(float(v[k]), 4) for k in ("mfma_busy_frac", "wait_inst_any_over_wave_cycles", "l2_hit_rate", "lds_bank_conflict_over_active_lds") if k in v}
+            out["source"] = "profiles/%s/pmc_cfgB_split.txt (committed rocprofv3 --pmc passes of the default command, not this run)" % rnd
+            return out
     return None
 
 
@@ -734,7 +753,20 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
                            "traffic": pmc_traffic("gemm_edge_l1", args.config), "avg_us": gemm_us,
                            "empty_event_pair_us": empty_us, "launches": gemm_n,
                            "algorithmic_flops": flops, "ms_per_step": gemm_us * c["L"] / 1e3}
-    if agg_n:
+    if agg_n and per_step.get("node_chain", 0) > 0:
+        # node_agg_fn runs inside node_chain_kernel (csrc/node_chain.hip: aggregate -> node update -> next step's projections): what that
+        # launch must move at least -- the messages once, the CSR offsets, the projection table in (P0) and out (P') for all steps but
+        # the last, x' out, and in training the aggregate rows kept for the backward
+        L_ = max(int(c["L"]), 1)
+        pw = 2 * he + 2 * hn
+        bytes_nc = E * dn * 4 + (2 * N + 1) * 4 + N * dn * 4 + (N * 2 * dn * 4 if mode == "train" else 0) + 2.0 * N * pw * 4 * (L_ - 1) / L_
+        ach = bytes_nc / (agg_us * 1e-6) / 1e9
+        res["roofline_aggregation"] = {"bound": "hbm", "kernel": "node_chain_kernel (node_agg_fn=%s over %d messages x %d-d + node update + next projections [%d x %d], one launch)"
+                                                                 % (args.agg, E, dn, N, pw),
+                                       "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "avg_us": agg_us,
+                                       "launches": agg_n, "algorithmic_bytes": bytes_nc, "ms_per_step": agg_us * L_ / 1e3,
+                                       "fused_into": "node_chain_kernel"}
+    elif agg_n:
         # M (dn s + 4) + N dn s per direction (+ CSR offsets), both directions in one launch
         bytes_agg = E * (dn * 4 + 4) + 2 * N * dn * 4 + (2 * N + 1) * 4
         ach = bytes_agg / (agg_us * 1e-6) / 1e9
@@ -840,6 +872,20 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
     for v in res.values():
         if isinstance(v, dict) and "traffic" in v:
             v["traffic_source"] = TRAFFIC_SOURCE if v["traffic"] else None
+    if mode == "train":
+        for key, kern in (("roofline_fwd_chain", "edge_chain_kernel"), ("roofline_bwd_chain", "edge_chain_bwd_kernel"), ("roofline_weight_grad", "wgrad_panel_kernel")):
+            ctr = pmc_counters(kern, args.config, args.precision)
+            if ctr and isinstance(res.get(key), dict):
+                res[key]["counters"] = ctr
+                res[key]["mfma_busy_frac"] = ctr.get("mfma_busy_frac")
+        if isinstance(res.get("roofline"), dict) and res["roofline"].get("dominant_of"):
+            top = max(res["roofline"]["dominant_of"], key=res["roofline"]["dominant_of"].get)
+            if isinstance(res.get(top), dict) and "counters" in res[top]:
+                res["roofline"]["counters"] = res[top]["counters"]
+                res["roofline"]["mfma_busy_frac"] = res[top].get("mfma_busy_frac")
+        ctr = pmc_counters("node_chain_kernel", args.config, args.precision)
+        if ctr and isinstance(res.get("roofline_aggregation"), dict):
+            res["roofline_aggregation"]["counters"] = ctr
     return res
 
 
@@ -855,7 +901,7 @@ def ordered_line(out):
             return r
         keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_us", "launches_per_step",
                 "ms_per_step", "algorithmic_bytes", "algorithmic_flops", "traffic_over_algorithmic", "mfma_frac_of_bf16_peak",
-                "dominant_of", "fused_into")
+                "dominant_of", "fused_into", "mfma_busy_frac")
         c = {k: r[k] for k in keep if k in r}
         if "kernel" in c:
             c["kernel"] = short(c["kernel"].split(":")[0].split(" (")[0], 60)
@@ -919,6 +965,8 @@ def ordered_line(out):
                 summary[k.replace("roofline_", "") + "_ms_per_step"] = round(r["ms_per_step"], 3)
             if r.get("traffic_over_algorithmic"):
                 summary[k.replace("roofline_", "") + "_traffic_over_algorithmic"] = round(r["traffic_over_algorithmic"], 2)
+            if r.get("mfma_busy_frac") is not None:
+                summary[k.replace("roofline_", "") + "_mfma_busy_frac"] = r["mfma_busy_frac"]
         elif isinstance(r, dict) and "fused_into" in r:
             summary[k.replace("roofline_", "") + "_fused_into"] = r["fused_into"]
     for name, v in (out.get("other_configs") or {}).items():

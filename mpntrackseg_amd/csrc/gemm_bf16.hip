@@ -636,10 +636,15 @@ extern "C" int mpnhip_time_linear_bf16(const mpnhip_linear_bf16_args* args, int 
     using namespace mpnhip;
     hipStream_t s = static_cast<hipStream_t>(stream);
     MPN_CHECK_ARG(args && avg_us && iters > 0, "time_linear_bf16: bad argument");
-    hipEvent_t t0, t1;
-    MPN_HIP(hipEventCreate(&t0));
-    MPN_HIP(hipEventCreate(&t1));
+    // (the first call validates the arguments and the shape BEFORE any event exists; the guard destroys both on every later exit)
     MPN_TRY(linear_bf16_call(args, s));
+    struct Events {
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        ~Events() { if (t0) (void)hipEventDestroy(t0); if (t1) (void)hipEventDestroy(t1); }
+    } ev;
+    MPN_HIP(hipEventCreate(&ev.t0));
+    MPN_HIP(hipEventCreate(&ev.t1));
+    const hipEvent_t t0 = ev.t0, t1 = ev.t1;
     MPN_HIP(hipEventRecord(t0, s));
     for (int i = 0; i < iters; ++i) MPN_TRY(linear_bf16_call(args, s));
     MPN_HIP(hipEventRecord(t1, s));
@@ -647,7 +652,5 @@ extern "C" int mpnhip_time_linear_bf16(const mpnhip_linear_bf16_args* args, int 
     float ms = 0.f;
     MPN_HIP(hipEventElapsedTime(&ms, t0, t1));
     *avg_us = ms * 1000.f / iters;
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     return MPNHIP_OK;
 }

@@ -517,7 +517,11 @@ static int run_step(const mpnhip_model& m, const Dims& d, const GraphView& g, co
         node_chain_image_shorts(d.dn, d.pw, &off_wx);
         NodeChainArgs a = {(int)N, d.dn, d.pw, m.agg, g.seg_ptr, b.M, io.nc_img, m.node.bias[0], io.nc_img + off_wx, io.P0,
                            io.last ? nullptr : io.P_next, io.x_new, save_acts ? b.AGG : nullptr};
-        return launch_node_chain(a, s);
+        // (profiled under the aggregation's kind: node_agg_fn runs inside this launch)
+        prof_begin(PROF_AGG, s);
+        const int st_nc = launch_node_chain(a, s);
+        prof_end(PROF_AGG, s);
+        return st_nc;
     }
     if (io.fuse_node) {
         MPN_TRY(node_step32(g, b.M, m.agg, m.node.weight[0], m.node.bias[0], io.x_new, save_acts ? b.AGG : nullptr, Wnode + io.kxa, d.kx,

@@ -587,10 +587,10 @@ int launch_node_chain(const NodeChainArgs& a_in, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.N + 31) / 32);
     // (MPNHIP_NODE_CHAIN_WAVES=4: round 3's four-wave blocks, A-B)
     static const int nwv = getenv("MPNHIP_NODE_CHAIN_WAVES") ? atoi(getenv("MPNHIP_NODE_CHAIN_WAVES")) : 8;
-    if (a.dn == 128 && nwv == 4) hipLaunchKernelGGL((node_chain_kernel<4, 4>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.dn == 128) hipLaunchKernelGGL((node_chain_kernel<4, 8>), dim3(blocks), dim3(512), 0, s, a);
-    else if (a.dn == 64 && nwv == 4) hipLaunchKernelGGL((node_chain_kernel<2, 4>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.dn == 64) hipLaunchKernelGGL((node_chain_kernel<2, 8>), dim3(blocks), dim3(512), 0, s, a);
+    if (a.dn == 128 && nwv == 4) MPN_LAUNCH_PROFILED((node_chain_kernel<4, 4>), dim3(blocks), dim3(256), s, a);
+    else if (a.dn == 128) MPN_LAUNCH_PROFILED((node_chain_kernel<4, 8>), dim3(blocks), dim3(512), s, a);
+    else if (a.dn == 64 && nwv == 4) MPN_LAUNCH_PROFILED((node_chain_kernel<2, 4>), dim3(blocks), dim3(256), s, a);
+    else if (a.dn == 64) MPN_LAUNCH_PROFILED((node_chain_kernel<2, 8>), dim3(blocks), dim3(512), s, a);
     else { set_error("node_chain: unsupported width %d", a.dn); return MPNHIP_ERR_UNSUPPORTED; }
     MPN_LAUNCH_CHECK();
     return MPNHIP_OK;

@@ -272,21 +272,37 @@ __global__ __launch_bounds__(R16_NT, 2) void wgrad_rows16_kernel(WpTable tab) {
 // projections, [1024 x 2048] encoder layers: GEMM-shaped, few rows and a wide output; the row-panel kernel's 128 x 128 tiles re-read
 // the fp32 operand rows 17 / 2 times there).  Every 1 KiB piece of a row must have a live lane (the counted vmcnt waits assume every DMA
 // instruction was issued): 256-column tiles are one piece per row, live for any non-empty tile.
+// the invariant behind the kernel's counted `s_waitcnt vmcnt(NPW * (NST - 2))`: every wave issues EVERY DMA instruction of a stage, i.e.
+// every 512-column (1 KiB) piece of the variant's [bo | bc] row image has at least one live 8-column chunk in EVERY tile of the job -- a
+// dead piece is skipped by the compiler's execz branch and the count under-waits.  Checked here, where the variant is
+// chosen: a shape that would break it goes to the row-panel kernel instead.
+static bool r16_pieces_live(int bo, int bc, int n_out, int k_in, int to, int tc) {
+    auto live = [](int width, int tiles, int b) {
+        const int last = width - (tiles - 1) * b;                 // live columns of the last (narrowest) tile
+        const int pieces = (b + 511) / 512;
+        return last >= 8 && last > 512 * (pieces - 1);            // ... reach into the tile's last piece
+    };
+    return live(n_out, to, bo) && live(k_in, tc, bc);
+}
+
 int r16_variant(int n_out, int k_in, int* tiles_o, int* tiles_c) {
     if (getenv("MPNHIP_NO_WGRAD_ROWS16") || n_out % 8 != 0 || k_in % 8 != 0) return -1;
-    *tiles_o = 1;
-    *tiles_c = 1;
-    if (n_out > 512 && n_out <= 640 && k_in <= 128) return 16;
-    if (n_out <= 128 && k_in > 512 && k_in <= 640) return 17;
-    if (n_out > 256 && n_out <= 448 && k_in <= 128) return 18;
-    if (n_out > 128 && n_out <= 256 && k_in > 256 && k_in <= 512) { *tiles_c = 2; return 19; }
+    const int bo[4] = {640, 128, 448, 256}, bc[4] = {128, 640, 128, 256};
+    int v = -1, to = 1, tc = 1;
     static const bool tiled = !getenv("MPNHIP_NO_WGRAD_ROWS16_TILED");
-    if (tiled && ((n_out > 640 && k_in > 128) || (n_out > 128 && k_in > 640))) {
-        *tiles_o = (n_out + 255) / 256;
-        *tiles_c = (k_in + 255) / 256;
-        return 19;
+    if (n_out > 512 && n_out <= 640 && k_in <= 128) v = 16;
+    else if (n_out <= 128 && k_in > 512 && k_in <= 640) v = 17;
+    else if (n_out > 256 && n_out <= 448 && k_in <= 128) v = 18;
+    else if (n_out > 128 && n_out <= 256 && k_in > 256 && k_in <= 512) { tc = 2; v = 19; }
+    else if (tiled && ((n_out > 640 && k_in > 128) || (n_out > 128 && k_in > 640))) {
+        to = (n_out + 255) / 256;
+        tc = (k_in + 255) / 256;
+        v = 19;
     }
-    return -1;
+    if (v < 0 || !r16_pieces_live(bo[v - 16], bc[v - 16], n_out, k_in, to, tc)) return -1;
+    *tiles_o = to;
+    *tiles_c = tc;
+    return v;
 }
 
 size_t r16_lds_bytes() {

@@ -472,7 +472,10 @@ def test_bf16_fused_chain_runs_and_agrees_with_the_unfused_products(d, L, agg, m
     # (two bf16 evaluations with different fp32 summation orders also differ where a pre-activation within rounding noise of zero
     # lands on the other side: measured 1e-3 .. 5.1e-3 over the four cases and two orders of the projections' product -- round 5's
     # [x0 | x] single product moved the 256-d case from 4.6e-3 to 5.1e-3; the statement is "far below the 2e-2 oracle tolerance")
-    assert rel_err(got, ref) < 8e-3 and rel_err(xg, xr) < 5e-3 and rel_err(eg, er) < 5e-3
+    # (the gate stays 5e-3; only the 256-d case, whose measured difference is 5.1e-3, gets 1.3 x that figure -- and BOTH
+    # evaluations must sit within the oracle tolerance, so a regression of either path cannot hide behind the other)
+    assert rel_err(ref, want) < 2e-2 and rel_err(xr, xw) < 2e-2 and rel_err(er, ew) < 2e-2
+    assert rel_err(got, ref) < (6.6e-3 if d == 256 else 5e-3) and rel_err(xg, xr) < 5e-3 and rel_err(eg, er) < 5e-3
 
 
 @pytest.mark.parametrize("agg", ["sum", "mean", "max"])
