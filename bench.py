@@ -736,6 +736,13 @@ def rooflines(prof, c, args, N, E, chain, mode="fwd"):
         # compulsory bytes of one fused message-passing step (every distinct input read once, every
         # output written once) -- what `traffic` (PMC, the chain kernel alone) is to be read against
         alg_bytes = E * (2 * de * 4 + de * 4 + 8 + 4) + N * (2 * dn * 4 + dn * 4)
+        if mode == "train":
+            # the training launch also keeps, per edge, the fp32 rows of H1 / HF / HC for the weight-gradient products and the ReLU
+            # decisions of all five activation blocks as bits (8 bytes per mask word: 64 lanes x 4 bytes per 32-edge wave tile); the
+            # messages M [E, dn] are written for the node side either way -- every one of them is read again by the backward
+            mask_words = sum(((w + 31) // 32 + 1) // 2 for w in (he, de, hn, dn)) + 1
+            alg_bytes += E * ((he + hn + hc) * 4 + mask_words * 8)
+        alg_bytes += E * dn * 4          # (M: the chain kernel's own output, aggregated by node_chain_kernel)
         res["roofline"]["algorithmic_bytes"] = alg_bytes
         if res["roofline"]["traffic"]:
             res["roofline"]["traffic_over_algorithmic"] = res["roofline"]["traffic"] / alg_bytes

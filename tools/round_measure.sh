@@ -34,10 +34,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg
 # HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_Et -- python $R/bench.py --config E --precision bf16 --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch_Et.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_Et -- python $R/bench.py --config E --precision bf16 --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write_Et.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_fetch32.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras > $O/pmc_write32.log 2>&1
+# (--no-forward-rate: the passes hold TRAINING launches only -- with the forward-rate leg the chain kernel's average mixed 276 inference
+# launches into 84 training ones, round 6)
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras --no-forward-rate > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras --no-forward-rate > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras --no-forward-rate > $O/pmc_fetch32.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-split-line --no-extras --no-forward-rate > $O/pmc_write32.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_E.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_E -- python $R/bench.py --config E --precision bf16 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_E.log 2>&1
 cd $R
