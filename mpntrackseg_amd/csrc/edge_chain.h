@@ -96,6 +96,9 @@ static inline size_t chain_mask_ints(int64_t E, int he, int de, int hn, int dn) 
 }
 bool edge_chain_supported(int he, int de, int hn, int dn, int hc, int k1a, int k1b);
 int launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);
+// the three-layer edge encoder at the wider models' dims in one launch (edge_chain.hip: k_edge_encoder_mfma); 1 launched / 0 not its shape / < 0 error
+int launch_edge_encoder_mfma(const float* x, const int* idx, int64_t rows, int in_dim, const float* const w[3], const float* const b[3],
+                             const int dims[3], float* h1_out, float* h2_out, float* y, hipStream_t s);
 // Split image of the logical operand A[k][n] = src[k * sk + n * sn] (zero beyond K x N), padded to Kp x Np (multiples of
 // 16 / 32): Kp Np 6 bytes at dst, in the unit order edge_chain.hip documents.  ntr_image / t0: the Np / 32 column tiles are
 // tiles t0 .. of an image with ntr_image tiles per k block (default: the whole image).

@@ -1213,6 +1213,111 @@ struct StampDump {
 static StampDump g_stamp_fwd, g_stamp_bwd;
 #endif
 
+// ---- the edge encoder at the wider models' dims (MLPGraphIndependent, mpn.py:355 / :164-178; mlp.py:27: three Linear + ReLU layers,
+// e.g. 6 -> 72 -> 72 -> 64 at d = 128) in ONE launch -- round 6.  As three launches of the GEMM kernels (K = 6 FMA kernel 20 us, two
+// [50000 x 72] products 20 + 16 us at cfg-B) the layers were all launch and latency: 14 MB of activations each.  Here a wave carries 32
+// edges through the three layers with the chain kernels' transposed products (edges on the MFMA lane dimension, a layer's accumulator tile
+// is the next layer's B operand; fp32 MFMAs -- exact fp32 in every operand form), the three weight matrices sit in LDS as zero-padded
+// [k][n] images built by the block itself from the nn.Linear [out][in] rows (68 KB at T = 3 / 3 / 2: two blocks per CU), hidden
+// activations leave only when the backward needs them.  T1 / T2 / TO = 32-wide tiles of the two hidden widths and the output.
+template <int T1, int T2, int TO>
+__global__ __launch_bounds__(256, 2) void k_edge_encoder_mfma(const float* __restrict__ x, const int* __restrict__ idx, int64_t rows, int in_dim,
+                                                              const float* __restrict__ w0, const float* __restrict__ b0, int h1,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1, int h2,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2, int od,
+                                                              float* __restrict__ h1_out, float* __restrict__ h2_out, float* __restrict__ y) {
+    constexpr int N1 = 32 * T1, N2 = 32 * T2, NO = 32 * TO;
+    __shared__ __attribute__((aligned(16))) float smem[16 * N1 + N1 * N2 + N2 * NO + N1 + N2 + NO];
+    float* const w0t = smem;                      // [16 k][N1]
+    float* const w1t = w0t + 16 * N1;             // [N1 k][N2]
+    float* const w2t = w1t + N1 * N2;             // [N2 k][NO]
+    float* const sb = w2t + N2 * NO;              // biases b0 | b1 | b2, zero-padded
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 31, lh = lane >> 5;
+    // images: zero, then the live [k < K][n < N] part transposed out of the row-major [N][K] weights (reads along k are contiguous)
+    for (int i = tid; i < 16 * N1 + N1 * N2 + N2 * NO + N1 + N2 + NO; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < h1 * in_dim; i += 256) { const int n = i / in_dim, k = i - n * in_dim; w0t[k * N1 + n] = w0[i]; }
+    for (int i = tid; i < h2 * h1; i += 256) { const int n = i / h1, k = i - n * h1; w1t[k * N2 + n] = w1[i]; }
+    for (int i = tid; i < od * h2; i += 256) { const int n = i / h2, k = i - n * h2; w2t[k * NO + n] = w2[i]; }
+    for (int i = tid; i < h1; i += 256) sb[i] = b0[i];
+    for (int i = tid; i < h2; i += 256) sb[N1 + i] = b1[i];
+    for (int i = tid; i < od; i += 256) sb[N1 + N2 + i] = b2[i];
+    __syncthreads();
+    const int64_t e_raw = (int64_t)blockIdx.x * 128 + wave * 32 + lj;
+    const bool ok = e_raw < rows;
+    const int64_t e = ok ? e_raw : rows - 1;
+    // layer-0 input in the accumulator layout: register r of lane (j, h) = feature (r & 3) + 8 (r >> 2) + 4 h of edge j (in_dim <= 16)
+    f32x16 src;
+    {
+        const float* xr = x + (int64_t)(idx ? idx[e] : e) * in_dim;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            src[r] = (r < 8 && k < in_dim) ? xr[k < in_dim ? k : 0] : 0.f;
+        }
+    }
+    // (tile counts as template arguments: a run-time bound would index the register arrays dynamically, i.e. put them in scratch memory)
+    auto bias_tiles = [&](auto nt_tag, f32x16* a, const float* b) {
+        constexpr int NT = decltype(nt_tag)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) set4(a[t], g, *reinterpret_cast<const float4*>(b + 32 * t + 8 * g + 4 * lh));
+    };
+    auto store_rows = [&](auto nt_tag, float* out, int width, const f32x16* a) {
+        constexpr int NT = decltype(nt_tag)::value;
+        float* o = out + e * width;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) strow<false>(o, 32 * t + 8 * g + 4 * lh, width, get4(a[t], g), ok);
+    };
+    using I1 = std::integral_constant<int, T1>;
+    using I2 = std::integral_constant<int, T2>;
+    using IO = std::integral_constant<int, TO>;
+    f32x16 a1[T1], a2[T2], a3[TO];
+    bias_tiles(I1{}, a1, sb);
+    chain_half<T1>(src, 0, a1, w0t, N1, 4 * lh * N1 + lj);
+#pragma unroll
+    for (int t = 0; t < T1; ++t) relu16(a1[t]);
+    if (h1_out) store_rows(I1{}, h1_out, h1, a1);
+    bias_tiles(I2{}, a2, sb + N1);
+#pragma unroll
+    for (int t = 0; t < T1; ++t) chain_tile<T2>(a1[t], a2, w1t, N2, 32 * t, 0, 4 * lh * N2 + lj);
+#pragma unroll
+    for (int t = 0; t < T2; ++t) relu16(a2[t]);
+    if (h2_out) store_rows(I2{}, h2_out, h2, a2);
+    bias_tiles(IO{}, a3, sb + N1 + N2);
+#pragma unroll
+    for (int t = 0; t < T2; ++t) chain_tile<TO>(a2[t], a3, w2t, NO, 32 * t, 0, 4 * lh * NO + lj);
+#pragma unroll
+    for (int t = 0; t < TO; ++t) relu16(a3[t]);
+    store_rows(IO{}, y, od, a3);
+}
+
+// 1: launched; 0: not this kernel's shape (three layers, in_dim <= 16, hidden widths <= 96, output <= 64, every width a multiple of 4,
+// 16-byte aligned outputs); < 0: error
+int launch_edge_encoder_mfma(const float* x, const int* idx, int64_t rows, int in_dim, const float* const w[3], const float* const b[3],
+                             const int dims[3], float* h1_out, float* h2_out, float* y, hipStream_t s) {
+    if (rows <= 0 || in_dim < 1 || in_dim > 16 || dims[0] > 96 || dims[1] > 96 || dims[2] > 64 || dims[0] % 4 || dims[1] % 4 || dims[2] % 4 ||
+        dims[0] < 4 || dims[1] < 4 || dims[2] < 4 || getenv("MPNHIP_NO_ENCODER_MFMA"))
+        return 0;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(y) || (h1_out && !al16(h1_out)) || (h2_out && !al16(h2_out))) return 0;
+    const int t1 = (dims[0] + 31) / 32, t2 = (dims[1] + 31) / 32, to = (dims[2] + 31) / 32;
+    const dim3 grid((unsigned)((rows + 127) / 128)), block(256);
+#define MPN_EE(A, B, C) hipLaunchKernelGGL((k_edge_encoder_mfma<A, B, C>), grid, block, 0, s, x, idx, rows, in_dim, w[0], b[0], dims[0], w[1], b[1], \
+                                          dims[1], w[2], b[2], dims[2], h1_out, h2_out, y)
+    if (t1 == 3 && t2 == 3 && to == 2) MPN_EE(3, 3, 2);
+    else if (t1 == 2 && t2 == 2 && to == 1) MPN_EE(2, 2, 1);
+    else if (t1 <= 3 && t2 <= 3 && to <= 2) MPN_EE(3, 3, 2);   // (narrower widths ride on the widest instantiation: zero-padded tiles)
+    else return 0;
+#undef MPN_EE
+    if (hipGetLastError() != hipSuccess) { set_error("edge encoder (mfma): launch failed"); return MPNHIP_ERR_HIP; }
+    return 1;
+}
+
 static int chain_variant(int he, int de, int hn, int dn) {
     const int t1 = (he + 31) / 32, t2 = (de + 31) / 32, tf = (hn + 31) / 32, td = (dn + 31) / 32;
     if (t1 == 10 && t2 == 2 && tf == 7 && td == 4) return 128;

@@ -605,6 +605,16 @@ static bool edge_encoder_fused(const mpnhip_mlp& m, const float* x, const int* i
                                int64_t rows, hipStream_t s, int* status) {
     *status = MPNHIP_OK;
     if (getenv("MPNHIP_NO_ENCODER_FUSION")) return false;
+    if (m.n_layers == 3 && rows > 0 && !(m.in_dim == 6 && m.out_dims[0] == 18 && m.out_dims[1] == 18 && m.out_dims[2] == 16)) {
+        // the wider models' encoder (e.g. 6 -> 72 -> 72 -> 64 at d = 128): the MFMA form (edge_chain.hip, k_edge_encoder_mfma)
+        const float* w[3] = {m.weight[0], m.weight[1], m.weight[2]};
+        const float* b[3] = {m.bias[0], m.bias[1], m.bias[2]};
+        const int dims[3] = {m.out_dims[0], m.out_dims[1], m.out_dims[2]};
+        const int r = launch_edge_encoder_mfma(x, idx, rows, m.in_dim, w, b, dims, keep_hidden ? hidden[0] : nullptr, keep_hidden ? hidden[1] : nullptr, y, s);
+        if (r < 0) *status = r;
+        if (r != 0) count_path(PC_EDGE_ENCODER);
+        return r != 0;
+    }
     if (m.n_layers != 3 || m.in_dim != 6 || m.out_dims[0] != 18 || m.out_dims[1] != 18 || m.out_dims[2] != 16 || rows <= 0) return false;
     count_path(PC_EDGE_ENCODER);
     hipLaunchKernelGGL((k_edge_encoder<6, 18, 18, 16>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, idx, rows, m.weight[0],
