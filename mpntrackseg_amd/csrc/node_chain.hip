@@ -5,14 +5,18 @@
 //   P'[n]   = P0[n] + Wx x'[n]          the next step's [Pr | Pc | Pf_out | Pf_in] rows (P0: the re-attached x0's share + biases)
 // for widths above the reference's (dn = 64 / 128; dn = 32 has k_node_step32, segment.hip).  Before: k_aggregate + two launches of
 // the GEMM kernel (7 + 11 + 22 us at cfg-B: 157 row tiles of a [5000 x 128] x [128 x 1088] product are four K steps each -- all
-// prologue and epilogue).  Here a block owns 32 nodes:
-//   A. aggregation: dn / 4 lanes per (node, direction) segment read whole message rows, 4 rows in flight, in segment order; the
-//      tile [32 nodes][2 dn] goes to LDS (and to HBM when the backward needs it);
-//   B. x' tile t by wave t: transposed product D^T[feature][node] (nodes on the MFMA's lane dimension), fp32 operands as three bf16
-//      pieces, six v_mfma_f32_32x32x16_bf16 per 16 contraction steps (edge_chain.hip section "split operands"); bias, ReLU; x' to LDS;
-//   C. every wave takes every 4th 32-feature tile of P': C-in = the gathered P0 tile, 6 x dn / 16 products, rows stored.
+// prologue and epilogue).  Here a block owns 32 nodes (round 6 form, 8 waves):
+//   A. aggregation: NWV lanes per (node, direction) segment read whole message rows, up to 4 rows in flight, in segment order; each lane
+//      splits its run of the aggregate row into three bf16 pieces and leaves them in LDS as MFMA B-operand units (the fp32 row goes
+//      to HBM from the registers when the backward needs it);
+//   B. x' tile (wave % DT), the contraction shared by the NWV / DT waves of a tile: transposed product D^T[feature][node] (nodes on the
+//      MFMA's lane dimension), six v_mfma_f32_32x32x16_bf16 per 16 contraction steps (edge_chain.hip section "split operands"); partial
+//      tiles meet in LDS in a fixed order; bias, ReLU; x' to LDS as fp32 rows (stored as whole lines) and, split once, as B-operand units;
+//   C. every wave takes every NWV-th 32-feature tile of P': C-in = the P0 tile, 6 x dn / 16 products; P0 in and P' out travel as whole
+//      128-byte lines through a per-wave [32][36] LDS patch; the order "MFMAs of k block kb, then refill kb's ring slot for the next
+//      tile" is pinned with sched_barriers (left alone hipcc drained the whole ring in front of every tile).
 // Weights: packed once per forward as 1 KiB MFMA A-operand units [output tile][k block][piece] (k_pack_node_units), read
-// straight from L2 by contiguous 16-byte-per-lane loads, four k blocks ahead -- every block reads the same 1 MB image.
+// straight from L2 by contiguous 16-byte-per-lane loads, a whole output tile ahead -- every block reads the same 1 MB image.
 #include "common.h"
 
 namespace mpnhip {
